@@ -1,0 +1,209 @@
+"""Parameter registry of GIMM-VFI-R: state_dict key names and shapes.
+
+The key set is part of the drop-in contract: reference checkpoints are loaded
+with ``model.load_state_dict(ckpt["state_dict"], strict=True)``
+(reference src/video_Nx.py:114-115), so every name below matches the
+reference module tree (gimmvfi_r.py:37-124, raft/raft.py:54-70,
+raft/extractor.py:122-166, raft/update.py:94-148, modules/fi_components.py).
+414 entries / 19,789,980 elements.
+
+``random_state_dict(seed)`` builds seeded random weights of this architecture
+for benchmarks and parity tests (no pretrained checkpoints exist offline).
+Norm statistics, PReLU slopes and the splat alphas are deliberately
+non-trivial so that BN folding / per-channel PReLU / alpha handling are tested.
+"""
+from collections import OrderedDict
+import math
+
+import torch
+
+
+def _conv(d, name, cout, cin, kh, kw=None):
+    kw = kh if kw is None else kw
+    d[name + ".weight"] = (cout, cin, kh, kw)
+    d[name + ".bias"] = (cout,)
+
+
+def _bn(d, name, c):
+    d[name + ".weight"] = (c,)
+    d[name + ".bias"] = (c,)
+    d[name + ".running_mean"] = (c,)
+    d[name + ".running_var"] = (c,)
+    d[name + ".num_batches_tracked"] = ()
+
+
+def _encoder(d, p, batchnorm, out_dim):
+    # raft/extractor.py:122-166
+    if batchnorm:
+        _bn(d, p + ".norm1", 64)
+    _conv(d, p + ".conv1", 64, 3, 7)
+    cin = 64
+    for li, dim in ((1, 64), (2, 96), (3, 128)):
+        for bi in (0, 1):
+            q = f"{p}.layer{li}.{bi}"
+            stride2 = bi == 0 and li > 1
+            _conv(d, q + ".conv1", dim, cin if bi == 0 else dim, 3)
+            _conv(d, q + ".conv2", dim, dim, 3)
+            if batchnorm:
+                _bn(d, q + ".norm1", dim)
+                _bn(d, q + ".norm2", dim)
+                if stride2:
+                    _bn(d, q + ".norm3", dim)
+            if stride2:
+                _conv(d, q + ".downsample.0", dim, cin, 1)
+                if batchnorm:
+                    _bn(d, q + ".downsample.1", dim)
+        cin = dim
+    _conv(d, p + ".conv2", out_dim, 128, 1)
+
+
+def _convrelu(d, p, cout, cin, k):
+    _conv(d, p + ".0", cout, cin, k)
+    d[p + ".1.weight"] = (cout,)
+
+
+def _resblock(d, p, c, side):
+    _convrelu(d, p + ".conv1", c, c, 3)
+    _convrelu(d, p + ".conv2", side, side, 3)
+    _convrelu(d, p + ".conv3", c, c, 3)
+    _convrelu(d, p + ".conv4", side, side, 3)
+    _conv(d, p + ".conv5", c, c, 3)
+    d[p + ".prelu.weight"] = (c,)
+
+
+def _amt_update(d, p):
+    # gimmvfi_r.py:113-124 -> modules/fi_components.py:157-197
+    _conv(d, p + ".convc1", 256, 648, 1)
+    _conv(d, p + ".convc2", 192, 256, 3)
+    _conv(d, p + ".convf1", 128, 4, 7)
+    _conv(d, p + ".convf2", 64, 128, 3)
+    _conv(d, p + ".conv", 188, 256, 3)
+    _conv(d, p + ".gru.0", 192, 320, 3)
+    _conv(d, p + ".gru.2", 192, 192, 3)
+    _conv(d, p + ".feat_head.0", 192, 192, 3)
+    _conv(d, p + ".feat_head.2", 128, 192, 3)
+    _conv(d, p + ".flow_head.0", 192, 192, 3)
+    _conv(d, p + ".flow_head.2", 4, 192, 3)
+
+
+def param_spec() -> "OrderedDict[str, tuple]":
+    d = OrderedDict()
+    d["g_filter"] = (1, 1, 1, 3, 3)
+    d["alpha_v"] = (1,)
+    d["alpha_fe"] = (1,)
+    fe = "flow_estimator"
+    _encoder(d, fe + ".fnet", False, 256)
+    _encoder(d, fe + ".cnet", True, 256)
+    u = fe + ".update_block"
+    _conv(d, u + ".encoder.convc1", 256, 324, 1)
+    _conv(d, u + ".encoder.convc2", 192, 256, 3)
+    _conv(d, u + ".encoder.convf1", 128, 2, 7)
+    _conv(d, u + ".encoder.convf2", 64, 128, 3)
+    _conv(d, u + ".encoder.conv", 126, 256, 3)
+    for n, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
+        for g in "zrq":
+            _conv(d, f"{u}.gru.conv{g}{n}", 128, 384, kh, kw)
+    _conv(d, u + ".flow_head.conv1", 256, 128, 3)
+    _conv(d, u + ".flow_head.conv2", 2, 256, 3)
+    _conv(d, u + ".mask.0", 256, 128, 3)
+    _conv(d, u + ".mask.2", 576, 256, 1)
+    _conv(d, "amt_last_cproj", 256, 128, 1)
+    _conv(d, "amt_second_last_cproj", 128, 96, 1)
+    _conv(d, "amt_fproj", 256, 256, 1)
+    p = "amt_init_decoder"
+    _convrelu(d, p + ".upsample.1", 64, 64, 5)
+    for i in (2, 3, 4):
+        _convrelu(d, f"{p}.upsample.{i}", 64, 64, 3)
+    _convrelu(d, p + ".upsample.5", 128, 64, 3)
+    _conv(d, p + ".upsample.6", 128, 128, 1)
+    _bn(d, p + ".upsample.7", 128)
+    _convrelu(d, p + ".convblock.0", 128, 272, 1)
+    for i in (1, 2, 3):
+        _resblock(d, f"{p}.convblock.{i}", 128, 64)
+    _conv(d, p + ".convblock.4", 133, 128, 3)
+    p = "amt_final_decoder"
+    _convrelu(d, p + ".upsample.2", 32, 8, 5)
+    for i in (3, 4, 5):
+        _convrelu(d, f"{p}.upsample.{i}", 32, 32, 3)
+    _convrelu(d, p + ".upsample.6", 64, 32, 3)
+    _conv(d, p + ".upsample.7", 64, 64, 1)
+    _bn(d, p + ".upsample.8", 64)
+    _convrelu(d, p + ".convblock.0", 256, 273, 3)
+    for i in (1, 2, 3):
+        _resblock(d, f"{p}.convblock.{i}", 256, 64)
+    _conv(d, p + ".convblock.4", 24, 256, 3)
+    _amt_update(d, "amt_update4_low")
+    _amt_update(d, "amt_update4_high")
+    _conv(d, "amt_comb_block.0", 18, 9, 7)
+    d["amt_comb_block.1.weight"] = (18,)
+    _conv(d, "amt_comb_block.2", 3, 18, 7)
+    _conv(d, "cnn_encoder.0", 16, 2, 3)
+    _conv(d, "cnn_encoder.1", 32, 16, 3)
+    for i in (3, 4, 5):
+        _conv(d, f"cnn_encoder.{i}.layers.0", 32, 32, 3)
+        _conv(d, f"cnn_encoder.{i}.layers.2", 32, 32, 3)
+    _conv(d, "cnn_encoder.7", 16, 32, 3)
+    _conv(d, "res_conv.0", 32, 64, 3)
+    _conv(d, "res_conv.1", 64, 32, 3)
+    _conv(d, "res_conv.3.layers.0", 64, 64, 3)
+    _conv(d, "res_conv.3.layers.2", 64, 64, 3)
+    _conv(d, "res_conv.5", 32, 64, 3)
+    d["hyponet.params_dict.linear_wb0"] = (36, 128)
+    for i in (1, 2, 3):
+        d[f"hyponet.params_dict.linear_wb{i}"] = (129, 128)
+    d["hyponet.params_dict.linear_wb4"] = (129, 2)
+    return d
+
+
+def random_state_dict(seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded random weights (CPU generator => identical on every machine).
+
+    conv weights/biases ~ U(+-gain/sqrt(fan_in)) (torch's default Conv2d init
+    range), SIREN-style INR weights (modules/utils.py:36-44)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+
+    def U(shape, lo, hi):
+        return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+    sd = OrderedDict()
+    spec = param_spec()
+    for name, shape in spec.items():
+        if name == "g_filter":
+            sd[name] = torch.tensor(
+                [[1 / 16, 1 / 8, 1 / 16], [1 / 8, 1 / 4, 1 / 8], [1 / 16, 1 / 8, 1 / 16]], dtype=torch.float32
+            ).reshape(1, 1, 1, 3, 3)
+        elif name == "alpha_v":
+            sd[name] = torch.tensor([0.8], dtype=torch.float32)
+        elif name == "alpha_fe":
+            sd[name] = torch.tensor([1.3], dtype=torch.float32)
+        elif name.endswith("num_batches_tracked"):
+            sd[name] = torch.tensor(0, dtype=torch.long)
+        elif name.endswith("running_mean"):
+            sd[name] = U(shape, -0.1, 0.1)
+        elif name.endswith("running_var"):
+            sd[name] = U(shape, 0.6, 1.4)
+        elif name.startswith("hyponet"):
+            fan_in = shape[0] - 1
+            first = name.endswith("wb0")
+            std = (1.0 / fan_in) if first else math.sqrt(6.0 / fan_in)
+            sd[name] = U(shape, -std, std)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            b = gain / math.sqrt(fan_in)
+            sd[name] = U(shape, -b, b)
+        elif name.endswith(".bias"):
+            wname = name[: -len("bias")] + "weight"
+            ws = spec.get(wname)
+            if ws is not None and len(ws) == 4:
+                b = gain / math.sqrt(ws[1] * ws[2] * ws[3])
+                sd[name] = U(shape, -b, b)
+            else:  # BatchNorm beta
+                sd[name] = U(shape, -0.1, 0.1)
+        elif name.endswith(".weight"):
+            # 1-D weight: BatchNorm gamma or PReLU slope
+            is_bn = (name[: -len("weight")] + "running_mean") in spec
+            sd[name] = U(shape, 0.8, 1.2) if is_bn else U(shape, 0.1, 0.4)
+        else:
+            raise KeyError(name)
+    return sd
