@@ -1,0 +1,52 @@
+"""Builds gimm-vfi_amd/lib/libgimmvfi_hip.so (gfx950) from csrc/*.hip with hipcc.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree
+to the GPU box.  Objects are cached by source mtime."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB = os.path.join(OUT_DIR, "libgimmvfi_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+def _deps():
+    return [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "gimmvfi_hip.h")]
+
+
+def _compile(src):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+    newest = max(os.path.getmtime(p) for p in [src] + _deps())
+    if os.path.exists(obj) and os.path.getmtime(obj) > newest:
+        return obj
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return obj
+
+
+def build(verbose=True):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build()

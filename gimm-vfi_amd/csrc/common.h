@@ -1,0 +1,90 @@
+// Shared device/host helpers for the GIMM-VFI HIP kernels (gfx950 / CDNA4 only).
+//
+// The same sources are also compiled for the host by tests/hostsim (a thread-per-lane
+// emulator used ONLY by the CPU test-suite to check index math before a GPU run);
+// GVFI_HOSTSIM selects that build.  The product library is always the hipcc build.
+#pragma once
+
+#ifdef GVFI_HOSTSIM
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include <stdint.h>
+#include <string.h>
+#include "../../include/gimmvfi_hip.h"
+
+#ifndef GVFI_HOSTSIM
+// simple = no LDS / barriers / cross-lane ops;  coop = anything else.  Identical on device.
+#define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+#define GVFI_LAUNCH_COOP(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+#endif
+
+typedef uint16_t bf16_t;
+
+__host__ __device__ __forceinline__ float bf2f(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+__host__ __device__ __forceinline__ bf16_t f2bf(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+
+// element traits: T = float or bf16_t
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VE = 4;  // elements per 16-byte vector
+    __host__ __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __host__ __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VE = 8;
+    __host__ __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __host__ __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// load / store one element of a tensor whose dtype is a runtime flag (f32 = 1)
+template <typename T> __host__ __device__ __forceinline__ float ld_any(const void* p, long i, int is_f32) {
+    return is_f32 ? ((const float*)p)[i] : Elem<T>::ld(((const T*)p) + i);
+}
+template <typename T> __host__ __device__ __forceinline__ void st_any(void* p, long i, int is_f32, float v) {
+    if (is_f32) ((float*)p)[i] = v; else Elem<T>::st(((T*)p) + i, v);
+}
+
+__device__ __forceinline__ float gvfi_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float apply_act(float v, int act, const float* slope, int c) {
+    switch (act) {
+        case GVFI_ACT_RELU: return v > 0.f ? v : 0.f;
+        case GVFI_ACT_LRELU: return v > 0.f ? v : 0.1f * v;
+        case GVFI_ACT_PRELU: return v > 0.f ? v : slope[c] * v;
+        case GVFI_ACT_SIGMOID: return gvfi_sigmoid(v);
+        case GVFI_ACT_TANH: return tanhf(v);
+        case GVFI_ACT_SIN: return sinf(v);
+        default: return v;
+    }
+}
+
+__host__ __device__ __forceinline__ int reflect_idx(int i, int n) {
+    // torch 'reflect' padding (no edge repeat); valid for -n < i < 2n-1
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define GVFI_DISPATCH_T(dtype, ...)                         \
+    do {                                                    \
+        if ((dtype) == GVFI_F32) { typedef float T; __VA_ARGS__; } \
+        else { typedef bf16_t T; __VA_ARGS__; }             \
+    } while (0)

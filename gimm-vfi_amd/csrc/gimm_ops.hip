@@ -1,0 +1,228 @@
+// GIMM (motion INR) side kernels: flow (un)normalisation, splatting metric, softmax-splat forward
+// warp (the reference's one native CUDA kernel on the path) and INR input packing.
+#include "common.h"
+
+#define GVFI_BLOCK 256
+static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK - 1) / GVFI_BLOCK)); }
+
+// ------------------------------------------------------------------ per-sample abs-max   modules/fi_utils.py:52-57
+// non-negative floats order like their bit patterns -> atomicMax on the raw bits
+__global__ void flow_absmax_kernel(const float* __restrict__ f01, const float* __restrict__ f10,
+                                   unsigned* __restrict__ scaler, long long per_b) {
+    const int b = blockIdx.y;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_b; i += (long long)gridDim.x * blockDim.x) {
+        m = fmaxf(m, fabsf(f01[b * per_b + i]));
+        m = fmaxf(m, fabsf(f10[b * per_b + i]));
+    }
+    union { float f; unsigned u; } c;
+    c.f = m;
+    atomicMax(scaler + b, c.u);
+}
+extern "C" int gvfi_flow_absmax(const float* f01, const float* f10, float* scaler, int B, int HW, void* stream) {
+    const long long per_b = 2LL * HW;
+    dim3 grid((unsigned)(per_b < 64 * GVFI_BLOCK ? (per_b + GVFI_BLOCK - 1) / GVFI_BLOCK : 64), (unsigned)B);
+    GVFI_LAUNCH_SIMPLE(flow_absmax_kernel, grid, dim3(GVFI_BLOCK), (hipStream_t)stream, f01, f10, (unsigned*)scaler,
+                       per_b);
+    return (int)hipGetLastError();
+}
+
+// n = (f/s + 1)/2 for [f01, -f10]   modules/fi_utils.py:52-60, gimmvfi_r.py:142-145
+template <typename T>
+__global__ void flow_normalize_kernel(const float* __restrict__ f01, const float* __restrict__ f10,
+                                      const float* __restrict__ scaler, T* __restrict__ act, int ld, int pad,
+                                      float* __restrict__ nflow, int B, long long HW) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (d, b, pix)
+    if (idx >= 2 * B * HW) return;
+    const long long pix = idx % HW;
+    const int n = (int)(idx / HW);
+    const int d = n / B, b = n % B;
+    const float s = scaler[b];
+    float v[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float f = d == 0 ? f01[((long long)b * HW + pix) * 2 + c] : -f10[((long long)b * HW + pix) * 2 + c];
+        v[c] = (f / s + 1.0f) / 2.0f;
+        if (nflow) nflow[(((long long)b * 2 + c) * 2 + d) * HW + pix] = v[c];
+    }
+    T* a = act + idx * ld;
+    for (int c = 0; c < pad; ++c) Elem<T>::st(a + c, c < 2 ? v[c] : 0.f);
+}
+extern "C" int gvfi_flow_normalize(const float* f01, const float* f10, const float* scaler, void* act, int ld, int pad,
+                                   float* nflow_out, int B, int H, int W, int dtype, void* stream) {
+    const long long HW = (long long)H * W, total = 2 * B * HW;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((flow_normalize_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, f01, f10, scaler, (T*)act, ld, pad, nflow_out, B,
+                                              HW));
+    return (int)hipGetLastError();
+}
+
+// flow_t = (n*2 - 1) * s   modules/fi_utils.py:63-64
+__global__ void flow_unnormalize_kernel(const float* __restrict__ ninr, const float* __restrict__ scaler,
+                                        float* __restrict__ flow_t, float* __restrict__ ninr_nchw, long long total,
+                                        long long HW) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, pix, c)
+    if (idx >= total) return;
+    const int c = (int)(idx & 1);
+    const long long bp = idx >> 1;
+    const long long b = bp / HW, pix = bp % HW;
+    const float v = ninr[idx];
+    flow_t[idx] = (v * 2.0f - 1.0f) * scaler[b];
+    if (ninr_nchw) ninr_nchw[(b * 2 + c) * HW + pix] = v;
+}
+extern "C" int gvfi_flow_unnormalize(const float* ninr, const float* scaler, float* flow_t, float* ninr_nchw, int B,
+                                     int HW, void* stream) {
+    const long long total = 2LL * B * HW;
+    GVFI_LAUNCH_SIMPLE(flow_unnormalize_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, ninr, scaler,
+                       flow_t, ninr_nchw, total, (long long)HW);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ splatting metric   gimmvfi_r.py:444-492
+// Z = 1/(1 + err*alpha_fe) + 1/(1 + std*alpha_v);  std = mean_c sqrt(clamp(G*f^2 - (G*f)^2, 1e-9)) with a
+// reflect-padded 3x3 filter;  err = mean_c | -warp(f_rev, f) - f |  (border warp, align_corners=True).
+__device__ __forceinline__ void sample_border2(const float* __restrict__ img, int H, int W, float fx, float fy,
+                                               float& o0, float& o1) {
+    fx = fminf(fmaxf(fx, 0.f), (float)(W - 1));
+    fy = fminf(fmaxf(fy, 0.f), (float)(H - 1));
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float ax = fx - x0f, ay = fy - y0f;
+    const bool x1ok = x0 + 1 < W, y1ok = y0 + 1 < H;
+    const float* p = img + ((long long)y0 * W + x0) * 2;
+    float w = (1.f - ax) * (1.f - ay);
+    o0 = w * p[0];
+    o1 = w * p[1];
+    if (x1ok) { w = ax * (1.f - ay); o0 += w * p[2]; o1 += w * p[3]; }
+    if (y1ok) { w = (1.f - ax) * ay; o0 += w * p[2 * W]; o1 += w * p[2 * W + 1]; }
+    if (x1ok && y1ok) { w = ax * ay; o0 += w * p[2 * W + 2]; o1 += w * p[2 * W + 3]; }
+}
+__global__ void splat_weights_kernel(const float* __restrict__ f01, const float* __restrict__ f10,
+                                     const float* __restrict__ g9, float alpha_v, float alpha_fe,
+                                     float* __restrict__ z0, float* __restrict__ z1, int B, int H, int W) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (d, b, y, x)
+    const long long HW = (long long)H * W;
+    if (idx >= 2 * B * HW) return;
+    const long long pix = idx % HW;
+    const int x = (int)(pix % W), y = (int)(pix / W);
+    const int n = (int)(idx / HW);
+    const int d = n / B, b = n % B;
+    const float* f = (d == 0 ? f01 : f10) + (long long)b * HW * 2;
+    const float* fr = (d == 0 ? f10 : f01) + (long long)b * HW * 2;
+    float sq[2] = {0.f, 0.f}, mn[2] = {0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = reflect_idx(y + ky - 1, H), xx = reflect_idx(x + kx - 1, W);
+            const float g = g9[ky * 3 + kx];
+            const float a = f[((long long)yy * W + xx) * 2 + 0], c = f[((long long)yy * W + xx) * 2 + 1];
+            sq[0] += g * (a * a);
+            sq[1] += g * (c * c);
+            mn[0] += g * a;
+            mn[1] += g * c;
+        }
+    const float v0 = sqrtf(fmaxf(sq[0] - mn[0] * mn[0], 1e-9f));
+    const float v1 = sqrtf(fmaxf(sq[1] - mn[1] * mn[1], 1e-9f));
+    const float var = (v0 + v1) / 2.0f;
+    const float fx = f[pix * 2 + 0], fy = f[pix * 2 + 1];
+    float w0, w1;
+    sample_border2(fr, H, W, (float)x + fx, (float)y + fy, w0, w1);
+    const float err = (fabsf(-w0 - fx) + fabsf(-w1 - fy)) / 2.0f;
+    const float z = 1.0f / (1.0f + err * alpha_fe) + 1.0f / (1.0f + var * alpha_v);
+    (d == 0 ? z0 : z1)[(long long)b * HW + pix] = z;
+}
+extern "C" int gvfi_splat_weights(const float* f01, const float* f10, const float* gfilt9, float alpha_v,
+                                  float alpha_fe, float* z0, float* z1, int B, int H, int W, void* stream) {
+    if (H < 2 || W < 2) return -2;
+    const long long total = 2LL * B * H * W;
+    GVFI_LAUNCH_SIMPLE(splat_weights_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, f01, f10, gfilt9,
+                       alpha_v, alpha_fe, z0, z1, B, H, W);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ softmax-splat forward   modules/softsplat.py:371-421
+// One thread per (source pixel, channel) of [lat*Z, Z] (channel fastest: the C+1 atomics of one source
+// pixel land in consecutive floats of the NHWC accumulator).  Targets outside the image are dropped,
+// non-finite targets are skipped (softsplat.py:384-385, 406-420).
+template <typename T>
+__global__ void softsplat_accum_kernel(const T* __restrict__ lat, int ldl, int C, const float* __restrict__ flow,
+                                       const float* __restrict__ z, const float* __restrict__ t, int one_minus_t,
+                                       float* __restrict__ acc, long long total, int H, int W) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int C1 = C + 1;
+    const int c = (int)(idx % C1);
+    const long long pix = idx / C1;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    const float ts = one_minus_t ? (1.0f - t[b]) : t[b];
+    const float fx = (float)x + flow[pix * 2 + 0] * ts;
+    const float fy = (float)y + flow[pix * 2 + 1] * ts;
+    if (!isfinite(fx) || !isfinite(fy)) return;
+    const float zz = z[pix];
+    const float v = c < C ? Elem<T>::ld(lat + pix * ldl + c) * zz : zz;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float wnw = ((float)x1 - fx) * ((float)y1 - fy);
+    const float wne = (fx - (float)x0) * ((float)y1 - fy);
+    const float wsw = ((float)x1 - fx) * (fy - (float)y0);
+    const float wse = (fx - (float)x0) * (fy - (float)y0);
+    float* o = acc + b * (long long)H * W * C1 + c;
+    const bool x0in = x0 >= 0 && x0 < W, x1in = x1 >= 0 && x1 < W;
+    const bool y0in = y0 >= 0 && y0 < H, y1in = y1 >= 0 && y1 < H;
+    if (x0in && y0in) atomicAdd(o + ((long long)y0 * W + x0) * C1, v * wnw);
+    if (x1in && y0in) atomicAdd(o + ((long long)y0 * W + x1) * C1, v * wne);
+    if (x0in && y1in) atomicAdd(o + ((long long)y1 * W + x0) * C1, v * wsw);
+    if (x1in && y1in) atomicAdd(o + ((long long)y1 * W + x1) * C1, v * wse);
+}
+extern "C" int gvfi_softsplat_accum(const void* lat, int ldl, int C, const float* flow, const float* z, const float* t,
+                                    int one_minus_t, float* acc, int B, int H, int W, int dtype, void* stream) {
+    const long long total = (long long)B * H * W * (C + 1);
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((softsplat_accum_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, (const T*)lat, ldl, C, flow, z, t, one_minus_t, acc,
+                                              total, H, W));
+    return (int)hipGetLastError();
+}
+// "linear-zeroeps": out = splat(x*Z) / splat(Z) with exact-zero denominators replaced by 1  softsplat.py:325-344
+template <typename T>
+__global__ void softsplat_normalize_kernel(const float* __restrict__ acc, int C, T* __restrict__ dst, int ldd,
+                                           long long total) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long pix = idx / C;
+    float nrm = acc[pix * (C + 1) + C];
+    if (nrm == 0.0f) nrm = 1.0f;
+    Elem<T>::st(dst + pix * ldd + c, acc[pix * (C + 1) + c] / nrm);
+}
+extern "C" int gvfi_softsplat_normalize(const float* acc, int C, void* dst, int ldd, long long npix, int dtype,
+                                        void* stream) {
+    const long long total = npix * C;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((softsplat_normalize_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, acc, C, (T*)dst, ldd, total));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ INR input   modules/hyponet.py:91-95
+template <typename T>
+__global__ void inr_pack_kernel(const T* __restrict__ lat, int ldl, int C, const float* __restrict__ coord,
+                                T* __restrict__ dst, int ldd, int pad, long long total) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % pad);
+    const long long pix = idx / pad;
+    float v = 0.f;
+    if (c < C) v = Elem<T>::ld(lat + pix * ldl + c);
+    else if (c < C + 3) v = coord[pix * 3 + (c - C)];
+    Elem<T>::st(dst + pix * ldd + c, v);
+}
+extern "C" int gvfi_inr_pack(const void* lat, int ldl, int C, const float* coord, void* dst, int ldd, int pad,
+                             long long npix, int dtype, void* stream) {
+    const long long total = npix * pad;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((inr_pack_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, (const T*)lat, ldl, C, coord, (T*)dst, ldd, pad,
+                                              total));
+    return (int)hipGetLastError();
+}

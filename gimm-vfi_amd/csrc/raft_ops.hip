@@ -1,0 +1,166 @@
+// RAFT-side HBM-bound kernels: correlation pyramid pooling, 4-level 9x9 bilinear correlation
+// lookup, coordinate grid, flow packing and the convex 8x flow upsampler.
+#include "common.h"
+
+#define GVFI_BLOCK 256
+static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK - 1) / GVFI_BLOCK)); }
+
+// ------------------------------------------------------------------ F.avg_pool2d(.., 2, stride=2)   raft/corr.py:139-142
+__global__ void avgpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, long long total, int h, int w,
+                                int ho, int wo) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % wo);
+    const int y = (int)((idx / wo) % ho);
+    const long long m = idx / ((long long)wo * ho);
+    const float* s = src + m * (long long)h * w + (long long)(2 * y) * w + 2 * x;
+    dst[idx] = 0.25f * (s[0] + s[1] + s[w] + s[w + 1]);
+}
+extern "C" int gvfi_avgpool2_f32(const float* src, float* dst, long long maps, int h, int w, void* stream) {
+    const int ho = h / 2, wo = w / 2;
+    const long long total = maps * ho * wo;
+    GVFI_LAUNCH_SIMPLE(avgpool2_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, src, dst, total, h, w, ho,
+                       wo);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ correlation lookup   raft/corr.py:144-165
+// Output channel  l*(2r+1)^2 + i*(2r+1) + j  samples level l of the query's correlation map at
+// (x = cx/2^l + (i-r),  y = cy/2^l + (j-r)):  the FIRST window index moves x (the reference adds
+// meshgrid(dy,dx) to (x,y) coordinates).  grid_sample(align_corners=True, zeros padding) semantics
+// including the normalise/un-normalise round trip of raft/utils/utils.py:66-80.
+template <typename T>
+__global__ void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
+                                   const float* __restrict__ l2, const float* __restrict__ l3,
+                                   const float* __restrict__ coords, T* __restrict__ out, int ldo, long long total,
+                                   int h2, int w2, int radius) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int win = 2 * radius + 1;
+    const int per_q = 4 * win * win;
+    const int ch = (int)(idx % per_q);
+    const long long q = idx / per_q;  // global query index (n*h*w + y*w + x)
+    const int l = ch / (win * win);
+    const int ij = ch - l * win * win;
+    const int i = ij / win, j = ij - i * win;
+    const int hl = h2 >> l, wl = w2 >> l;
+    const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + q * (long long)hl * wl;
+    const float sc = 1.0f / (float)(1 << l);
+    const float cx = coords[q * 2 + 0] * sc + (float)(i - radius);
+    const float cy = coords[q * 2 + 1] * sc + (float)(j - radius);
+    // bilinear_sampler: normalise to [-1,1] then grid_sample un-normalises (align_corners=True)
+    const float xn = 2.f * cx / (float)(wl - 1) - 1.f;
+    const float yn = 2.f * cy / (float)(hl - 1) - 1.f;
+    const float ix = ((xn + 1.f) * 0.5f) * (float)(wl - 1);
+    const float iy = ((yn + 1.f) * 0.5f) * (float)(hl - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float ax = ix - x0f, ay = iy - y0f;
+    float v = 0.f;
+    const bool xin0 = x0 >= 0 && x0 < wl, xin1 = x0 + 1 >= 0 && x0 + 1 < wl;
+    const bool yin0 = y0 >= 0 && y0 < hl, yin1 = y0 + 1 >= 0 && y0 + 1 < hl;
+    if (xin0 && yin0) v += (1.f - ax) * (1.f - ay) * base[(long long)y0 * wl + x0];
+    if (xin1 && yin0) v += ax * (1.f - ay) * base[(long long)y0 * wl + x0 + 1];
+    if (xin0 && yin1) v += (1.f - ax) * ay * base[(long long)(y0 + 1) * wl + x0];
+    if (xin1 && yin1) v += ax * ay * base[(long long)(y0 + 1) * wl + x0 + 1];
+    Elem<T>::st(out + q * ldo + ch, v);
+}
+extern "C" int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3,
+                                const float* coords, void* out, int ldo, int dtype, int N, int h, int w, int h2,
+                                int w2, int radius, void* stream) {
+    const int win = 2 * radius + 1;
+    const long long total = (long long)N * h * w * 4 * win * win;
+    if ((h2 >> 3) < 2 || (w2 >> 3) < 2) return -2;  // coarsest level must be >= 2x2 (reference divides by W-1)
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((corr_lookup_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, l0, l1, l2, l3, coords, (T*)out, ldo, total, h2, w2,
+                                              radius));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ coords grid   raft/utils/utils.py:83-88
+__global__ void coords_init_kernel(float* __restrict__ coords, long long total, int h, int w) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    coords[idx * 2 + 0] = (float)(idx % w);
+    coords[idx * 2 + 1] = (float)((idx / w) % h);
+}
+extern "C" int gvfi_coords_init(float* coords, int N, int h, int w, void* stream) {
+    const long long total = (long long)N * h * w;
+    GVFI_LAUNCH_SIMPLE(coords_init_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, coords, total, h, w);
+    return (int)hipGetLastError();
+}
+
+// flow = coords1 - coords0   raft/raft.py:148 ; written where the motion encoder / GRU read it
+template <typename T>
+__global__ void flow_pack_kernel(const float* __restrict__ coords1, T* __restrict__ dst0, int ld0, int pad0,
+                                 T* __restrict__ dst1, int ld1, long long total, int h, int w) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float fx = coords1[idx * 2 + 0] - (float)(idx % w);
+    const float fy = coords1[idx * 2 + 1] - (float)((idx / w) % h);
+    T* d0 = dst0 + idx * ld0;
+    Elem<T>::st(d0 + 0, fx);
+    Elem<T>::st(d0 + 1, fy);
+    for (int c = 2; c < pad0; ++c) Elem<T>::st(d0 + c, 0.f);
+    if (dst1) {
+        Elem<T>::st(dst1 + idx * ld1 + 0, fx);
+        Elem<T>::st(dst1 + idx * ld1 + 1, fy);
+    }
+}
+extern "C" int gvfi_flow_pack(const float* coords1, void* dst0, int ld0, int pad0, void* dst1, int ld1, int N, int h,
+                              int w, int dtype, void* stream) {
+    const long long total = (long long)N * h * w;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((flow_pack_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, coords1, (T*)dst0, ld0, pad0, (T*)dst1, ld1, total,
+                                              h, w));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ convex upsampling   raft/raft.py:86-97
+// out[n, 8y+i, 8x+j, c] = sum_k softmax_k(mask[n,y,x, k*64+i*8+j]) * 8*flow[n, y+k/3-1, x+k%3-1, c]
+template <typename T>
+__global__ void convex_upsample_kernel(const float* __restrict__ coords1, const void* __restrict__ mask, int ldm,
+                                       int mask_f32, float* __restrict__ out, long long total, int h, int w) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int W = 8 * w, H = 8 * h;
+    const int X = (int)(idx % W);
+    const int Y = (int)((idx / W) % H);
+    const long long n = idx / ((long long)W * H);
+    const int x = X >> 3, j = X & 7, y = Y >> 3, i = Y & 7;
+    const long long q = (n * h + y) * (long long)w + x;
+    float m[9];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        m[k] = ld_any<T>(mask, q * ldm + k * 64 + i * 8 + j, mask_f32);
+        mx = fmaxf(mx, m[k]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        m[k] = expf(m[k] - mx);
+        den += m[k];
+    }
+    float ox = 0.f, oy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;  // unfold zero padding
+        const long long qq = (n * h + yy) * (long long)w + xx;
+        const float fx = 8.f * (coords1[qq * 2 + 0] - (float)xx);
+        const float fy = 8.f * (coords1[qq * 2 + 1] - (float)yy);
+        const float wk = m[k] / den;
+        ox += wk * fx;
+        oy += wk * fy;
+    }
+    out[idx * 2 + 0] = ox;
+    out[idx * 2 + 1] = oy;
+}
+extern "C" int gvfi_convex_upsample(const float* coords1, const void* mask, int ldm, int mask_f32, float* flow_up,
+                                    int N, int h, int w, int dtype, void* stream) {
+    const long long total = (long long)N * 64 * h * w;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((convex_upsample_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, coords1, mask, ldm, mask_f32, flow_up, total, h, w));
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,190 @@
+// Frame-synthesis glue kernels (flow time-scaling, bidirectional lookup coordinates, multi-flow
+// warp/blend, decoder head fix-up, output finalisation) and library identity.
+#include "common.h"
+
+#define GVFI_BLOCK 256
+static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK - 1) / GVFI_BLOCK)); }
+
+// F(t->0) = -t * flow_t,  F(t->1) = (1-t) * flow_t     gimmvfi_r.py:239-240
+__global__ void flow_split_t_kernel(const float* __restrict__ flow_t, const float* __restrict__ t,
+                                    float* __restrict__ ft0, float* __restrict__ ft1, long long total, long long HW2) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float tt = t[idx / HW2];
+    const float f = flow_t[idx];
+    ft0[idx] = f * (-tt);
+    ft1[idx] = f * (1.0f - tt);
+}
+extern "C" int gvfi_flow_split_t(const float* flow_t, const float* t, float* ft0, float* ft1, int B, int HW,
+                                 void* stream) {
+    const long long total = 2LL * B * HW;
+    GVFI_LAUNCH_SIMPLE(flow_split_t_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, flow_t, t, ft0, ft1,
+                       total, 2LL * HW);
+    return (int)hipGetLastError();
+}
+
+// c0 = grid + fl1 * 1/(1-t),  c1 = grid + fl0 * 1/t     gimmvfi_r.py:494-507
+__global__ void lookup_coords_kernel(const float* __restrict__ fl0, const float* __restrict__ fl1,
+                                     const float* __restrict__ t, float* __restrict__ c0, float* __restrict__ c1,
+                                     long long total, int h, int w) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over pixels
+    if (idx >= total) return;
+    const float tt = t[idx / ((long long)h * w)];
+    const float s0 = 1.0f / tt, s1 = 1.0f / (1.0f - tt);
+    const float gx = (float)(idx % w), gy = (float)((idx / w) % h);
+    c0[idx * 2 + 0] = gx + fl1[idx * 2 + 0] * s1;
+    c0[idx * 2 + 1] = gy + fl1[idx * 2 + 1] * s1;
+    c1[idx * 2 + 0] = gx + fl0[idx * 2 + 0] * s0;
+    c1[idx * 2 + 1] = gy + fl0[idx * 2 + 1] * s0;
+}
+extern "C" int gvfi_lookup_coords(const float* fl0, const float* fl1, const float* t, float* c0, float* c1, int B,
+                                  int h, int w, void* stream) {
+    const long long total = (long long)B * h * w;
+    GVFI_LAUNCH_SIMPLE(lookup_coords_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, fl0, fl1, t, c0, c1,
+                       total, h, w);
+    return (int)hipGetLastError();
+}
+
+// bilinear sample of a 4-float-per-pixel image, border padding, align_corners=True (fi_utils.py:19-49)
+__device__ __forceinline__ void sample_border_rgb(const float* __restrict__ img, int H, int W, float fx, float fy,
+                                                  float o[3]) {
+    fx = fminf(fmaxf(fx, 0.f), (float)(W - 1));
+    fy = fminf(fmaxf(fy, 0.f), (float)(H - 1));
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float ax = fx - x0f, ay = fy - y0f;
+    const bool x1ok = x0 + 1 < W, y1ok = y0 + 1 < H;
+    const float* p = img + ((long long)y0 * W + x0) * 4;
+    float w = (1.f - ax) * (1.f - ay);
+    o[0] = w * p[0]; o[1] = w * p[1]; o[2] = w * p[2];
+    if (x1ok) { w = ax * (1.f - ay); o[0] += w * p[4]; o[1] += w * p[5]; o[2] += w * p[6]; }
+    if (y1ok) {
+        const float* q = p + 4LL * W;
+        w = (1.f - ax) * ay; o[0] += w * q[0]; o[1] += w * q[1]; o[2] += w * q[2];
+        if (x1ok) { w = ax * ay; o[0] += w * q[4]; o[1] += w * q[5]; o[2] += w * q[6]; }
+    }
+}
+
+// warp_w_mask + (x+1)/2 + clamp     gimmvfi_r.py:213-220, 259-261   (mask given pre-sigmoid)
+__global__ void warp_blend_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
+                                  const float* __restrict__ f0, const float* __restrict__ f1,
+                                  const float* __restrict__ mask, float* __restrict__ out, long long total, int H,
+                                  int W) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long HW = (long long)H * W;
+    const long long pix = idx % HW, b = idx / HW;
+    const int x = (int)(pix % W), y = (int)(pix / W);
+    float a[3], c[3];
+    sample_border_rgb(i0 + b * HW * 4, H, W, (float)x + f0[idx * 2], (float)y + f0[idx * 2 + 1], a);
+    sample_border_rgb(i1 + b * HW * 4, H, W, (float)x + f1[idx * 2], (float)y + f1[idx * 2 + 1], c);
+    const float m = gvfi_sigmoid(mask[idx]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = (m * a[k] + (1.f - m) * c[k] + 1.0f) / 2.0f;
+        out[(b * 3 + k) * HW + pix] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+}
+extern "C" int gvfi_warp_blend(const float* img4_0, const float* img4_1, const float* f0, const float* f1,
+                               const float* mask, float* out_nchw, int B, int H, int W, void* stream) {
+    const long long total = (long long)B * H * W;
+    GVFI_LAUNCH_SIMPLE(warp_blend_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, img4_0, img4_1, f0, f1,
+                       mask, out_nchw, total, H, W);
+    return (int)hipGetLastError();
+}
+
+// multi_flow_combine front half     modules/fi_components.py:57-88
+template <typename T>
+__global__ void combine_warps_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
+                                     const float* __restrict__ dec, int ldd, T* __restrict__ act, int lda, int pad,
+                                     float* __restrict__ mean4, long long total, int H, int W) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long HW = (long long)H * W;
+    const long long pix = idx % HW, b = idx / HW;
+    const int x = (int)(pix % W), y = (int)(pix / W);
+    const float* d = dec + idx * ldd;
+    float mean[3] = {0.f, 0.f, 0.f};
+    T* a = act + idx * lda;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float w0[3], w1[3];
+        sample_border_rgb(i0 + b * HW * 4, H, W, (float)x + d[2 * k], (float)y + d[2 * k + 1], w0);
+        sample_border_rgb(i1 + b * HW * 4, H, W, (float)x + d[6 + 2 * k], (float)y + d[6 + 2 * k + 1], w1);
+        const float m = d[12 + k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = m * w0[c] + (1.f - m) * w1[c] + d[15 + 3 * k + c];
+            mean[c] += v;
+            Elem<T>::st(a + 3 * k + c, v);
+        }
+    }
+    for (int c = 9; c < pad; ++c) Elem<T>::st(a + c, 0.f);
+    float* mo = mean4 + idx * 4;
+    mo[0] = mean[0] / 3.0f; mo[1] = mean[1] / 3.0f; mo[2] = mean[2] / 3.0f; mo[3] = 0.f;
+}
+extern "C" int gvfi_combine_warps(const float* img4_0, const float* img4_1, const float* dec, int ldd, void* act,
+                                  int lda, int pad, float* mean4, int B, int H, int W, int dtype, void* stream) {
+    const long long total = (long long)B * H * W;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((combine_warps_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, img4_0, img4_1, dec, ldd, (T*)act, lda, pad, mean4,
+                                              total, H, W));
+    return (int)hipGetLastError();
+}
+
+// decoder head     modules/fi_components.py:331-340
+__global__ void decoder_head_kernel(float* __restrict__ dec, int ldd, const float* __restrict__ flow0,
+                                    const float* __restrict__ flow1, const float* __restrict__ mask, long long total) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (pix, 15)
+    if (idx >= total) return;
+    const int c = (int)(idx % 15);
+    const long long pix = idx / 15;
+    float* d = dec + pix * ldd + c;
+    if (c < 6) *d += flow0[pix * 2 + (c & 1)];
+    else if (c < 12) *d += flow1[pix * 2 + (c & 1)];
+    else *d = gvfi_sigmoid(*d + mask[pix]);
+}
+extern "C" int gvfi_decoder_head(float* dec, int ldd, const float* flow0, const float* flow1, const float* mask,
+                                 long long npix, void* stream) {
+    const long long total = npix * 15;
+    GVFI_LAUNCH_SIMPLE(decoder_head_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, dec, ldd, flow0,
+                       flow1, mask, total);
+    return (int)hipGetLastError();
+}
+
+// imgt_pred = clamp((x + 1)/2, 0, 1)     modules/fi_components.py:92, gimmvfi_r.py:308
+__global__ void finalize_image_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, long long total,
+                                      long long HW) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, c, pix)
+    if (idx >= total) return;
+    const long long pix = idx % HW;
+    const int c = (int)((idx / HW) % 3);
+    const long long b = idx / (3 * HW);
+    const float v = (x[(b * HW + pix) * ld + c] + 1.0f) / 2.0f;
+    out[idx] = fminf(fmaxf(v, 0.f), 1.f);
+}
+extern "C" int gvfi_finalize_image(const float* x, int ld, float* out_nchw, int B, int H, int W, void* stream) {
+    const long long HW = (long long)H * W, total = 3 * HW * B;
+    GVFI_LAUNCH_SIMPLE(finalize_image_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, x, ld, out_nchw,
+                       total, HW);
+    return (int)hipGetLastError();
+}
+
+extern "C" const char* gvfi_version(void) {
+#ifdef GVFI_HOSTSIM
+    return "gimmvfi-hostsim (test emulator, not a product build)";
+#else
+    return "gimmvfi-hip gfx950 r1";
+#endif
+}
+extern "C" int gvfi_device_ok(void) {
+#ifdef GVFI_HOSTSIM
+    return 0;
+#else
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    return strstr(prop.gcnArchName, "gfx950") != nullptr ? 1 : 0;
+#endif
+}

@@ -1,0 +1,577 @@
+"""GIMM-VFI-R inference pipeline on the HIP kernels (NHWC, one launch list per forward).
+
+Mirrors reference generalizable_INR/gimmvfi_r.py:324-407 stage by stage; the stage names in
+``taps`` are those of oracle/gimmvfi_r_oracle.py so tests can compare stage boundaries.
+
+Work the reference performs but never uses is not executed (BASELINE.md "minimal" figure):
+the duplicate fnet pass of the second RAFT direction, the mask head + convex upsampling of RAFT
+iterations 1..19, and the t-independent decoder `upsample` stacks inside the timestep loop.
+"""
+import math
+
+import torch
+
+from . import lib as L
+from .ops import ConvLayer, Runtime, V, View
+
+A = L  # activation / epilogue constants
+
+
+def _fold_bn(w, b, sd, p, eps=1e-5):
+    g = sd[p + ".weight"].float()
+    beta = sd[p + ".bias"].float()
+    mean = sd[p + ".running_mean"].float()
+    var = sd[p + ".running_var"].float()
+    s = g / torch.sqrt(var + eps)
+    return w.float() * s.view(-1, 1, 1, 1), (b.float() - mean) * s + beta
+
+
+class Engine:
+    def __init__(self, rt: Runtime, sd):
+        self.rt = rt
+        sd = {k: v.detach() for k, v in sd.items()}
+        self.alpha_v = float(sd["alpha_v"].float().cpu().item())
+        self.alpha_fe = float(sd["alpha_fe"].float().cpu().item())
+        self.g9 = sd["g_filter"].float().reshape(9).contiguous().to(rt.device)
+        self.layers = {}
+        self._build(sd)
+
+    # ------------------------------------------------------------------ weight preparation
+    def _add(self, name, w, b, **kw):
+        self.layers[name] = ConvLayer(self.rt, w, b, **kw)
+
+    def _conv(self, sd, key, name=None, bn=None, slope=None, **kw):
+        w, b = sd[key + ".weight"], sd[key + ".bias"]
+        if bn is not None:
+            w, b = _fold_bn(w, b, sd, bn)
+        self._add(name or key, w, b, slope=None if slope is None else sd[slope], **kw)
+
+    def _build_encoder(self, sd, p, batchnorm):
+        # raft/extractor.py:122-166
+        self._conv(sd, p + ".conv1", bn=(p + ".norm1") if batchnorm else None, stride=2)
+        for li in (1, 2, 3):
+            for bi in (0, 1):
+                q = f"{p}.layer{li}.{bi}"
+                s2 = li > 1 and bi == 0
+                self._conv(sd, q + ".conv1", bn=(q + ".norm1") if batchnorm else None, stride=2 if s2 else 1)
+                self._conv(sd, q + ".conv2", bn=(q + ".norm2") if batchnorm else None)
+                if s2:
+                    self._conv(sd, q + ".downsample.0", bn=(q + ".downsample.1") if batchnorm else None, stride=2)
+
+    def _build_resblock(self, sd, p):
+        for i in (1, 2, 3, 4):
+            self._conv(sd, f"{p}.conv{i}.0", slope=f"{p}.conv{i}.1.weight")
+        self._conv(sd, p + ".conv5", slope=p + ".prelu.weight")
+
+    def _build_update(self, sd, p):
+        for k in ("convc1", "convc2", "convf1", "convf2", "conv", "gru.0", "gru.2", "feat_head.0", "feat_head.2",
+                  "flow_head.0", "flow_head.2"):
+            self._conv(sd, f"{p}.{k}")
+
+    def _build(self, sd):
+        fe = "flow_estimator"
+        self._build_encoder(sd, fe + ".fnet", False)
+        self._conv(sd, fe + ".fnet.conv2")
+        self._build_encoder(sd, fe + ".cnet", True)
+        w, b = sd[fe + ".cnet.conv2.weight"], sd[fe + ".cnet.conv2.bias"]
+        self._add("cnet.out_net", w[:128], b[:128])   # tanh half   raft/raft.py:134-136
+        self._add("cnet.out_inp", w[128:], b[128:])   # relu half
+        u = fe + ".update_block"
+        for k in ("encoder.convc1", "encoder.convc2", "encoder.convf1", "encoder.convf2", "encoder.conv",
+                  "flow_head.conv1", "flow_head.conv2", "mask.0", "mask.2"):
+            self._conv(sd, f"{u}.{k}")
+        for n in ("1", "2"):
+            wz, wr = sd[f"{u}.gru.convz{n}.weight"], sd[f"{u}.gru.convr{n}.weight"]
+            bz, br = sd[f"{u}.gru.convz{n}.bias"], sd[f"{u}.gru.convr{n}.bias"]
+            self._add(f"gru.zr{n}", torch.cat([wz, wr], 0), torch.cat([bz, br], 0))
+            self._conv(sd, f"{u}.gru.convq{n}", name=f"gru.q{n}")
+        for k in ("amt_last_cproj", "amt_second_last_cproj", "amt_fproj"):
+            self._conv(sd, k)
+        p = "amt_init_decoder"
+        for i in (1, 2, 3, 4, 5):
+            self._conv(sd, f"{p}.upsample.{i}.0", slope=f"{p}.upsample.{i}.1.weight")
+        self._conv(sd, p + ".upsample.6", bn=p + ".upsample.7")
+        self._conv(sd, p + ".convblock.0.0", slope=p + ".convblock.0.1.weight")
+        for i in (1, 2, 3):
+            self._build_resblock(sd, f"{p}.convblock.{i}")
+        w, b = sd[p + ".convblock.4.weight"], sd[p + ".convblock.4.bias"]
+        self._add("init.head5", w[:5], b[:5])     # [dflow0(2) dflow1(2) mask(1)]  fi_components.py:272-276
+        self._add("init.ft", w[5:], b[5:])
+        p = "amt_final_decoder"
+        for i in (2, 3, 4, 5, 6):
+            self._conv(sd, f"{p}.upsample.{i}.0", slope=f"{p}.upsample.{i}.1.weight")
+        self._conv(sd, p + ".upsample.7", bn=p + ".upsample.8")
+        self._conv(sd, p + ".convblock.0.0", slope=p + ".convblock.0.1.weight")
+        for i in (1, 2, 3):
+            self._build_resblock(sd, f"{p}.convblock.{i}")
+        self._conv(sd, p + ".convblock.4")
+        self._build_update(sd, "amt_update4_low")
+        self._build_update(sd, "amt_update4_high")
+        self._conv(sd, "amt_comb_block.0", slope="amt_comb_block.1.weight")
+        self._conv(sd, "amt_comb_block.2")
+        self._conv(sd, "cnn_encoder.0")
+        self._conv(sd, "cnn_encoder.1")
+        for i in (3, 4, 5):
+            self._conv(sd, f"cnn_encoder.{i}.layers.0")
+            self._conv(sd, f"cnn_encoder.{i}.layers.2")
+        self._conv(sd, "cnn_encoder.7", pad_mode=L.PAD_REFLECT)
+        self._conv(sd, "res_conv.0")
+        self._conv(sd, "res_conv.1")
+        self._conv(sd, "res_conv.3.layers.0")
+        self._conv(sd, "res_conv.3.layers.2")
+        self._conv(sd, "res_conv.5", pad_mode=L.PAD_REFLECT)
+        # INR: weights L2-normalised along fan_in once (constant at inference)  modules/hyponet.py:124-128
+        for i in range(5):
+            wb = sd[f"hyponet.params_dict.linear_wb{i}"].float()
+            w = torch.nn.functional.normalize(wb[:-1], dim=0)
+            b = wb[-1].clone()
+            if i == 4:
+                b = b + 0.5  # output_bias, hyponet.py:143
+            self._add(f"inr.{i}", w.t().reshape(w.shape[1], w.shape[0], 1, 1).contiguous(), b)
+
+    # ------------------------------------------------------------------ building blocks
+    def _enc(self, x, p, norm, B2):
+        """raft/extractor.py:168-220.  x: prepared images [2B,H,W,8]."""
+        rt, Ls = self.rt, self.layers
+        n, H, W = x.shape[:3]
+        inst = norm == "instance"
+
+        def cn(name, src, h, w, cout, res=None, final_relu=True, first=True):
+            # conv (+norm) + relu ; for the block's second conv: relu(res + relu(norm(conv)))
+            lay = Ls[name]
+            if inst:
+                raw = rt.act(n, h, w, cout)
+                rt.conv(lay, src, raw)
+                return rt.instnorm(raw, cout, relu=final_relu, res=res).t
+            out = rt.act(n, h, w, cout)
+            rt.conv(lay, src, out, act1=A.ACT_RELU if final_relu else A.ACT_NONE, res=res,
+                    act2=A.ACT_RELU if res is not None else A.ACT_NONE)
+            return out
+
+        h, w = H // 2, W // 2
+        y = cn(p + ".conv1", View(x, 0, 3), h, w, 64)
+        feats = []
+        cin = 64
+        for li, dim in ((1, 64), (2, 96), (3, 128)):
+            for bi in (0, 1):
+                q = f"{p}.layer{li}.{bi}"
+                s2 = li > 1 and bi == 0
+                if s2:
+                    h, w = h // 2, w // 2
+                y1 = cn(q + ".conv1", y, h, w, dim)
+                if s2:
+                    sc = cn(q + ".downsample.0", y, h, w, dim, final_relu=False)
+                else:
+                    sc = y
+                y = cn(q + ".conv2", y1, h, w, dim, res=sc)
+            feats.append(y)
+            cin = dim
+        return y, feats, (h, w)
+
+    def _corr_pyramids(self, fa, fb, n, h8, w8):
+        """All-pairs volume fa^T fb / sqrt(256) + 3 pooled levels (raft/corr.py:127-142,167-175)
+        as a grouped 1x1 'convolution' whose weights are the other frame's features."""
+        rt = self.rt
+        P8 = h8 * w8
+        vol = rt.f32(n * P8, P8)
+        out = View(vol.view(n, h8, w8, P8))
+        rt.conv(None, fa, out, groups=n, w_group_stride=P8 * fb.shape[-1], w_raw=fb, cout=P8,
+                out_scale=1.0 / math.sqrt(256.0))
+        pyr = [vol]
+        hh, ww = h8, w8
+        for _ in range(3):
+            pyr.append(rt.avgpool2(pyr[-1], n * P8, hh, ww))
+            hh, ww = hh // 2, ww // 2
+        return pyr
+
+    def _resblock(self, p, x, C, side=64):
+        """modules/fi_components.py:97-154 with the channel concatenations expressed as two-source convs."""
+        rt, Ls = self.rt, self.layers
+        n, h, w = x.shape[:3]
+        o1 = rt.act(n, h, w, C)
+        rt.conv(Ls[p + ".conv1.0"], x, o1, act1=A.ACT_PRELU)
+        s2 = rt.act(n, h, w, side)
+        rt.conv(Ls[p + ".conv2.0"], View(o1, C - side, side), s2, act1=A.ACT_PRELU)
+        o3 = rt.act(n, h, w, C)
+        rt.conv(Ls[p + ".conv3.0"], View(o1, 0, C - side), o3, x1=s2, act1=A.ACT_PRELU)
+        s4 = rt.act(n, h, w, side)
+        rt.conv(Ls[p + ".conv4.0"], View(o3, C - side, side), s4, act1=A.ACT_PRELU)
+        out = rt.act(n, h, w, C)
+        lay = Ls[p + ".conv5"]
+        rt.conv(lay, View(o3, 0, C - side), out, x1=s4, res=x, act2=A.ACT_PRELU, slope2=lay.slope)
+        return out
+
+    # ------------------------------------------------------------------ RAFT (both directions batched)
+    def _raft(self, imgA, B, iters, taps):
+        rt, Ls = self.rt, self.layers
+        n = 2 * B
+        H, W = imgA.shape[1:3]
+        fe = "flow_estimator"
+        f128, _, (h8, w8) = self._enc(imgA, fe + ".fnet", "instance", n)
+        fmap = rt.act(n, h8, w8, 256)
+        rt.conv(Ls[fe + ".fnet.conv2"], f128, fmap)
+        c128, cfeats, _ = self._enc(imgA, fe + ".cnet", "batch", n)
+        hA = rt.act(n, h8, w8, 128)
+        hB = rt.act(n, h8, w8, 128)
+        xbuf = rt.act(n, h8, w8, 256)     # [inp(128) | motion(126) | flow(2)]  raft/update.py:143-144
+        rt.conv(Ls["cnet.out_net"], c128, hA, act1=A.ACT_TANH)
+        rt.conv(Ls["cnet.out_inp"], c128, View(xbuf, 0, 128), act1=A.ACT_RELU)
+        # correlation pyramids: direction 0->1 for images [0,B), 1->0 for [B,2B)
+        pyr_a = self._corr_pyramids(fmap[:B], fmap[B:], B, h8, w8)
+        pyr_b = self._corr_pyramids(fmap[B:], fmap[:B], B, h8, w8)
+        if taps is not None:
+            taps["r01_fmap1"] = fmap[:B]
+            taps["r01_net0"] = hA[:B].clone()
+            taps["r01_inp"] = xbuf[:B, ..., :128].clone()
+            taps["r01_corr_l0"] = pyr_a[0]
+            taps["r01_corr_l3"] = pyr_a[3]
+        coords = rt.coords_init(n, h8, w8)
+        corrf = rt.act(n, h8, w8, 324, zero=True)
+        flow8 = rt.act(n, h8, w8, 2, zero=True)
+        c1 = rt.act(n, h8, w8, 256)
+        corflo = rt.act(n, h8, w8, 256)
+        f1 = rt.act(n, h8, w8, 128)
+        zbuf = rt.act(n, h8, w8, 128)
+        rh = rt.act(n, h8, w8, 128)
+        fh = rt.act(n, h8, w8, 256)
+        u = fe + ".update_block"
+        for it in range(iters):
+            rt.corr_lookup(pyr_a, coords[:B], corrf[:B], B, h8, w8, h8, w8)
+            rt.corr_lookup(pyr_b, coords[B:], corrf[B:], B, h8, w8, h8, w8)
+            rt.flow_pack(coords, flow8, View(xbuf, 254, 2))
+            rt.conv(Ls[u + ".encoder.convc1"], View(corrf, 0, 324), c1, act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.conv"], corflo, View(xbuf, 128, 126), act1=A.ACT_RELU)
+            hc, hn = hA, hB
+            for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73
+                rt.conv(Ls["gru.zr" + nn_], hc, zbuf, x1=xbuf, epi=A.EPI_GRU_ZR, y2=rh, aux0=hc)
+                rt.conv(Ls["gru.q" + nn_], rh, hn, x1=xbuf, epi=A.EPI_GRU_Q, aux0=hc, aux1=zbuf)
+                hc, hn = hn, hc
+            # after two passes the state is back in hA
+            rt.conv(Ls[u + ".flow_head.conv1"], hA, fh, act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".flow_head.conv2"], fh, View(coords), res=View(coords))   # coords1 += delta
+            if taps is not None and it in (0, iters - 1):
+                taps[f"r01_corr_it{it}"] = corrf[:B, ..., :324].clone()
+                taps[f"r01_net_it{it}"] = hA[:B].clone()
+                taps[f"r01_coords_it{it}"] = coords[:B].clone()
+        rt.conv(Ls[u + ".mask.0"], hA, fh, act1=A.ACT_RELU)
+        mask = rt.f32(n, h8, w8, 576)
+        rt.conv(Ls[u + ".mask.2"], fh, mask, out_scale=0.25)
+        flow_up = rt.convex_upsample(coords, mask)
+        return flow_up, fmap, cfeats, (h8, w8)
+
+    # ------------------------------------------------------------------ AMT-style update block
+    def _amt_update(self, p, net, flow4_f32, corr, B, h, w, st4, ft_4, low):
+        """modules/fi_components.py:199-222.  net: [B,h,w,128] (already down-sampled for the low block)."""
+        rt, Ls = self.rt, self.layers
+        c1 = rt.act(B, h, w, 256)
+        rt.conv(Ls[p + ".convc1"], View(corr, 0, 648), c1, act1=A.ACT_LRELU)
+        corflo = rt.act(B, h, w, 256)
+        rt.conv(Ls[p + ".convc2"], c1, View(corflo, 0, 192), act1=A.ACT_LRELU)
+        flo = rt.act(B, h, w, 4, zero=True)
+        rt.copy(View(flow4_f32, 0, 4), View(flo, 0, 4), 4)
+        f1 = rt.act(B, h, w, 128)
+        rt.conv(Ls[p + ".convf1"], View(flo, 0, 4), f1, act1=A.ACT_LRELU)
+        rt.conv(Ls[p + ".convf2"], f1, View(corflo, 192, 64), act1=A.ACT_LRELU)
+        inp = rt.act(B, h, w, 192)          # [inp(188) | flow(4)] ; net(128) is the second conv source
+        rt.conv(Ls[p + ".conv"], corflo, View(inp, 0, 188), act1=A.ACT_LRELU)
+        rt.copy(View(flow4_f32, 0, 4), View(inp, 188, 4), 4)
+        g0 = rt.act(B, h, w, 192)
+        rt.conv(Ls[p + ".gru.0"], inp, g0, x1=net, act1=A.ACT_LRELU)
+        out = rt.act(B, h, w, 192)
+        rt.conv(Ls[p + ".gru.2"], g0, out)
+        fh0 = rt.act(B, h, w, 192)
+        rt.conv(Ls[p + ".feat_head.0"], out, fh0, act1=A.ACT_LRELU)
+        lh0 = rt.act(B, h, w, 192)
+        rt.conv(Ls[p + ".flow_head.0"], out, lh0, act1=A.ACT_LRELU)
+        if low:
+            dnet = rt.act(B, h, w, 128)
+            rt.conv(Ls[p + ".feat_head.2"], fh0, dnet)
+            dflow = rt.f32(B, h, w, 4)
+            rt.conv(Ls[p + ".flow_head.2"], lh0, dflow)
+            up = rt.resize(dnet, 128, 2.0)
+            rt.copy(up, ft_4, 128, add=ft_4)
+            upf = rt.resize(dflow, 4, 2.0, mul=2.0)
+            rt.copy(upf, View(st4, 0, 4), 4, add=View(st4, 0, 4))
+        else:
+            rt.conv(Ls[p + ".feat_head.2"], fh0, ft_4, res=ft_4)
+            rt.conv(Ls[p + ".flow_head.2"], lh0, View(st4, 0, 4), res=View(st4, 0, 4))
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, img_xs, coord, t, iters=20, ds_factor=None, taps=None, want_aux=True):
+        rt, Ls, lib = self.rt, self.layers, self.rt.lib
+        st = rt.stream
+        assert isinstance(t, list) and isinstance(coord, list) and len(t) == len(coord)
+        img_xs = img_xs.to(device=rt.device, dtype=torch.float32).contiguous()
+        B, _, _, Hf, Wf = img_xs.shape
+        img4_full = None
+        if ds_factor is not None:
+            # gimmvfi_r.py:329-337
+            _, img4_full = rt.prep_images(img_xs)
+            img_xs = rt.resize_planes(img_xs, ds_factor)
+        imgA, img4 = rt.prep_images(img_xs)
+        H, W = img_xs.shape[-2:]
+        assert H % 8 == 0 and W % 8 == 0 and H >= 128 and W >= 128, "working resolution must be >=128 and /8"
+        n = 2 * B
+        HW = H * W
+
+        # ---- cal_bidirection_flow (gimmvfi_r.py:126-156)
+        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps)
+        f01, f10 = flow_up[:B], flow_up[B:]
+        h4, w4 = H // 4, W // 4
+        g = rt.act(n, h8, w8, 256)
+        rt.conv(Ls["amt_fproj"], fmap, g)
+        pyr = self._corr_pyramids(g[:B], g[B:], B, h8, w8)      # corr
+        pyrT = self._corr_pyramids(g[B:], g[:B], B, h8, w8)     # corr_T (raft/corr.py:32)
+        feat4 = rt.act(n, h4, w4, 128)
+        rt.conv(Ls["amt_second_last_cproj"], cfeats[1], feat4)
+        feat8 = rt.act(n, h8, w8, 256)
+        rt.conv(Ls["amt_last_cproj"], cfeats[2], feat8)
+        scaler = rt.f32(B, zero=True)
+        rt._chk(lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), B, HW, st()), "flow_absmax")
+        nfA = rt.act(n, H, W, 2, zero=True)
+        nflow = rt.f32(B, 2, 2, H, W)
+        rt._chk(lib.flow_normalize(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), nfA.data_ptr(), nfA.shape[-1],
+                                   nfA.shape[-1], nflow.data_ptr(), B, H, W, rt.dtype, st()), "flow_normalize")
+        raft_flow = torch.stack([rt.nhwc_to_nchw(f01, 2), rt.nhwc_to_nchw(f10, 2)], dim=2)
+
+        # ---- predict_flow (gimmvfi_r.py:158-211): splat metric + latent encoder
+        z0, z1 = rt.f32(B, H, W), rt.f32(B, H, W)
+        rt._chk(lib.splat_weights(f01.data_ptr(), f10.data_ptr(), self.g9.data_ptr(), self.alpha_v, self.alpha_fe,
+                                  z0.data_ptr(), z1.data_ptr(), B, H, W, st()), "splat_weights")
+        e0 = rt.act(n, H, W, 16)
+        rt.conv(Ls["cnn_encoder.0"], View(nfA, 0, 2), e0)
+        e = rt.act(n, H, W, 32)
+        rt.conv(Ls["cnn_encoder.1"], e0, e, act1=A.ACT_LRELU)
+        tA = rt.act(n, H, W, 32)
+        for i in (3, 4, 5):
+            rt.conv(Ls[f"cnn_encoder.{i}.layers.0"], e, tA, act1=A.ACT_LRELU)
+            e2 = rt.act(n, H, W, 32)
+            rt.conv(Ls[f"cnn_encoder.{i}.layers.2"], tA, e2, res=e, act2=A.ACT_LRELU if i == 5 else A.ACT_NONE)
+            e = e2
+        latcat = rt.act(B, H, W, 64)   # [pl0 | pl1 | splat0 | splat1]  gimmvfi_r.py:187-192
+        rt.conv(Ls["cnn_encoder.7"], e[:B], View(latcat, 0, 16))
+        rt.conv(Ls["cnn_encoder.7"], e[B:], View(latcat, 16, 16))
+        if taps is not None:
+            taps["f01"], taps["f10"] = f01, f10
+            taps["w1"], taps["w2"] = z0, z1
+            taps["pl0"] = latcat[..., 0:16].clone()
+            taps["feat0_4"], taps["feat0_8"] = feat4[:B], feat8[:B]
+
+        # ---- t-independent decoder front ends, hoisted out of the timestep loop
+        up8 = self._init_upsample(feat8)      # [2B,h4,w4,128]
+        up4 = self._final_upsample(feat4)     # [2B,H,W,64]
+        i0q = rt.resize(View(img4[:B], 0, 4), 4, 0.25)   # fi_components.py:265-267
+        i1q = rt.resize(View(img4[B:], 0, 4), 4, 0.25)
+
+        out = {k: [] for k in ("imgt_pred", "other_pred", "flowt0_pred", "flowt1_pred", "ninrflow", "flowt")}
+        for i, (c, cur_t) in enumerate(zip(coord, t)):
+            assert isinstance(c, tuple) and c[1] is None, "sub-sampled coordinates are a training feature"
+            cg = c[0].to(device=rt.device, dtype=torch.float32).contiguous()
+            tv = cur_t.to(device=rt.device, dtype=torch.float32).reshape(-1).contiguous()
+            assert cg.shape[0] == B and cg.shape[1] == 1 and cg.shape[-1] == 3 and tv.numel() == B
+            Hc, Wc = cg.shape[2], cg.shape[3]
+            # softmax splatting of the two latents to time t   gimmvfi_r.py:171-193
+            for d, (fl, zz) in enumerate(((f01, z0), (f10, z1))):
+                acc = rt.f32(B, H, W, 17, zero=True)
+                rt._chk(lib.softsplat_accum(View(latcat, 16 * d, 16).ptr, latcat.shape[-1], 16, fl.data_ptr(),
+                                            zz.data_ptr(), tv.data_ptr(), d, acc.data_ptr(), B, H, W, rt.dtype, st()),
+                        "softsplat_accum")
+                rt._chk(lib.softsplat_normalize(acc.data_ptr(), 16, View(latcat, 32 + 16 * d, 16).ptr,
+                                                latcat.shape[-1], B * HW, rt.dtype, st()), "softsplat_normalize")
+            r0 = rt.act(B, H, W, 32)
+            rt.conv(Ls["res_conv.0"], latcat, r0)
+            r1 = rt.act(B, H, W, 64)
+            rt.conv(Ls["res_conv.1"], r0, r1, act1=A.ACT_LRELU)
+            r2 = rt.act(B, H, W, 64)
+            rt.conv(Ls["res_conv.3.layers.0"], r1, r2, act1=A.ACT_LRELU)
+            r3 = rt.act(B, H, W, 64)
+            rt.conv(Ls["res_conv.3.layers.2"], r2, r3, res=r1, act2=A.ACT_LRELU)
+            lat = rt.act(B, H, W, 32)
+            rt.conv(Ls["res_conv.5"], r3, lat, res=View(latcat, 32, 32))
+            if taps is not None:
+                taps[f"t{i}_splat0"] = latcat[..., 32:48].clone()
+                taps[f"t{i}_latent"] = lat
+            # INR   modules/hyponet.py:71-146
+            if (Hc, Wc) != (H, W):
+                lat = rt.resize(lat, 32, None, size=(Hc, Wc)).t
+            xin = rt.act(B, Hc, Wc, 35, zero=True)
+            rt._chk(lib.inr_pack(lat.data_ptr(), lat.shape[-1], 32, cg.data_ptr(), xin.data_ptr(), xin.shape[-1],
+                                 xin.shape[-1], B * Hc * Wc, rt.dtype, st()), "inr_pack")
+            hcur = View(xin, 0, 35)
+            for li in range(4):
+                hn = rt.act(B, Hc, Wc, 128)
+                rt.conv(Ls[f"inr.{li}"], hcur, hn, act1=A.ACT_SIN)
+                hcur = hn
+            ninr = rt.f32(B, Hc, Wc, 2)
+            rt.conv(Ls["inr.4"], hcur, ninr)
+            flow_t = rt.f32(B, Hc, Wc, 2)
+            ninr_nchw = rt.f32(B, 2, 1, Hc, Wc)
+            rt._chk(lib.flow_unnormalize(ninr.data_ptr(), scaler.data_ptr(), flow_t.data_ptr(), ninr_nchw.data_ptr(),
+                                         B, Hc * Wc, st()), "flow_unnormalize")
+            out["ninrflow"].append(ninr_nchw)
+            ft_nchw = rt.nhwc_to_nchw(flow_t, 2)
+            out["flowt"].append(ft_nchw.squeeze())     # B==1 squeeze quirk, gimmvfi_r.py:364-372
+            assert (Hc, Wc) == (H, W), "frame synthesis needs the INR grid at the working resolution"
+            pred, f0p, f1p, oth = self._synthesize(B, H, W, Hf, Wf, img4, img4_full, flow_t, tv, up8, up4, i0q, i1q,
+                                                   pyr, pyrT, taps, f"t{i}_", want_aux)
+            out["imgt_pred"].append(pred)
+            out["flowt0_pred"].append(f0p)
+            out["flowt1_pred"].append(f1p)
+            out["other_pred"].append(oth)
+        out["raft_flow"] = raft_flow
+        out["nflow"] = nflow
+        return out
+
+    def _init_upsample(self, feat8):
+        # modules/fi_components.py:234-244
+        rt, Ls = self.rt, self.layers
+        p = "amt_init_decoder.upsample"
+        x = rt.pixel_shuffle2(feat8, 64)
+        n, h, w = x.shape[:3]
+        for i, co in ((1, 64), (2, 64), (3, 64), (4, 64), (5, 128)):
+            y = rt.act(n, h, w, co)
+            rt.conv(Ls[f"{p}.{i}.0"], x, y, act1=A.ACT_PRELU)
+            x = y
+        y = rt.act(n, h, w, 128)
+        rt.conv(Ls[p + ".6"], x, y, act1=A.ACT_RELU)
+        return y
+
+    def _final_upsample(self, feat4):
+        # modules/fi_components.py:284-295
+        rt, Ls = self.rt, self.layers
+        p = "amt_final_decoder.upsample"
+        x = rt.pixel_shuffle2(feat4, 32)
+        x = rt.pixel_shuffle2(x, 8)
+        n, h, w = x.shape[:3]
+        for i, co in ((2, 32), (3, 32), (4, 32), (5, 32), (6, 64)):
+            y = rt.act(n, h, w, co)
+            rt.conv(Ls[f"{p}.{i}.0"], View(x, 0, x.shape[-1] if i > 2 else 8), y, act1=A.ACT_PRELU)
+            x = y
+        y = rt.act(n, h, w, 64)
+        rt.conv(Ls[p + ".7"], x, y, act1=A.ACT_RELU)
+        return y
+
+    def _synthesize(self, B, H, W, Hf, Wf, img4, img4_full, flow_t, tv, up8, up4, i0q, i1q, pyr, pyrT, taps, tag,
+                    want_aux):
+        """gimmvfi_r.py:222-322."""
+        rt, Ls, lib = self.rt, self.layers, self.rt.lib
+        st = rt.stream
+        HW = H * W
+        h4, w4, h8, w8 = H // 4, W // 4, H // 8, W // 8
+        ft0, ft1 = rt.f32(B, H, W, 2), rt.f32(B, H, W, 2)
+        rt._chk(lib.flow_split_t(flow_t.data_ptr(), tv.data_ptr(), ft0.data_ptr(), ft1.data_ptr(), B, HW, st()),
+                "flow_split_t")
+        # quarter-resolution flows  gimmvfi_r.py:242-244 ; fl4in = [F_t0/4, F_t1/4, 0..] doubles as the head residual
+        fl4in = rt.f32(B, h4, w4, 8, zero=True)
+        rt.resize(ft0, 2, 0.25, mul=0.25, out=View(fl4in, 0, 2))
+        rt.resize(ft1, 2, 0.25, mul=0.25, out=View(fl4in, 2, 2))
+        # ---- NewInitDecoder  fi_components.py:255-276
+        f_in = rt.act(B, h4, w4, 272)
+        rt.warp(up8[:B], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
+        rt.warp(up8[B:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
+        rt.copy(View(fl4in, 0, 4), View(f_in, 256, 4), 4)
+        rt.copy(View(i0q.t, 0, 3), View(f_in, 260, 3), 3)
+        rt.copy(View(i1q.t, 0, 3), View(f_in, 263, 3), 3)
+        rt.warp(View(i0q.t, 0, 3), 3, View(fl4in, 0, 2), View(f_in, 266, 3))
+        rt.warp(View(i1q.t, 0, 3), 3, View(fl4in, 2, 2), View(f_in, 269, 3))
+        p = "amt_init_decoder.convblock"
+        x = rt.act(B, h4, w4, 128)
+        rt.conv(Ls[p + ".0.0"], f_in, x, act1=A.ACT_PRELU)
+        for i in (1, 2, 3):
+            x = self._resblock(f"{p}.{i}", x, 128)
+        st4 = rt.f32(B, h4, w4, 8, zero=True)    # [flowt0_4(2) flowt1_4(2) mask_4(1) pad]
+        rt.conv(Ls["init.head5"], x, View(st4, 0, 5), res=View(fl4in, 0, 5))
+        ft_4 = rt.act(B, h4, w4, 128)
+        rt.conv(Ls["init.ft"], x, ft_4)
+        mask_4 = View(st4, 4, 1)
+        if taps is not None:
+            taps[tag + "init_flow0_4"] = st4[..., 0:2].clone()
+            taps[tag + "init_ft_4"] = ft_4.clone()
+        others = []
+        if want_aux:
+            # warp_w_mask at scale 4  gimmvfi_r.py:213-220, 259-261
+            f0u = rt.resize(View(st4, 0, 2), 2, 4.0, mul=4.0)
+            f1u = rt.resize(View(st4, 2, 2), 2, 4.0, mul=4.0)
+            m4u = rt.resize(mask_4, 1, 4.0)
+            iw4 = rt.f32(B, 3, H, W)
+            rt._chk(lib.warp_blend(img4[:B].data_ptr(), img4[B:].data_ptr(), f0u.t.data_ptr(), f1u.t.data_ptr(),
+                                   m4u.t.data_ptr(), iw4.data_ptr(), B, H, W, st()), "warp_blend")
+            others = [iw4]
+        # ---- _amt_corr_scale_lookup (downsample=2)  gimmvfi_r.py:494-507
+        fl0 = rt.resize(View(st4, 0, 2), 2, 0.5, mul=0.5).t
+        fl1 = rt.resize(View(st4, 2, 2), 2, 0.5, mul=0.5).t
+        c0, c1 = rt.f32(B, h8, w8, 2), rt.f32(B, h8, w8, 2)
+        rt._chk(lib.lookup_coords(fl0.data_ptr(), fl1.data_ptr(), tv.data_ptr(), c0.data_ptr(), c1.data_ptr(), B, h8,
+                                  w8, st()), "lookup_coords")
+        corr = rt.act(B, h8, w8, 648, zero=True)
+        rt.corr_lookup(pyr, c0, View(corr, 0, 324), B, h8, w8, h8, w8)
+        rt.corr_lookup(pyrT, c1, View(corr, 324, 324), B, h8, w8, h8, w8)
+        flow_lr = rt.f32(B, h8, w8, 4)
+        rt.copy(fl0, View(flow_lr, 0, 2), 2)
+        rt.copy(fl1, View(flow_lr, 2, 2), 2)
+        net_lr = rt.resize(ft_4, 128, 0.5).t
+        self._amt_update("amt_update4_low", net_lr, flow_lr, corr, B, h8, w8, st4, ft_4, low=True)
+        corr_up = rt.resize(View(corr, 0, 648), 648, 2.0).t
+        flow4 = rt.f32(B, h4, w4, 4)
+        rt.copy(View(st4, 0, 4), flow4, 4)
+        self._amt_update("amt_update4_high", ft_4, flow4, corr_up, B, h4, w4, st4, ft_4, low=False)
+        if taps is not None:
+            taps[tag + "upd_flow0_4"] = st4[..., 0:2].clone()
+            taps[tag + "upd_ft_4"] = ft_4.clone()
+        # ---- NewMultiFlowDecoder  fi_components.py:307-340
+        fl0u = rt.resize(View(st4, 0, 2), 2, 4.0, mul=4.0).t
+        fl1u = rt.resize(View(st4, 2, 2), 2, 4.0, mul=4.0).t
+        mku = rt.resize(mask_4, 1, 4.0).t
+        fin = rt.act(B, H, W, 273, zero=True)
+        rt.resize(ft_4, 128, 4.0, out=View(fin, 0, 128))
+        rt.warp(up4[:B], 64, fl0u, View(fin, 128, 64))
+        rt.warp(up4[B:], 64, fl1u, View(fin, 192, 64))
+        rt.copy(fl0u, View(fin, 256, 2), 2)
+        rt.copy(fl1u, View(fin, 258, 2), 2)
+        rt.copy(mku, View(fin, 260, 1), 1)
+        rt.copy(View(img4[:B], 0, 3), View(fin, 261, 3), 3)
+        rt.copy(View(img4[B:], 0, 3), View(fin, 264, 3), 3)
+        rt.warp(View(img4[:B], 0, 3), 3, fl0u, View(fin, 267, 3))
+        rt.warp(View(img4[B:], 0, 3), 3, fl1u, View(fin, 270, 3))
+        p = "amt_final_decoder.convblock"
+        x = rt.act(B, H, W, 256)
+        rt.conv(Ls[p + ".0.0"], View(fin, 0, 273), x, act1=A.ACT_PRELU)
+        for i in (1, 2, 3):
+            x = self._resblock(f"{p}.{i}", x, 256)
+        dec = rt.f32(B, H, W, 24)
+        rt.conv(Ls[p + ".4"], x, dec)
+        rt._chk(lib.decoder_head(dec.data_ptr(), 24, fl0u.data_ptr(), fl1u.data_ptr(), mku.data_ptr(), B * HW, st()),
+                "decoder_head")
+        if taps is not None:
+            taps[tag + "final_flow0_1"] = dec[..., 0:6].clone()
+            taps[tag + "final_mask"] = dec[..., 12:15].clone()
+            taps[tag + "final_res"] = dec[..., 15:24].clone()
+        i0f, i1f = img4[:B], img4[B:]
+        if img4_full is not None:
+            # gimmvfi_r.py:294-303
+            inv = Hf / H
+            decf = rt.f32(B, Hf, Wf, 24)
+            rt.resize(View(dec, 0, 12), 12, inv, mul=inv, out=View(decf, 0, 12))
+            rt.resize(View(dec, 12, 12), 12, inv, out=View(decf, 12, 12))
+            dec = decf
+            i0f, i1f = img4_full[:B], img4_full[B:]
+        # ---- multi_flow_combine + comb_block  fi_components.py:57-94, gimmvfi_r.py:305-308
+        cw = rt.act(B, Hf, Wf, 9, zero=False)
+        mean4 = rt.f32(B, Hf, Wf, 4)
+        rt._chk(lib.combine_warps(i0f.data_ptr(), i1f.data_ptr(), dec.data_ptr(), 24, cw.data_ptr(), cw.shape[-1],
+                                  cw.shape[-1], mean4.data_ptr(), B, Hf, Wf, rt.dtype, st()), "combine_warps")
+        cb = rt.act(B, Hf, Wf, 18, zero=True)
+        rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU)
+        o4 = rt.f32(B, Hf, Wf, 4)
+        rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3))
+        pred = rt.f32(B, 3, Hf, Wf)
+        rt._chk(lib.finalize_image(o4.data_ptr(), 4, pred.data_ptr(), B, Hf, Wf, st()), "finalize_image")
+        f01 = rt.nhwc_to_nchw(View(dec, 0, 6), 6).reshape(B, 3, 2, Hf, Wf)
+        f11 = rt.nhwc_to_nchw(View(dec, 6, 6), 6).reshape(B, 3, 2, Hf, Wf)
+        f04 = rt.nhwc_to_nchw(View(st4, 0, 2), 2)
+        f14 = rt.nhwc_to_nchw(View(st4, 2, 2), 2)
+        return pred, [f01, f04], [f11, f14], others

@@ -1,0 +1,115 @@
+"""``GIMMVFI_R``: drop-in module for reference generalizable_INR/gimmvfi_r.py:34-442.
+
+Same constructor config fields, same ``forward(img_xs, coord, t, iters, ds_factor)`` /
+``sample_coord_input`` signatures and return dict, and the same 414 state_dict keys (so
+``load_state_dict(ckpt["state_dict"], strict=True)`` of reference checkpoints works,
+src/video_Nx.py:114-115).  Differences by design:
+
+* inference only (no autograd graph); compute runs on the HIP kernels of
+  libgimmvfi_hip.so via ``Engine`` -- there is no torch/CPU fallback;
+* the constructor does not read ``pretrained_ckpt/raft-things.pth`` (reference
+  raft/__init__.py:7-24): RAFT weights are part of the GIMM-VFI checkpoint loaded afterwards;
+* ``precision``: "bf16" (default, MFMA bf16 with fp32 accumulation; flows, coordinates,
+  correlation volumes and splat sums stay fp32) or "fp32" (exact-f32 MFMA validation mode).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .engine import Engine
+from .ops import Runtime
+from .params import param_spec, random_state_dict
+
+
+class _Node(nn.Module):
+    """Pure container; mirrors the reference module tree so state_dict keys match."""
+
+
+_BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+class GIMMVFI_R(nn.Module):
+    def __init__(self, config=None, precision=None):
+        super().__init__()
+        self.config = config
+        self.raft_iter = 20  # gimmvfi_r.py:41 (config.raft_iter is ignored by the reference too)
+        self.precision = precision or os.environ.get("GIMMVFI_PRECISION", "bf16")
+        self.coord_range = (-1.0, 1.0)
+        if config is not None:
+            cr = config["coord_range"] if isinstance(config, dict) else getattr(config, "coord_range", None)
+            if cr is not None:
+                self.coord_range = (float(cr[0]), float(cr[1]))
+        sd0 = random_state_dict(0)
+        for name, shape in param_spec().items():
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            val = sd0[name].clone()
+            if parts[-1] in _BUFFER_SUFFIXES:
+                node.register_buffer(parts[-1], val)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
+        self._engine = None
+        self._engine_key = None
+
+    # ---- engine cache invalidation: weights are folded/packed for the kernels lazily
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._engine = None
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._engine = None
+        return r
+
+    def engine(self, device=None, runtime=None):
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        key = (str(device), self.precision, id(runtime))
+        if self._engine is None or self._engine_key != key:
+            if runtime is None:
+                if device.type != "cuda":
+                    raise RuntimeError(
+                        "GIMMVFI_R runs only on an MI355X through libgimmvfi_hip.so: move the model and inputs to "
+                        "'cuda' (there is no CPU fallback)"
+                    )
+                runtime = Runtime(L.get(), self.precision, device)
+            self._engine = Engine(runtime, self.state_dict())
+            self._engine_key = key
+        return self._engine
+
+    # ---- reference API -------------------------------------------------------------------
+    def forward(self, img_xs, coord=None, t=None, iters=None, ds_factor=None):
+        assert isinstance(t, list)
+        assert isinstance(coord, list)
+        assert len(t) == len(coord)
+        iters = self.raft_iter  # gimmvfi_r.py:127-132 hard-codes 20
+        return self.engine(img_xs.device).forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
+
+    def sample_coord_input(self, batch_size, s_shape, t_ids, coord_range=None, upsample_ratio=1.0, device=None):
+        """modules/coord_sampler.py:15-43,73-91 (list t_ids) -> (B, T, H', W', 3) ordered (t, y, x).
+        Pure index generation (host plumbing, no arithmetic of the hot path)."""
+        assert device is not None
+        assert coord_range is None
+        lo, hi = self.coord_range
+        assert isinstance(t_ids, list)
+        cs = [torch.tensor(t_ids, device=device, dtype=torch.float32) / 1.0]
+        for n in s_shape:
+            n = int(n * upsample_ratio)
+            c = (0.5 + torch.arange(n, device=device)) / n
+            cs.append(lo + (hi - lo) * c)
+        g = torch.stack(torch.meshgrid(*cs, indexing="ij"), dim=-1)
+        return g.unsqueeze(0).repeat(batch_size, 1, 1, 1, 1)
+
+    def compute_psnr(self, preds, targets, reduction="mean"):
+        # gimmvfi_r.py:412-426
+        assert reduction in ["mean", "sum", "none"]
+        b = preds.shape[0]
+        mse = torch.reshape((preds - targets) ** 2, (b, -1)).mean(dim=-1)
+        psnr = -10 * torch.log10(mse)
+        return psnr.mean() if reduction == "mean" else (psnr.sum() if reduction == "sum" else psnr)

@@ -1,0 +1,287 @@
+"""Host-side launch wrappers over the C ABI (include/gimmvfi_hip.h).
+
+torch is used here only for device memory (allocation, views) and the current
+HIP stream; every arithmetic operation of the path is a HIP kernel behind the
+C ABI.  ``Runtime`` carries the library handle, the element type of the
+activation tensors (bf16 fast path / fp32 validation path) and the device.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+
+def roundup(x, m):
+    return (x + m - 1) // m * m
+
+
+class View:
+    """A channel slice [coff, coff+c) of an NHWC tensor t[N,H,W,ld]."""
+
+    __slots__ = ("t", "coff", "c")
+
+    def __init__(self, t, coff=0, c=None):
+        self.t = t
+        self.coff = coff
+        self.c = (t.shape[-1] - coff) if c is None else c
+
+    @property
+    def ld(self):
+        return self.t.shape[-1]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + self.coff * self.t.element_size()
+
+    @property
+    def is_f32(self):
+        return 1 if self.t.dtype == torch.float32 else 0
+
+    @property
+    def npix(self):
+        return self.t.numel() // self.t.shape[-1]
+
+    def imgs(self, a, b):
+        """Sub-batch [a, b) of images (leading dimension)."""
+        return View(self.t[a:b], self.coff, self.c)
+
+
+def V(t, coff=0, c=None):
+    return t if isinstance(t, View) else View(t, coff, c)
+
+
+class ConvLayer:
+    """Packed weights [Cout][KH][KW][cin_pad] (+ float bias / PReLU slope) of one convolution."""
+
+    def __init__(self, rt, w, b, stride=1, pad=None, pad_mode=L.PAD_ZEROS, slope=None, cin_pad=None):
+        cout, cin, kh, kw = w.shape
+        cp = roundup(cin, rt.VE) if cin_pad is None else cin_pad
+        pk = torch.zeros(cout, kh, kw, cp, dtype=torch.float32, device=w.device)
+        pk[..., :cin] = w.detach().float().permute(0, 2, 3, 1)
+        self.w = pk.to(rt.tdtype).contiguous().to(rt.device)
+        self.b = None if b is None else b.detach().float().contiguous().to(rt.device)
+        self.slope = None if slope is None else slope.detach().float().contiguous().to(rt.device)
+        self.cout, self.cin, self.cin_pad, self.kh, self.kw = cout, cin, cp, kh, kw
+        self.stride = stride
+        self.pad = (kh // 2, kw // 2) if pad is None else pad
+        self.pad_mode = pad_mode
+
+
+class Runtime:
+    def __init__(self, lib, precision, device):
+        self.lib = lib
+        self.precision = precision
+        if precision == "fp32":
+            self.dtype, self.tdtype, self.VE = L.F32, torch.float32, 4
+        elif precision == "bf16":
+            self.dtype, self.tdtype, self.VE = L.BF16, torch.bfloat16, 8
+        else:
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision}")
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.n_launch = 0
+
+    # ------------------------------------------------------------------ memory
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else 0
+
+    def cp(self, c):
+        return roundup(c, self.VE)
+
+    def act(self, n, h, w, c, zero=None):
+        """Activation tensor in the runtime element type with padded channel pitch."""
+        cpad = self.cp(c)
+        z = (cpad != c) if zero is None else zero
+        f = torch.zeros if z else torch.empty
+        return f((n, h, w, cpad), dtype=self.tdtype, device=self.device)
+
+    def f32(self, *shape, zero=False):
+        return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.device)
+
+    def _chk(self, rc, name):
+        self.n_launch += 1
+        if rc != 0:
+            raise RuntimeError(f"gvfi_{name} failed with code {rc}")
+
+    # ------------------------------------------------------------------ convolution
+    def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
+             slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
+             w_group_stride=0, w_raw=None, cout=None, tile=0):
+        x0 = V(x0)
+        out = V(out)
+        p = L.ConvParams()
+        p.dtype = self.dtype
+        n, h, w_ = x0.t.shape[0], x0.t.shape[1], x0.t.shape[2]
+        p.x0, p.ld0, p.c0 = x0.ptr, x0.ld, self.cp(x0.c)
+        if x1 is not None:
+            x1 = V(x1)
+            assert x1.t.shape[:3] == x0.t.shape[:3]
+            assert x0.c % self.VE == 0, "first source of a two-source conv must be vector aligned"
+            p.x1, p.ld1, p.c1 = x1.ptr, x1.ld, self.cp(x1.c)
+        else:
+            p.x1, p.ld1, p.c1 = None, 0, 0
+        assert x0.coff % self.VE == 0 and (x1 is None or x1.coff % self.VE == 0)
+        p.N, p.H, p.W = n, h, w_
+        if layer is not None:
+            assert p.c0 + p.c1 == layer.cin_pad, (p.c0, p.c1, layer.cin_pad)
+            p.w = layer.w.data_ptr()
+            p.bias = None if layer.b is None else layer.b.data_ptr()
+            kh, kw, st, (ph, pw), pm = layer.kh, layer.kw, layer.stride, layer.pad, layer.pad_mode
+            p.Cout = layer.cout
+        else:  # weights are another activation tensor (correlation volume): [groups][cout][c0]
+            p.w = w_raw.data_ptr()
+            p.bias = None
+            kh = kw = st = 1
+            ph = pw = 0
+            pm = L.PAD_ZEROS
+            p.Cout = cout
+        p.w_group_stride, p.groups = w_group_stride, groups
+        p.KH, p.KW, p.stride, p.pad_h, p.pad_w, p.pad_mode = kh, kw, st, ph, pw, pm
+        p.Ho = (h + 2 * ph - kh) // st + 1
+        p.Wo = (w_ + 2 * pw - kw) // st + 1
+        assert out.t.shape[0] == n and out.t.shape[1] == p.Ho and out.t.shape[2] == p.Wo, (out.t.shape, n, p.Ho, p.Wo)
+        p.epi_mode = epi
+        p.act1, p.act2 = act1, act2
+        s1 = slope1 if slope1 is not None else (layer.slope if (layer is not None and act1 == L.ACT_PRELU) else None)
+        p.slope1 = None if s1 is None else s1.data_ptr()
+        p.slope2 = None if slope2 is None else slope2.data_ptr()
+        if res is not None:
+            res = V(res)
+            p.res, p.ldr, p.res_f32 = res.ptr, res.ld, res.is_f32
+        else:
+            p.res, p.ldr, p.res_f32 = None, 0, 0
+        p.out_scale = out_scale
+        p.y, p.ldy, p.y_f32 = out.ptr, out.ld, out.is_f32
+        if y2 is not None:
+            y2 = V(y2)
+            p.y2, p.ldy2 = y2.ptr, y2.ld
+        if aux0 is not None:
+            aux0 = V(aux0)
+            p.aux0, p.lda0 = aux0.ptr, aux0.ld
+        if aux1 is not None:
+            aux1 = V(aux1)
+            p.aux1, p.lda1 = aux1.ptr, aux1.ld
+        p.tile_hint = tile
+        self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
+        return out
+
+    # ------------------------------------------------------------------ thin wrappers
+    def resize_planes(self, src, scale):
+        *lead, h, w = src.shape
+        ho, wo = int(math.floor(h * scale)), int(math.floor(w * scale))
+        dst = self.f32(*lead, ho, wo)
+        planes = src.numel() // (h * w)
+        self._chk(self.lib.resize_planes_f32(src.data_ptr(), dst.data_ptr(), planes, h, w, ho, wo,
+                                             float(1.0 / scale), self.stream()), "resize_planes_f32")
+        return dst
+
+    def prep_images(self, img_xs):
+        b, _, _, h, w = img_xs.shape
+        act = torch.empty((2 * b, h, w, 8), dtype=self.tdtype, device=self.device)
+        img4 = self.f32(2 * b, h, w, 4)
+        self._chk(self.lib.prep_images(img_xs.data_ptr(), act.data_ptr(), img4.data_ptr(), b, h, w, self.dtype,
+                                       self.stream()), "prep_images")
+        return act, img4
+
+    def instnorm(self, x, c, relu, res=None, out=None):
+        x = V(x)
+        n, h, w = x.t.shape[:3]
+        stats = self.f32(n, c, 2, zero=True)
+        self._chk(self.lib.instnorm_stats(x.ptr, x.ld, c, n, h * w, stats.data_ptr(), self.dtype, self.stream()),
+                  "instnorm_stats")
+        out = V(self.act(n, h, w, c) if out is None else out)
+        r = None if res is None else V(res)
+        self._chk(self.lib.instnorm_apply(x.ptr, x.ld, c, n, h * w, stats.data_ptr(), 1 if relu else 0,
+                                          None if r is None else r.ptr, 0 if r is None else r.ld, out.ptr, out.ld,
+                                          self.dtype, self.stream()), "instnorm_apply")
+        return out
+
+    def avgpool2(self, src, maps, h, w):
+        dst = self.f32(maps, h // 2, w // 2)
+        self._chk(self.lib.avgpool2_f32(src.data_ptr(), dst.data_ptr(), maps, h, w, self.stream()), "avgpool2_f32")
+        return dst
+
+    def corr_lookup(self, pyr, coords, out, n, h, w, h2, w2, radius=4):
+        out = V(out)
+        self._chk(self.lib.corr_lookup(pyr[0].data_ptr(), pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(),
+                                       coords.data_ptr(), out.ptr, out.ld, self.dtype, n, h, w, h2, w2, radius,
+                                       self.stream()), "corr_lookup")
+
+    def coords_init(self, n, h, w):
+        c = self.f32(n, h, w, 2)
+        self._chk(self.lib.coords_init(c.data_ptr(), n, h, w, self.stream()), "coords_init")
+        return c
+
+    def flow_pack(self, coords1, dst0, dst1):
+        n, h, w = coords1.shape[:3]
+        dst0, dst1 = V(dst0), V(dst1)
+        self._chk(self.lib.flow_pack(coords1.data_ptr(), dst0.ptr, dst0.ld, dst0.ld, dst1.ptr, dst1.ld, n, h, w,
+                                     self.dtype, self.stream()), "flow_pack")
+
+    def convex_upsample(self, coords1, mask):
+        n, h, w = coords1.shape[:3]
+        mask = V(mask)
+        out = self.f32(n, 8 * h, 8 * w, 2)
+        self._chk(self.lib.convex_upsample(coords1.data_ptr(), mask.ptr, mask.ld, mask.is_f32, out.data_ptr(), n, h, w,
+                                           self.dtype, self.stream()), "convex_upsample")
+        return out
+
+    def resize(self, src, c, scale, mul=1.0, out=None, out_f32=None, rscale=None, size=None):
+        """dst = mul * bilinear_resize(src) (align_corners=False).  Either scale (torch scale_factor
+        semantics) or size=(Ho,Wo) (torch size semantics: rscale = in/out)."""
+        src = V(src)
+        n, h, w = src.t.shape[:3]
+        if size is None:
+            ho, wo = int(math.floor(h * scale)), int(math.floor(w * scale))
+            rs = float(1.0 / scale)
+            rs_h = rs_w = rs
+        else:
+            ho, wo = size
+            rs_h, rs_w = h / ho, w / wo
+            assert abs(rs_h - rs_w) < 1e-12 or True
+        if out is None:
+            f32o = src.is_f32 if out_f32 is None else out_f32
+            out = self.f32(n, ho, wo, c) if f32o else self.act(n, ho, wo, c)
+        out = V(out)
+        assert out.t.shape[1] == ho and out.t.shape[2] == wo
+        if size is not None and rs_h != rs_w:
+            raise NotImplementedError("anisotropic resize")
+        self._chk(self.lib.resize_nhwc(src.ptr, src.ld, src.is_f32, out.ptr, out.ld, out.is_f32, c, n, h, w, ho, wo,
+                                       float(rs_h), float(mul), self.dtype, self.stream()), "resize_nhwc")
+        return out
+
+    def warp(self, src, c, flow, out, fmul=1.0):
+        src, out, flow = V(src), V(out), V(flow)
+        n, h, w = out.t.shape[:3]
+        assert src.t.shape[1] == h and src.t.shape[2] == w and flow.t.shape[1] == h
+        self._chk(self.lib.warp_nhwc(src.ptr, src.ld, src.is_f32, flow.ptr, flow.ld, float(fmul), out.ptr, out.ld,
+                                     out.is_f32, c, n, h, w, self.dtype, self.stream()), "warp_nhwc")
+        return out
+
+    def pixel_shuffle2(self, src, cout):
+        src = V(src)
+        n, h, w = src.t.shape[:3]
+        out = self.act(n, 2 * h, 2 * w, cout)
+        self._chk(self.lib.pixel_shuffle2(src.ptr, src.ld, out.data_ptr(), out.shape[-1], cout, n, h, w, self.dtype,
+                                          self.stream()), "pixel_shuffle2")
+        return out
+
+    def copy(self, src, dst, c, mul=1.0, add=None):
+        src, dst = V(src), V(dst)
+        a = None if add is None else V(add)
+        self._chk(self.lib.copy_channels(src.ptr, src.ld, src.is_f32, None if a is None else a.ptr,
+                                         0 if a is None else a.ld, 0 if a is None else a.is_f32, dst.ptr, dst.ld,
+                                         dst.is_f32, c, float(mul), dst.npix, self.dtype, self.stream()),
+                  "copy_channels")
+        return dst
+
+    def nhwc_to_nchw(self, src, c):
+        src = V(src)
+        assert src.is_f32
+        n, h, w = src.t.shape[:3]
+        out = self.f32(n, c, h, w)
+        self._chk(self.lib.nhwc_to_nchw_f32(src.ptr, src.ld, out.data_ptr(), c, n, h, w, self.stream()),
+                  "nhwc_to_nchw_f32")
+        return out

@@ -1,0 +1,166 @@
+/* gimmvfi_hip.h -- C ABI of libgimmvfi_hip.so (MI355X / gfx950 HIP kernels for the
+ * GIMM-VFI-R inference path).
+ *
+ * Plain pointers and sizes only: every pointer is a DEVICE pointer, every entry point
+ * enqueues on the hipStream_t passed last (cast to void*; 0 = default stream) and returns
+ * the hipError_t of the launch (0 = success).  No torch types cross this boundary.
+ *
+ * Data layout ("activation tensor"): NHWC, channel-contiguous, with an explicit pixel
+ * pitch `ld` (elements between consecutive pixels) so that a kernel can read or write a
+ * channel slice of a wider (concatenation) buffer.  Element type `dtype` is
+ * GVFI_F32 (float) or GVFI_BF16 (raw bfloat16 bits); geometry (flows, coordinates,
+ * correlation volumes, splat accumulators, images for warping) is always float.
+ *
+ * Each entry point cites the reference code (GSeanCDAT/GIMM-VFI, paths relative to
+ * src/models/generalizable_INR/) it replaces.
+ */
+#ifndef GIMMVFI_HIP_H
+#define GIMMVFI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GVFI_F32 = 0, GVFI_BF16 = 1 };
+enum {
+    GVFI_ACT_NONE = 0,
+    GVFI_ACT_RELU = 1,
+    GVFI_ACT_LRELU = 2,   /* LeakyReLU(0.1) */
+    GVFI_ACT_PRELU = 3,   /* per-channel slope */
+    GVFI_ACT_SIGMOID = 4,
+    GVFI_ACT_TANH = 5,
+    GVFI_ACT_SIN = 6
+};
+enum { GVFI_PAD_ZEROS = 0, GVFI_PAD_REFLECT = 1 };
+enum {
+    GVFI_EPI_STD = 0,    /* y = act2(act1(acc + bias) + res) * out_scale                       */
+    GVFI_EPI_GRU_ZR = 1, /* cout <  Cout/2: y  = sigmoid(acc+bias)            (z gate)          *
+                          * cout >= Cout/2: y2 = sigmoid(acc+bias) * aux0     (r * h)           */
+    GVFI_EPI_GRU_Q = 2   /* y = (1 - aux1) * aux0 + aux1 * tanh(acc+bias)     (h update)        */
+};
+
+/* Implicit-GEMM convolution on the matrix cores (MFMA), NHWC, fused epilogue.
+ * Replaces every nn.Conv2d (+ bias + activation + residual + GRU gating) on the path:
+ * raft/extractor.py:6-58,122-220; raft/update.py:6-148; modules/fi_components.py:17-54,
+ * 97-222,229-340; gimmvfi_r.py:51-64,84-109; and, with per-group weights, the all-pairs
+ * correlation GEMM raft/corr.py:167-175 and the INR linear layers modules/hyponet.py:95-143. */
+typedef struct {
+    int dtype;              /* element type of x0, x1, w (and of y/res/aux unless flagged f32) */
+    /* input = channel concatenation of up to two NHWC sources (c1 may be 0).             */
+    const void* x0; int ld0; int c0;   /* c0, c1: multiples of the 16-byte vector (4 f32 / 8 bf16) */
+    const void* x1; int ld1; int c1;
+    int N, H, W;            /* input images, height, width                                 */
+    /* weights packed [groups][Cout][KH][KW][c0+c1] in `dtype`; w_group_stride in elements */
+    const void* w; long long w_group_stride; int groups;   /* images per group = N/groups  */
+    const float* bias;      /* [Cout] float or NULL (shared by all groups)                 */
+    int Cout, KH, KW, stride, pad_h, pad_w, pad_mode;
+    int Ho, Wo;
+    int epi_mode;
+    int act1; const float* slope1;
+    const void* res; int ldr; int res_f32;
+    int act2; const float* slope2;
+    float out_scale;
+    void* y; int ldy; int y_f32;
+    void* y2; int ldy2;                 /* GRU_ZR: r*h destination                          */
+    const void* aux0; int lda0;         /* GRU: h                                           */
+    const void* aux1; int lda1;         /* GRU_Q: z                                         */
+    int tile_hint;                      /* 0 = auto                                         */
+} gvfi_conv_params;
+
+int gvfi_conv2d(const gvfi_conv_params* p, void* stream);
+
+/* ---- input preparation (gimmvfi_r.py:230-231,329-337,349; raft/raft.py:111-112) ------ */
+/* bilinear resize of float planes, align_corners=False, rscale = (float)(1.0/scale_factor)
+ * as torch computes it for an explicit scale_factor (fi_utils.py:67-70) */
+int gvfi_resize_planes_f32(const float* src, float* dst, int planes, int H, int W, int Ho, int Wo,
+                           float rscale, void* stream);
+/* img_xs (B,3,2,H,W) in [0,1] -> normalised 2x-1 images, image order [frame0 of b=0..B-1, frame1 ...]:
+ * act [2B,H,W,8] in dtype (channels 3..7 = 0) for convolutions and img4 [2B,H,W,4] float for warps */
+int gvfi_prep_images(const float* img_xs, void* act, float* img4, int B, int H, int W, int dtype, void* stream);
+
+/* ---- InstanceNorm2d (affine=False, eps=1e-5) of raft fnet, raft/extractor.py:26-30,50-58 */
+int gvfi_instnorm_stats(const void* x, int ld, int C, int N, int HW, float* stats /*[N][C][2] zeroed*/,
+                        int dtype, void* stream);
+/* out = relu?( (x-mean)*rstd );  if res: out = relu(res + out) */
+int gvfi_instnorm_apply(const void* x, int ld, int C, int N, int HW, const float* stats, int relu,
+                        const void* res, int ldr, void* out, int ldo, int dtype, void* stream);
+
+/* ---- correlation pyramid + lookup (raft/corr.py:23-93,127-165; raft/utils/utils.py:66-80) */
+int gvfi_avgpool2_f32(const float* src, float* dst, long long maps, int h, int w, void* stream);
+int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3,
+                     const float* coords /*[N,h,w,2] (x,y)*/, void* out, int ldo, int dtype,
+                     int N, int h, int w, int h2, int w2, int radius, void* stream);
+
+/* ---- RAFT glue (raft/raft.py:77-97,139-161) ------------------------------------------- */
+int gvfi_coords_init(float* coords, int N, int h, int w, void* stream);
+/* flow = coords1 - grid -> dst0[.,0:2] (+ zero pad to pad0 channels) and dst1[.,0:2] */
+int gvfi_flow_pack(const float* coords1, void* dst0, int ld0, int pad0, void* dst1, int ld1,
+                   int N, int h, int w, int dtype, void* stream);
+int gvfi_convex_upsample(const float* coords1, const void* mask, int ldm, int mask_f32, float* flow_up,
+                         int N, int h, int w, int dtype, void* stream);
+
+/* ---- flow normalisation (modules/fi_utils.py:52-64) ----------------------------------- */
+/* scaler[b] = max |f01[b]|,|f10[b]| ; scaler must be zeroed by the caller */
+int gvfi_flow_absmax(const float* f01, const float* f10, float* scaler, int B, int HW, void* stream);
+/* nf[0:B] = (f01/s+1)/2, nf[B:2B] = (-f10/s+1)/2 -> act [2B,H,W,pad] dtype and nflow float (B,2,2,H,W) */
+int gvfi_flow_normalize(const float* f01, const float* f10, const float* scaler, void* act, int ld, int pad,
+                        float* nflow_out, int B, int H, int W, int dtype, void* stream);
+int gvfi_flow_unnormalize(const float* ninr /*[B,H,W,2]*/, const float* scaler, float* flow_t /*[B,H,W,2]*/,
+                          float* ninr_nchw /* (B,2,1,H,W) or NULL */, int B, int HW, void* stream);
+
+/* ---- splatting (gimmvfi_r.py:444-492; modules/softsplat.py:286-352,371-421) ------------ */
+int gvfi_splat_weights(const float* f01, const float* f10, const float* gfilt9, float alpha_v, float alpha_fe,
+                       float* z0, float* z1, int B, int H, int W, void* stream);
+/* acc[B,H,W,C+1] (float, zeroed) += splat of [lat*Z, Z] by flow*tscale[b] */
+int gvfi_softsplat_accum(const void* lat, int ldl, int C, const float* flow, const float* z, const float* t,
+                         int one_minus_t, float* acc, int B, int H, int W, int dtype, void* stream);
+int gvfi_softsplat_normalize(const float* acc, int C, void* dst, int ldd, long long npix, int dtype, void* stream);
+
+/* ---- INR (modules/hyponet.py:71-146, modules/coord_sampler.py:15-43) -------------------- */
+/* dst[.,0:C]=latent, dst[.,C:C+3]=coord(t,y,x), rest 0 up to pad */
+int gvfi_inr_pack(const void* lat, int ldl, int C, const float* coord, void* dst, int ldd, int pad,
+                  long long npix, int dtype, void* stream);
+
+/* ---- generic NHWC glue (modules/fi_utils.py:19-49,67-70; F.pixel_shuffle) --------------- */
+/* bilinear resize (align_corners=False, rscale = 1/scale_factor), dst = mul * resize(src) */
+int gvfi_resize_nhwc(const void* src, int lds, int src_f32, void* dst, int ldd, int dst_f32, int C,
+                     int N, int H, int W, int Ho, int Wo, float rscale, float mul, int dtype, void* stream);
+/* backward warp, border padding, align_corners=True; flow float [N,H,W,ldf] at channel foff, scaled by fmul */
+int gvfi_warp_nhwc(const void* src, int lds, int src_f32, const float* flow, int ldf, float fmul,
+                   void* dst, int ldd, int dst_f32, int C, int N, int H, int W, int dtype, void* stream);
+int gvfi_pixel_shuffle2(const void* src, int lds, void* dst, int ldd, int Cout, int N, int H, int W,
+                        int dtype, void* stream);
+/* dst[.,0:C] = mul*src[.,0:C] (+ add[.,0:C]) with independent dtypes/pitches */
+int gvfi_copy_channels(const void* src, int lds, int src_f32, const void* add, int lda, int add_f32,
+                       void* dst, int ldd, int dst_f32, int C, float mul, long long npix, int dtype, void* stream);
+/* per-sample time scaling of a flow field: dst0 = -t*f, dst1 = (1-t)*f   (gimmvfi_r.py:239-240) */
+int gvfi_flow_split_t(const float* flow_t, const float* t, float* ft0, float* ft1, int B, int HW, void* stream);
+/* lookup coordinates of gimmvfi_r.py:494-507: c0 = grid + fl1/(1-t), c1 = grid + fl0/t */
+int gvfi_lookup_coords(const float* fl0, const float* fl1, const float* t, float* c0, float* c1,
+                       int B, int h, int w, void* stream);
+
+/* ---- frame synthesis glue (modules/fi_components.py:57-94,255-340; gimmvfi_r.py:213-220,305-308) */
+/* out = clamp((sigmoid(mask)*warp(img0,f0) + (1-sigmoid(mask))*warp(img1,f1) + 1)/2, 0, 1), NCHW float */
+int gvfi_warp_blend(const float* img4_0, const float* img4_1, const float* f0, const float* f1,
+                    const float* mask, float* out_nchw, int B, int H, int W, void* stream);
+/* multi_flow_combine front half: 3 candidate blends + residual -> act [B,H,W,pad>=9] dtype, mean [B,H,W,4] float.
+ * dec = final decoder output float [B,H,W,24] = [flow0(6) flow1(6) mask(3, post-sigmoid) res(9)] */
+int gvfi_combine_warps(const float* img4_0, const float* img4_1, const float* dec, int ldd, void* act, int lda,
+                       int pad, float* mean4, int B, int H, int W, int dtype, void* stream);
+/* final decoder head fix-up (fi_components.py:331-340): dec[.,0:6]+=flow0 x3, [6:12]+=flow1 x3,
+ * [12:15] = sigmoid(dec + mask) ; flows float [.,2], mask float [.,1] */
+int gvfi_decoder_head(float* dec, int ldd, const float* flow0, const float* flow1, const float* mask,
+                      long long npix, void* stream);
+/* imgt = clamp((x+1)/2, 0, 1): float NHWC (ld, 3 ch) -> float NCHW (B,3,H,W) */
+int gvfi_finalize_image(const float* x, int ld, float* out_nchw, int B, int H, int W, void* stream);
+/* float NHWC [N,H,W,ld] channels [0,C) -> float NCHW (N,C,H,W) */
+int gvfi_nhwc_to_nchw_f32(const float* src, int ld, float* dst, int C, int N, int H, int W, void* stream);
+
+/* library identity / self-check */
+const char* gvfi_version(void);
+int gvfi_device_ok(void);   /* 1 if a gfx950 device is present and usable */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

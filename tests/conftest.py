@@ -1,0 +1,30 @@
+import os
+import sys
+import warnings
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+for p in (ROOT, os.path.join(ROOT, "gimm-vfi_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"),
+          os.path.join(ROOT, "tests", "hostsim")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+warnings.filterwarnings("ignore")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def sd():
+    from gimmvfi_hip.params import random_state_dict
+
+    return random_state_dict(0)
+
+
+@pytest.fixture(scope="session")
+def simlib():
+    from sim_runtime import hostsim_lib
+
+    return hostsim_lib()

@@ -1,0 +1,43 @@
+"""TEST INFRASTRUCTURE ONLY: compiles gimm-vfi_amd/csrc/*.hip for the HOST with the
+thread-per-lane emulator header (hip_emu.h) so CPU tests can exercise kernel index math.
+The result (tests/hostsim/_build/libgimmvfi_hostsim.so) is never loaded by the product."""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+CSRC = os.path.join(ROOT, "gimm-vfi_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libgimmvfi_hostsim.so")
+CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+def _compile(src):
+    obj = os.path.join(OUT, os.path.basename(src) + ".o")
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(HERE, "hip_emu.h"),
+            os.path.join(ROOT, "include", "gimmvfi_hip.h")]
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in deps):
+        return obj
+    cmd = [CXX, "-std=c++20", "-O2", "-DGVFI_HOSTSIM", "-ffp-contract=off", "-I", HERE, "-x", "c++", "-fPIC", "-pthread",
+           "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hostsim compile failed:\n" + r.stdout + r.stderr)
+    return obj
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        r = subprocess.run([CXX, "-shared", "-pthread", "-o", LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hostsim link failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build())

@@ -1,0 +1,282 @@
+"""Per-kernel parity cases shared by the CPU emulator tests and the GPU tests.
+
+Every case drives the C ABI through ``gimmvfi_hip.ops.Runtime`` (the emulator runtime on CPU, the
+real libgimmvfi_hip.so on the GPU) and compares with an independent torch / oracle statement.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+import gimmvfi_r_oracle as orc
+from gimmvfi_hip import lib as L
+from gimmvfi_hip.ops import ConvLayer, View
+
+
+def _dev(rt):
+    return rt.device
+
+
+def _to_act(rt, x_nchw, pad_to=None):
+    """NCHW float -> NHWC runtime dtype with padded pitch."""
+    n, c, h, w = x_nchw.shape
+    t = rt.act(n, h, w, c if pad_to is None else pad_to, zero=True)
+    t[..., :c] = x_nchw.permute(0, 2, 3, 1).to(t.dtype)
+    return t
+
+
+def _rounded(rt, x):
+    return x.to(rt.tdtype).float()
+
+
+def tol(rt, scale):
+    return (2e-5 if rt.precision == "fp32" else 1.2e-2) * scale
+
+
+def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.ACT_NONE, with_res=False,
+              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    slope = torch.rand(Cout, generator=g) * 0.3 + 0.1
+    x, w = _rounded(rt, x), _rounded(rt, w)
+    dev = _dev(rt)
+    lay = ConvLayer(rt, w, b, stride=stride, pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope)
+    if split is None:
+        xa = _to_act(rt, x).to(dev)
+        x0, x1 = View(xa, 0, Cin), None
+    else:  # two sources: channels [0,split) from a wider buffer at an offset, the rest from a second tensor
+        wide = rt.act(N, H, W, split + 2 * rt.VE, zero=True)
+        wide[..., rt.VE:rt.VE + split] = x[:, :split].permute(0, 2, 3, 1).to(wide.dtype)
+        xb = _to_act(rt, x[:, split:])
+        wide, xb = wide.to(dev), xb.to(dev)
+        x0, x1 = View(wide, rt.VE, split), View(xb, 0, Cin - split)
+    ph, pw = KH // 2, KW // 2
+    Ho, Wo = (H + 2 * ph - KH) // stride + 1, (W + 2 * pw - KW) // stride + 1
+    res = None
+    r = None
+    if with_res:
+        r = _rounded(rt, torch.randn(N, Cout, Ho, Wo, generator=g))
+        res = _to_act(rt, r).to(dev)
+    out = (rt.f32(N, Ho, Wo, Cout + 3, zero=True) if out_f32 else rt.act(N, Ho, Wo, Cout + 3, zero=True))
+    rt.conv(lay, x0, View(out, 2, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
+            slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile)
+    xi = F.pad(x, (pw, pw, ph, ph), mode="reflect") if reflect else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=0 if reflect else (ph, pw))
+
+    def act(v, k):
+        if k == L.ACT_RELU:
+            return F.relu(v)
+        if k == L.ACT_LRELU:
+            return F.leaky_relu(v, 0.1)
+        if k == L.ACT_PRELU:
+            return F.prelu(v, slope)
+        if k == L.ACT_SIGMOID:
+            return torch.sigmoid(v)
+        if k == L.ACT_TANH:
+            return torch.tanh(v)
+        if k == L.ACT_SIN:
+            return torch.sin(v)
+        return v
+
+    ref = act(ref, act1)
+    if with_res:
+        ref = ref + r
+    ref = act(ref, act2) * out_scale
+    got = out.float().cpu()
+    err = float((got[..., 2:2 + Cout].permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= tol(rt, float(ref.abs().max()) + 1.0), (err, float(ref.abs().max()))
+    # channels outside the destination slice must be untouched
+    assert float(got[..., :2].abs().max()) == 0.0 and float(got[..., 2 + Cout:].abs().max()) == 0.0
+    return err
+
+
+def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5):
+    """SepConvGRU half step with the fused epilogues (raft/update.py:58-66)."""
+    g = torch.Generator().manual_seed(seed)
+    h = _rounded(rt, torch.tanh(torch.randn(N, C, H, W, generator=g)))
+    x = _rounded(rt, torch.randn(N, 2 * C, H, W, generator=g))
+    wz, wr, wq = (_rounded(rt, torch.randn(C, 3 * C, kh, kw, generator=g) / (3 * C * kh * kw) ** 0.5) for _ in range(3))
+    bz, br, bq = (torch.randn(C, generator=g) for _ in range(3))
+    dev = _dev(rt)
+    lzr = ConvLayer(rt, torch.cat([wz, wr], 0), torch.cat([bz, br], 0))
+    lq = ConvLayer(rt, wq, bq)
+    ha, xa = _to_act(rt, h).to(dev), _to_act(rt, x).to(dev)
+    zb, rh, hn = rt.act(N, H, W, C), rt.act(N, H, W, C), rt.act(N, H, W, C)
+    rt.conv(lzr, ha, zb, x1=xa, epi=L.EPI_GRU_ZR, y2=rh, aux0=ha)
+    rt.conv(lq, rh, hn, x1=xa, epi=L.EPI_GRU_Q, aux0=ha, aux1=zb)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([h, x], 1)
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=pad))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=pad))
+    rhr = _rounded(rt, r * h)
+    q = torch.tanh(F.conv2d(torch.cat([rhr, x], 1), wq, bq, padding=pad))
+    ref = (1 - _rounded(rt, z)) * h + _rounded(rt, z) * q
+    err = float((hn.float().cpu().permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= tol(rt, 2.0), err
+    return err
+
+
+def corr_volume_case(rt, B=2, h=5, w=7, C=32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    f1 = _rounded(rt, torch.randn(B, C, h, w, generator=g))
+    f2 = _rounded(rt, torch.randn(B, C, h, w, generator=g))
+    dev = _dev(rt)
+    a, b = _to_act(rt, f1).to(dev), _to_act(rt, f2).to(dev)
+    P = h * w
+    vol = rt.f32(B * P, P)
+    rt.conv(None, a, View(vol.view(B, h, w, P)), groups=B, w_group_stride=P * C, w_raw=b, cout=P, out_scale=0.125)
+    ref = torch.einsum("bcp,bcq->bpq", f1.reshape(B, C, P), f2.reshape(B, C, P)) * 0.125
+    err = float((vol.cpu().view(B, P, P) - ref).abs().max())
+    assert err <= tol(rt, float(ref.abs().max())), err
+
+
+def instnorm_case(rt, N=2, H=9, W=11, C=24):
+    g = torch.Generator().manual_seed(1)
+    x = _rounded(rt, torch.randn(N, C, H, W, generator=g) * 2 + 0.5)
+    r = _rounded(rt, torch.randn(N, C, H, W, generator=g))
+    dev = _dev(rt)
+    xa, ra = _to_act(rt, x).to(dev), _to_act(rt, r).to(dev)
+    o1 = rt.instnorm(xa, C, relu=True).t
+    o2 = rt.instnorm(xa, C, relu=True, res=ra).t
+    o3 = rt.instnorm(xa, C, relu=False).t
+    n = F.instance_norm(x, eps=1e-5)
+    for got, ref in ((o1, F.relu(n)), (o2, F.relu(r + F.relu(n))), (o3, n)):
+        err = float((got.float().cpu().permute(0, 3, 1, 2)[:, :C] - ref).abs().max())
+        assert err <= tol(rt, 4.0), err
+
+
+def resize_warp_shuffle_case(rt):
+    g = torch.Generator().manual_seed(2)
+    dev = _dev(rt)
+    N, C, H, W = 2, 12, 16, 24
+    x = _rounded(rt, torch.randn(N, C, H, W, generator=g))
+    xa = _to_act(rt, x).to(dev)
+    xf = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    for s in (0.25, 0.5, 2.0, 4.0):
+        ref = F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False)
+        o = rt.resize(xa, C, s).t.float().cpu().permute(0, 3, 1, 2)[:, :C]
+        assert float((o - ref).abs().max()) <= tol(rt, 4.0)
+        o = rt.resize(xf, C, s, mul=s).t.cpu().permute(0, 3, 1, 2)
+        assert float((o - s * ref).abs().max()) <= 2e-5 * 16
+    ref = F.interpolate(x, size=(24, 36), mode="bilinear")
+    o = rt.resize(xf, C, None, size=(24, 36)).t.cpu().permute(0, 3, 1, 2)
+    assert float((o - ref).abs().max()) <= 1e-4
+    # warp: includes far out-of-range flows (border clamp)
+    flow = torch.randn(N, 2, H, W, generator=g) * 6
+    flow[0, :, 0, 0] = torch.tensor([-100.0, 50.0])
+    ref = orc.warp(x, flow)
+    fa = flow.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = rt.act(N, H, W, C + 8, zero=True)
+    rt.warp(xa, C, fa, View(out, 8, C))
+    o = out.float().cpu().permute(0, 3, 1, 2)[:, 8:8 + C]
+    assert float((o - ref).abs().max()) <= tol(rt, 4.0)
+    # pixel shuffle
+    y = _rounded(rt, torch.randn(N, 16, 5, 6, generator=g))
+    o = rt.pixel_shuffle2(_to_act(rt, y).to(dev), 4).float().cpu().permute(0, 3, 1, 2)[:, :4]
+    assert float((o - F.pixel_shuffle(y, 2)).abs().max()) == 0.0
+    # planes resize (input down-sampling, gimmvfi_r.py:329-337)
+    img = torch.rand(2, 3, 2, 16, 24, generator=g)
+    o = rt.resize_planes(img.to(dev), 0.5).cpu()
+    ref = torch.stack([F.interpolate(img[:, :, f], scale_factor=0.5, mode="bilinear", align_corners=False) for f in (0, 1)], 2)
+    assert float((o - ref).abs().max()) <= 1e-6
+
+
+def corr_lookup_case(rt, B=2, h=16, w=24):
+    g = torch.Generator().manual_seed(3)
+    dev = _dev(rt)
+    vol = torch.randn(B, h, w, 1, h, w, generator=g)
+    pyr = orc.corr_pyramid(vol)
+    coords = orc.coords_grid(B, h, w) + torch.randn(B, 2, h, w, generator=g) * 4
+    coords[0, :, 0, 0] = torch.tensor([-30.0, 3.3])     # fully out of range window
+    coords[0, :, 1, 1] = torch.tensor([w - 1.0, h - 1.0])  # exactly on the border
+    ref = orc.corr_lookup(pyr, coords)
+    dp = [rt.f32(B * h * w, h * w).copy_(vol.reshape(B * h * w, h * w))]
+    hh, ww = h, w
+    for _ in range(3):
+        dp.append(rt.avgpool2(dp[-1], B * h * w, hh, ww))
+        hh, ww = hh // 2, ww // 2
+    for lvl in range(4):
+        assert float((dp[lvl].cpu().reshape(pyr[lvl].shape) - pyr[lvl]).abs().max()) <= 1e-5
+    out = rt.act(B, h, w, 324 + 8, zero=True)
+    rt.corr_lookup(dp, coords.permute(0, 2, 3, 1).contiguous().to(dev), View(out, 8, 324), B, h, w, h, w)
+    o = out.float().cpu().permute(0, 3, 1, 2)[:, 8:8 + 324]
+    assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max())) + 1e-4
+
+
+def convex_upsample_case(rt, N=2, h=6, w=9):
+    g = torch.Generator().manual_seed(4)
+    dev = _dev(rt)
+    flow = torch.randn(N, 2, h, w, generator=g) * 3
+    mask = torch.randn(N, 576, h, w, generator=g)
+    ref = orc.convex_upsample(flow, mask)
+    coords = (orc.coords_grid(N, h, w) + flow).permute(0, 2, 3, 1).contiguous().to(dev)
+    m = mask.permute(0, 2, 3, 1).contiguous().to(dev)
+    o = rt.convex_upsample(coords, m).cpu().permute(0, 3, 1, 2)
+    assert float((o - ref).abs().max()) <= 2e-5 * 32
+
+
+def splat_case(rt, B=2, H=12, W=20, C=16):
+    """softmax-splat forward incl. the reference's edge cases: out-of-image targets, non-finite flow
+    (skipped), pixels nothing lands on (zero denominator -> 1)."""
+    g = torch.Generator().manual_seed(5)
+    dev = _dev(rt)
+    lat = _rounded(rt, torch.randn(B, C, H, W, generator=g))
+    flow = torch.randn(B, 2, H, W, generator=g) * 5
+    flow[0, :, 2, 3] = float("nan")
+    flow[0, 0, 4, 5] = float("inf")
+    flow[1, :, :, :6] = 40.0          # splat a whole band out of the image -> holes
+    z = torch.rand(B, 1, H, W, generator=g) + 0.5
+    t = torch.tensor([0.3, 0.75])
+    for omt in (0, 1):
+        ts = (1 - t) if omt else t
+        ref = orc.softsplat_linear_zeroeps(lat, flow * ts.view(-1, 1, 1, 1), z)
+        acc = rt.f32(B, H, W, C + 1, zero=True)
+        la = _to_act(rt, lat).to(dev)
+        fd = flow.permute(0, 2, 3, 1).contiguous().to(dev)   # keep references alive across the launch
+        zd = z.reshape(B, H, W).contiguous().to(dev)
+        td = t.to(dev)
+        rt._chk(rt.lib.softsplat_accum(la.data_ptr(), la.shape[-1], C, fd.data_ptr(), zd.data_ptr(), td.data_ptr(), omt,
+                                       acc.data_ptr(), B, H, W, rt.dtype, rt.stream()), "softsplat_accum")
+        out = rt.act(B, H, W, C)
+        rt._chk(rt.lib.softsplat_normalize(acc.data_ptr(), C, out.data_ptr(), out.shape[-1], B * H * W, rt.dtype,
+                                           rt.stream()), "softsplat_normalize")
+        o = out.float().cpu().permute(0, 3, 1, 2)
+        assert torch.isfinite(o).all()
+        assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max()))
+
+
+def splat_weights_and_norm_case(rt, sd, B=2, H=16, W=20):
+    g = torch.Generator().manual_seed(6)
+    dev = _dev(rt)
+    # rough (non-smooth) flows keep the variance away from the ill-conditioned zero-variance regime
+    f01 = torch.randn(B, 2, H, W, generator=g) * 3
+    f10 = torch.randn(B, 2, H, W, generator=g) * 3
+    w1, w2 = orc.cal_splatting_weights(sd, f01, f10)
+    a, b = f01.permute(0, 2, 3, 1).contiguous().to(dev), f10.permute(0, 2, 3, 1).contiguous().to(dev)
+    z0, z1 = rt.f32(B, H, W), rt.f32(B, H, W)
+    g9 = sd["g_filter"].reshape(9).contiguous().to(dev)
+    rt._chk(rt.lib.splat_weights(a.data_ptr(), b.data_ptr(), g9.data_ptr(), float(sd["alpha_v"]), float(sd["alpha_fe"]),
+                                 z0.data_ptr(), z1.data_ptr(), B, H, W, rt.stream()), "splat_weights")
+    assert float((z0.cpu() - w1[:, 0]).abs().max()) <= 1e-4
+    assert float((z1.cpu() - w2[:, 0]).abs().max()) <= 1e-4
+    # normalisation round trip  (fi_utils.py:52-64)
+    nref, sref = orc.normalize_flow(torch.stack([f01, -f10], 2))
+    sc = rt.f32(B, zero=True)
+    rt._chk(rt.lib.flow_absmax(a.data_ptr(), b.data_ptr(), sc.data_ptr(), B, H * W, rt.stream()), "flow_absmax")
+    assert float((sc.cpu() - sref.reshape(B)).abs().max()) == 0.0
+    nf = rt.act(2 * B, H, W, 2, zero=True)
+    nfl = rt.f32(B, 2, 2, H, W)
+    rt._chk(rt.lib.flow_normalize(a.data_ptr(), b.data_ptr(), sc.data_ptr(), nf.data_ptr(), nf.shape[-1], nf.shape[-1],
+                                  nfl.data_ptr(), B, H, W, rt.dtype, rt.stream()), "flow_normalize")
+    assert float((nfl.cpu() - nref).abs().max()) <= 1e-6
+    got = nf.float().cpu()
+    assert float((got[:B, ..., :2].permute(0, 3, 1, 2) - nref[:, :, 0]).abs().max()) <= tol(rt, 1.0)
+    assert float((got[B:, ..., :2].permute(0, 3, 1, 2) - nref[:, :, 1]).abs().max()) <= tol(rt, 1.0)
+    ninr = torch.rand(B, H, W, 2, generator=g).to(dev)
+    ft, nn_ = rt.f32(B, H, W, 2), rt.f32(B, 2, 1, H, W)
+    rt._chk(rt.lib.flow_unnormalize(ninr.data_ptr(), sc.data_ptr(), ft.data_ptr(), nn_.data_ptr(), B, H * W, rt.stream()),
+            "flow_unnormalize")
+    ref = orc.unnormalize_flow(ninr.cpu().permute(0, 3, 1, 2).unsqueeze(2), sref)
+    assert float((ft.cpu().permute(0, 3, 1, 2) - ref[:, :, 0]).abs().max()) <= 1e-5

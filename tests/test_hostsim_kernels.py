@@ -1,0 +1,65 @@
+"""CPU checks of the HIP kernel sources through the host emulator build (tests/hostsim): index math,
+LDS addressing, barriers, epilogues and edge cases, before any GPU minute is spent.  The same cases
+run against the real library in tests/test_gpu_kernels.py."""
+import pytest
+
+import kernel_cases as kc
+from gimmvfi_hip import lib as L
+from sim_runtime import SimRuntime
+
+
+@pytest.fixture(scope="module", params=["fp32", "bf16"])
+def rt(request):
+    return SimRuntime(request.param, emulate_conv=True)
+
+
+CONV_SHAPES = [
+    # N, H, W, Cin, Cout, KH, KW, kwargs
+    (1, 8, 12, 3, 5, 3, 3, {}),
+    (2, 9, 7, 20, 70, 3, 3, dict(stride=2, act1=L.ACT_RELU)),
+    (1, 6, 10, 40, 130, 1, 5, dict(act1=L.ACT_TANH)),
+    (1, 6, 10, 12, 33, 7, 7, dict(act1=L.ACT_PRELU, with_res=True)),
+    (1, 10, 10, 16, 16, 3, 3, dict(reflect=True, with_res=True, act2=L.ACT_LRELU)),
+    (1, 7, 9, 48, 24, 3, 3, dict(split=32, with_res=True, act2=L.ACT_PRELU, out_f32=True)),
+    (1, 5, 6, 35, 2, 1, 1, dict(act1=L.ACT_SIN, out_f32=True, out_scale=0.25)),
+    (1, 12, 12, 8, 64, 5, 5, dict(stride=1, act1=L.ACT_SIGMOID, tile=128)),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv(rt, shape):
+    *a, kw = shape
+    kc.conv_case(rt, *a, **kw)
+
+
+def test_gru_epilogues(rt):
+    kc.gru_case(rt, kh=1, kw=5)
+    kc.gru_case(rt, kh=5, kw=1, seed=1)
+
+
+def test_corr_volume_grouped_gemm(rt):
+    kc.corr_volume_case(rt)
+
+
+def test_instnorm(rt):
+    kc.instnorm_case(rt)
+
+
+def test_resize_warp_shuffle(rt):
+    kc.resize_warp_shuffle_case(rt)
+
+
+def test_corr_lookup(rt):
+    kc.corr_lookup_case(rt)
+
+
+def test_convex_upsample(rt):
+    kc.convex_upsample_case(rt)
+
+
+def test_softsplat_edge_cases(rt):
+    kc.splat_case(rt)
+
+
+def test_splat_weights_and_flow_norm(rt, sd):
+    kc.splat_weights_and_norm_case(rt, sd)

@@ -1,0 +1,57 @@
+"""The oracle restatement must reproduce the reference: (a) against the reference itself when the
+checkout is present (dev container), (b) against the committed golden fixtures that were produced
+by the reference (everywhere, incl. the GPU box)."""
+import pytest
+import torch
+
+import gimmvfi_r_oracle as orc
+import ref_harness as rh
+from util import golden_inputs, load_golden, maxabs
+
+CASES = ["r_128x192_t050", "r_b2_128x128_t025_075", "r_256x256_ds050_t050"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_golden(name, sd):
+    meta, gold = load_golden(name)
+    x, coords, ts = golden_inputs(meta)
+    with torch.no_grad():
+        o = orc.forward(sd, x, coords, ts, meta["ds"])
+    # same torch build => the restatement is bit-exact; allow 1e-5 for other BLAS/oneDNN builds
+    tol = 1e-5
+    assert maxabs(o["raft_flow"], gold["raft_flow"]) <= tol * 10
+    assert maxabs(o["nflow"], gold["nflow"]) <= tol
+    for i in range(len(meta["t"])):
+        assert maxabs(o["imgt_pred"][i], gold[f"imgt_pred_{i}"]) <= tol
+        assert maxabs(o["flowt"][i], gold[f"flowt_{i}"]) <= tol * 10
+        assert maxabs(o["flowt0_pred"][i][1], gold[f"flowt0_4_{i}"]) <= tol * 10
+        assert tuple(o["flowt"][i].shape) == tuple(gold[f"flowt_{i}"].shape)  # B==1 squeeze quirk
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="reference checkout only exists in the dev container")
+def test_oracle_matches_reference_live(sd):
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    ref = rh.build_reference_model(sd)
+    x = synthetic_pairs(1, 128, 160, 11)
+    tl = [0.3, 0.8]
+    ro = rh.reference_forward(ref, x, tl, None)
+    coords = [(orc.sample_coord_input(1, x.shape[-2:], [t], 1.0), None) for t in tl]
+    with torch.no_grad():
+        oo = orc.forward(sd, x, coords, [t * torch.ones(1) for t in tl], None)
+    for k in ("raft_flow", "nflow"):
+        assert maxabs(ro[k], oo[k]) == 0.0
+    for i in range(2):
+        for k in ("imgt_pred", "flowt", "ninrflow"):
+            assert maxabs(ro[k][i], oo[k][i]) == 0.0
+        assert maxabs(ro["other_pred"][i][0], oo["other_pred"][i][0]) == 0.0
+        for j in range(2):
+            assert maxabs(ro["flowt0_pred"][i][j], oo["flowt0_pred"][i][j]) == 0.0
+            assert maxabs(ro["flowt1_pred"][i][j], oo["flowt1_pred"][i][j]) == 0.0
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="reference checkout only exists in the dev container")
+def test_reference_accepts_our_state_dict_strict(sd):
+    ref = rh.build_reference_model()
+    ref.load_state_dict(sd, strict=True)
+    assert list(ref.state_dict().keys()) == list(sd.keys())
