@@ -1,0 +1,159 @@
+"""Benchmark of the GIMM-VFI-R inference hot path on MI355X (driver contract: one JSON line).
+
+step      = one forward of the hot path over one batch of synthetic frame pairs
+workload  = BASELINE.json configs[1]: GIMM-VFI-R, 448x256, batch=8 pairs, t=0.5, bf16 MFMA / fp32 accumulate
+value     = interpolated frames / second, whole job (inputs resident in HBM before the timed region)
+multi-GPU = frame pairs shard across ranks (weak scaling: 8 pairs per rank), no data-path collective;
+            the uint8 result frames are gathered to rank 0 over RCCL inside the timed region.
+
+roofline     : dominant kernel (MFMA implicit-GEMM convolution) -- algorithmic FLOPs of its launches /
+               their HIP-event durations, measured on the launch stream inside the timed steps.
+cpu_baseline : the CPU oracle (port of the reference algorithm, oracle/gimmvfi_r_oracle.py) timed on the
+               host cores on a bounded sample (B=1 pair of the same 448x256 workload), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "gimm-vfi_amd"),):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=448)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
+
+    from gimmvfi_hip.model import GIMMVFI_R
+    from gimmvfi_hip.params import random_state_dict
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    B, H, W = args.batch, args.height, args.width
+    model = GIMMVFI_R(precision=args.precision)
+    model.load_state_dict(random_state_dict(0), strict=True)
+    model = model.to(dev).eval()
+    x = synthetic_pairs(B, H, W, seed=100 + rank).to(dev)
+    coords = [(model.sample_coord_input(B, (H, W), [0.5], device=dev), None)]
+    ts = [0.5 * torch.ones(B, device=dev)]
+    eng = model.engine(dev)
+    rt = eng.rt
+    gather_buf = None
+    if world > 1 and rank == 0:
+        gather_buf = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
+
+    def step():
+        out = model(x, coords, t=ts)
+        frames = rt.frames_to_u8(out["imgt_pred"][0])
+        if world > 1:
+            dist.gather(frames, gather_buf, dst=0)   # the path's only collective: result gather to rank 0
+        return frames
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    rt.ev_log = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev = rt.ev_log
+    rt.ev_log = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        frames = world * B * args.steps       # one interpolated frame per pair per step (t = 0.5)
+        value = frames / dt
+        # ---- roofline of the dominant kernel from the event log of the timed steps
+        agg = {}
+        for tag, fl, e0, e1 in ev:
+            a = agg.setdefault(tag, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        tag, (fl, sec, cnt) = dom
+        peak = MFMA_PEAK_TFLOPS[args.precision]
+        achieved = fl / sec / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": tag, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "launches_per_step": cnt // args.steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+            "avg_launch_gflop": round(fl / cnt / 1e9, 3),
+            "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / args.steps * 1e3, 3),
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(H, W)
+        line = {
+            "metric": "interpolated frames/sec", "value": round(value, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"GIMM-VFI-R {W}x{H} batch={B} pairs/GPU, t=0.5, DS_SCALE=1, seeded random-init weights",
+                       "pairs_per_step_per_gpu": B, "raft_iters": 20, "parallelism": f"pair-sharded x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(H, W):
+    """Oracle (CPU port of the reference algorithm) on the host cores: B=1 pair, 1 warm-up + 2 timed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gimmvfi_r_oracle as orc
+    from gimmvfi_hip.params import random_state_dict
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    sd = random_state_dict(0)
+    x = synthetic_pairs(1, H, W, seed=100)
+    coords = [(orc.sample_coord_input(1, (H, W), [0.5], 1.0), None)]
+    ts = [0.5 * torch.ones(1)]
+    times = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            orc.forward(sd, x, coords, ts, None)
+            times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(1.0 / best, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 pair {W}x{H} t=0.5 fp32, 1 warm-up + best of 2 (CPU oracle, torch {torch.__version__})"}
+
+
+if __name__ == "__main__":
+    main()

@@ -170,6 +170,25 @@ extern "C" int gvfi_finalize_image(const float* x, int ld, float* out_nchw, int 
     return (int)hipGetLastError();
 }
 
+// float NCHW [0,1] frame -> uint8 HWC (truncating x*255 like reference src/video_Nx.py:192-196 astype(np.uint8))
+__global__ void frames_to_u8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, long long total,
+                                    long long HW) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, pix, c)
+    if (idx >= total) return;
+    const int c = (int)(idx % 3);
+    const long long bp = idx / 3;
+    const long long b = bp / HW, pix = bp % HW;
+    float v = src[(b * 3 + c) * HW + pix] * 255.0f;
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    dst[idx] = (unsigned char)v;
+}
+extern "C" int gvfi_frames_to_u8(const float* src_nchw, unsigned char* dst_nhwc, int B, int H, int W, void* stream) {
+    const long long HW = (long long)H * W, total = 3 * HW * B;
+    GVFI_LAUNCH_SIMPLE(frames_to_u8_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, src_nchw, dst_nhwc,
+                       total, HW);
+    return (int)hipGetLastError();
+}
+
 extern "C" const char* gvfi_version(void) {
 #ifdef GVFI_HOSTSIM
     return "gimmvfi-hostsim (test emulator, not a product build)";

@@ -82,6 +82,7 @@ class Runtime:
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.n_launch = 0
+        self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
 
     # ------------------------------------------------------------------ memory
     def stream(self):
@@ -164,7 +165,20 @@ class Runtime:
             aux1 = V(aux1)
             p.aux1, p.lda1 = aux1.ptr, aux1.ld
         p.tile_hint = tile
-        self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
+        if self.ev_log is None:
+            self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
+        else:
+            # measurement mode (bench.py): HIP events on the launch stream around this kernel
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
+            e1.record()
+            bn = tile if tile else (128 if p.Cout > 64 else (64 if p.Cout > 32 else 32))
+            cin_real = (layer.cin if layer is not None else x0.c)
+            flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
+            tag = f"conv_igemm_kernel<{'float' if self.dtype == L.F32 else 'bf16'},128,{bn}>"
+            self.ev_log.append((tag, flops, e0, e1))
         return out
 
     # ------------------------------------------------------------------ thin wrappers
@@ -276,6 +290,12 @@ class Runtime:
                                          dst.is_f32, c, float(mul), dst.npix, self.dtype, self.stream()),
                   "copy_channels")
         return dst
+
+    def frames_to_u8(self, frames_nchw):
+        b, _, h, w = frames_nchw.shape
+        out = torch.empty((b, h, w, 3), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.frames_to_u8(frames_nchw.data_ptr(), out.data_ptr(), b, h, w, self.stream()), "frames_to_u8")
+        return out
 
     def nhwc_to_nchw(self, src, c):
         src = V(src)

@@ -156,6 +156,10 @@ int gvfi_finalize_image(const float* x, int ld, float* out_nchw, int B, int H, i
 /* float NHWC [N,H,W,ld] channels [0,C) -> float NCHW (N,C,H,W) */
 int gvfi_nhwc_to_nchw_f32(const float* src, int ld, float* dst, int C, int N, int H, int W, void* stream);
 
+/* output frame (B,3,H,W) float in [0,1] -> uint8 [B,H,W,3] (truncation of x*255, src/video_Nx.py:192-196);
+ * the unit that is gathered to rank 0 over RCCL in multi-GPU runs */
+int gvfi_frames_to_u8(const float* src_nchw, unsigned char* dst_nhwc, int B, int H, int W, void* stream);
+
 /* library identity / self-check */
 const char* gvfi_version(void);
 int gvfi_device_ok(void);   /* 1 if a gfx950 device is present and usable */

@@ -1,0 +1,105 @@
+"""End-to-end GPU parity of the GIMM-VFI-R hot path (libgimmvfi_hip.so through the reference model API)
+against (a) golden outputs of the reference itself (tests/golden), (b) the CPU oracle stage by stage,
+and size-independent properties at the benchmark size (448x256, batch 8).
+
+Stated tolerances: fp32 mode PSNR >= 80 dB and flows within 2e-3 px of the reference;
+bf16 mode (bf16 activations/weights, fp32 accumulate; flows / correlation / splat sums fp32) PSNR >= 40 dB.
+"""
+import pytest
+import torch
+
+import gimmvfi_r_oracle as orc
+from util import golden_inputs, load_golden, maxabs, nchw, psnr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(sd, precision):
+    from gimmvfi_hip.model import GIMMVFI_R
+
+    m = GIMMVFI_R(precision=precision)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+def _run(m, x, coords, ts, ds=None):
+    out = m(x.to(DEV), [(c[0].to(DEV), None) for c in coords], t=[t.to(DEV) for t in ts], ds_factor=ds)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("name", ["r_128x192_t050", "r_b2_128x128_t025_075", "r_256x256_ds050_t050"])
+def test_fp32_matches_reference_golden(name, sd):
+    meta, gold = load_golden(name)
+    x, coords, ts = golden_inputs(meta)
+    out = _run(_model(sd, "fp32"), x, coords, ts, meta["ds"])
+    assert maxabs(out["raft_flow"], gold["raft_flow"]) < 2e-3
+    assert maxabs(out["nflow"], gold["nflow"]) < 1e-3
+    for i in range(len(meta["t"])):
+        p = psnr(out["imgt_pred"][i], gold[f"imgt_pred_{i}"])
+        assert p >= 80.0, p
+        assert tuple(out["flowt"][i].shape) == tuple(gold[f"flowt_{i}"].shape)
+        d = (out["flowt"][i].cpu() - gold[f"flowt_{i}"]).abs().flatten()
+        assert float(d.kthvalue(int(d.numel() * 0.999))[0]) < 2e-3
+        assert maxabs(out["flowt0_pred"][i][1], gold[f"flowt0_4_{i}"]) < 2e-3
+
+
+@pytest.mark.parametrize("name", ["r_128x192_t050", "r_b2_128x128_t025_075", "r_256x256_ds050_t050"])
+def test_bf16_matches_reference_golden(name, sd):
+    meta, gold = load_golden(name)
+    x, coords, ts = golden_inputs(meta)
+    out = _run(_model(sd, "bf16"), x, coords, ts, meta["ds"])
+    for i in range(len(meta["t"])):
+        p = psnr(out["imgt_pred"][i], gold[f"imgt_pred_{i}"])
+        assert p >= 40.0, p
+        d = (out["flowt"][i].cpu().float() - gold[f"flowt_{i}"]).abs().flatten()
+        assert float(d.mean()) < 0.05
+
+
+def test_fp32_stage_taps_vs_oracle(sd):
+    """Stage boundaries of SURVEY.md 8a against the oracle on the same seeded input."""
+    meta, _ = load_golden("r_128x192_t050")
+    x, coords, ts = golden_inputs(meta)
+    otaps = {}
+    with torch.no_grad():
+        orc.forward(sd, x, coords, ts, None, taps=otaps)
+    m = _model(sd, "fp32")
+    taps = {}
+    m.engine(DEV).forward(x.to(DEV), [(c[0].to(DEV), None) for c in coords], [t.to(DEV) for t in ts], taps=taps)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return maxabs(a, b) / (float(b.abs().max()) + 1e-12)
+
+    assert rel(nchw(taps["r01_fmap1"]), otaps["r01_fmap1"]) < 1e-4
+    assert rel(taps["r01_corr_l0"].reshape(otaps["r01_corr_l0"].shape), otaps["r01_corr_l0"]) < 1e-4
+    assert rel(taps["r01_corr_l3"].reshape(otaps["r01_corr_l3"].shape), otaps["r01_corr_l3"]) < 1e-4
+    assert rel(nchw(taps["r01_corr_it0"]), otaps["r01_corr_it0"]) < 1e-4
+    assert rel(nchw(taps["r01_net_it19"]), otaps["r01_net_it19"]) < 1e-3
+    assert rel(nchw(taps["f01"]), otaps["f01"]) < 1e-3
+    assert maxabs(taps["w1"].unsqueeze(1), otaps["w1"]) < 5e-3   # sqrt of a cancelling variance, see DESIGN.md
+    for k in ("pl0", "feat0_4", "feat0_8", "t0_latent", "t0_init_ft_4", "t0_upd_ft_4", "t0_final_res"):
+        assert rel(nchw(taps[k]), otaps[k]) < 1e-3, k
+
+
+def test_full_size_properties_bf16_vs_fp32_and_batch_consistency(sd):
+    """At the benchmark size (448x256, batch 8): bf16 vs fp32-mode PSNR, and batch invariance
+    (sample i of a batch-8 forward == the same pair run alone, up to atomic-order noise)."""
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    B, H, W = 8, 256, 448
+    x = synthetic_pairs(B, H, W, seed=42)
+    coords = [(orc.sample_coord_input(B, (H, W), [0.5], 1.0), None)]
+    ts = [0.5 * torch.ones(B)]
+    m32, m16 = _model(sd, "fp32"), _model(sd, "bf16")
+    o32 = _run(m32, x, coords, ts)
+    o16 = _run(m16, x, coords, ts)
+    assert torch.isfinite(o16["imgt_pred"][0]).all()
+    p = psnr(o16["imgt_pred"][0], o32["imgt_pred"][0])
+    assert p >= 40.0, p
+    one = _run(m32, x[3:4], [(coords[0][0][3:4], None)], [ts[0][3:4]])
+    assert psnr(one["imgt_pred"][0], o32["imgt_pred"][0][3:4]) >= 80.0
+    d = (one["flowt"][0] - o32["flowt"][0][3]).abs().flatten()
+    assert float(d.kthvalue(int(d.numel() * 0.999))[0]) < 2e-3
+    assert o32["flowt"][0].shape == (B, 2, H, W) and one["flowt"][0].shape == (2, H, W)

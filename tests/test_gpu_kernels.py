@@ -1,0 +1,80 @@
+"""GPU parity tests of every HIP kernel through the C ABI of libgimmvfi_hip.so (real MI355X)."""
+import pytest
+import torch
+
+import kernel_cases as kc
+from gimmvfi_hip import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["fp32", "bf16"])
+def rt(request):
+    from gimmvfi_hip.ops import Runtime
+
+    return Runtime(L.get(), request.param, "cuda:0")
+
+
+CONV_SHAPES = [
+    (1, 8, 12, 3, 5, 3, 3, {}),
+    (2, 9, 7, 20, 70, 3, 3, dict(stride=2, act1=L.ACT_RELU)),
+    (1, 6, 10, 40, 130, 1, 5, dict(act1=L.ACT_TANH)),
+    (1, 6, 10, 12, 33, 7, 7, dict(act1=L.ACT_PRELU, with_res=True)),
+    (1, 10, 10, 16, 16, 3, 3, dict(reflect=True, with_res=True, act2=L.ACT_LRELU)),
+    (1, 7, 9, 48, 24, 3, 3, dict(split=32, with_res=True, act2=L.ACT_PRELU, out_f32=True)),
+    (1, 5, 6, 35, 2, 1, 1, dict(act1=L.ACT_SIN, out_f32=True, out_scale=0.25)),
+    (1, 12, 12, 8, 64, 5, 5, dict(act1=L.ACT_SIGMOID, tile=128)),
+    # production shapes
+    (2, 64, 112, 256, 256, 3, 3, dict(act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),   # final decoder ResBlock
+    (2, 64, 112, 256, 256, 3, 3, dict(split=192)),                                          # two-source conv3/conv5
+    (4, 32, 56, 324, 256, 1, 1, dict(act1=L.ACT_RELU)),                                       # RAFT convc1 (324 -> pad)
+    (4, 32, 56, 384, 128, 5, 1, dict(split=128)),                                            # SepConvGRU geometry
+    (2, 128, 224, 3, 64, 7, 7, dict(stride=2, act1=L.ACT_RELU)),                              # encoder stem
+    (2, 64, 112, 273, 24, 3, 3, dict(out_f32=True)),                                         # 273-channel concat
+    (1, 40, 40, 648, 256, 1, 1, dict(act1=L.ACT_LRELU)),
+    (1, 33, 47, 18, 3, 7, 7, dict(out_f32=True, with_res=True)),                              # comb block, ragged size
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv(rt, shape):
+    *a, kw = shape
+    kc.conv_case(rt, *a, **kw)
+    torch.cuda.synchronize()
+
+
+def test_gru_epilogues(rt):
+    kc.gru_case(rt, kh=1, kw=5)
+    kc.gru_case(rt, kh=5, kw=1, seed=1)
+    kc.gru_case(rt, N=2, H=32, W=56, C=128, kh=1, kw=5, seed=2)
+
+
+def test_corr_volume_grouped_gemm(rt):
+    kc.corr_volume_case(rt)
+    kc.corr_volume_case(rt, B=2, h=32, w=56, C=256, seed=3)
+
+
+def test_instnorm(rt):
+    kc.instnorm_case(rt)
+    kc.instnorm_case(rt, N=2, H=64, W=112, C=96)
+
+
+def test_resize_warp_shuffle(rt):
+    kc.resize_warp_shuffle_case(rt)
+
+
+def test_corr_lookup(rt):
+    kc.corr_lookup_case(rt)
+
+
+def test_convex_upsample(rt):
+    kc.convex_upsample_case(rt)
+
+
+def test_softsplat_edge_cases(rt):
+    kc.splat_case(rt)
+    kc.splat_case(rt, B=2, H=64, W=96)
+
+
+def test_splat_weights_and_flow_norm(rt, sd):
+    kc.splat_weights_and_norm_case(rt, sd)
