@@ -15,15 +15,18 @@ __global__ void flow_absmax_kernel(const float* __restrict__ f01, const float* _
         m = fmaxf(m, fabsf(f01[b * per_b + i]));
         m = fmaxf(m, fabsf(f10[b * per_b + i]));
     }
+    // wave-level max first (64 lanes), then one atomic per wave instead of one per thread
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     union { float f; unsigned u; } c;
     c.f = m;
-    atomicMax(scaler + b, c.u);
+    if ((threadIdx.x & 63) == 0) atomicMax(scaler + b, c.u);
 }
 extern "C" int gvfi_flow_absmax(const float* f01, const float* f10, float* scaler, int B, int HW, void* stream) {
     const long long per_b = 2LL * HW;
     dim3 grid((unsigned)(per_b < 64 * GVFI_BLOCK ? (per_b + GVFI_BLOCK - 1) / GVFI_BLOCK : 64), (unsigned)B);
-    GVFI_LAUNCH_SIMPLE(flow_absmax_kernel, grid, dim3(GVFI_BLOCK), (hipStream_t)stream, f01, f10, (unsigned*)scaler,
-                       per_b);
+    GVFI_LAUNCH_COOP(flow_absmax_kernel, grid, dim3(GVFI_BLOCK), (hipStream_t)stream, f01, f10, (unsigned*)scaler,
+                     per_b);
     return (int)hipGetLastError();
 }
 

@@ -109,7 +109,7 @@ class Runtime:
     # ------------------------------------------------------------------ convolution
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0):
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0):
         x0 = V(x0)
         out = V(out)
         p = L.ConvParams()
@@ -165,6 +165,7 @@ class Runtime:
             aux1 = V(aux1)
             p.aux1, p.lda1 = aux1.ptr, aux1.ld
         p.tile_hint = tile
+        p.algo = algo
         if self.ev_log is None:
             self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
         else:
@@ -175,9 +176,16 @@ class Runtime:
             self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
             e1.record()
             bn = tile if tile else (128 if p.Cout > 64 else (64 if p.Cout > 32 else 32))
+            bke = 8 * self.VE
+            glds = algo == 2 or (algo == 0 and p.c0 % bke == 0 and p.c1 % bke == 0 and p.Cout > 32 and pm == L.PAD_ZEROS)
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
-            tag = f"conv_igemm_kernel<{'float' if self.dtype == L.F32 else 'bf16'},128,{bn}>"
+            bm = 128
+            if glds:
+                m_pix = n * p.Ho * p.Wo // max(groups, 1)
+                bn = tile if tile else (256 if (p.Cout >= 192 and m_pix >= 65536) else (128 if p.Cout > 64 else 64))
+                bm = 256 if bn == 256 else 128
+            tag = f"conv_igemm{'_glds' if glds else ''}_kernel<{'float' if self.dtype == L.F32 else 'bf16'},{bm},{bn}>"
             self.ev_log.append((tag, flops, e0, e1))
         return out
 

@@ -64,10 +64,15 @@ typedef struct {
     void* y2; int ldy2;                 /* GRU_ZR: r*h destination                          */
     const void* aux0; int lda0;         /* GRU: h                                           */
     const void* aux1; int lda1;         /* GRU_Q: z                                         */
-    int tile_hint;                      /* 0 = auto                                         */
+    int tile_hint;                      /* 0 = auto, else Cout tile width 32/64/128         */
+    int algo;                           /* 0 = auto, 1 = generic register-staged kernel,    *
+                                         * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32) */
 } gvfi_conv_params;
 
 int gvfi_conv2d(const gvfi_conv_params* p, void* stream);
+/* the two kernels behind gvfi_conv2d (exposed for A/B measurements) */
+int gvfi_conv2d_glds_eligible(const gvfi_conv_params* p);
+int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
 
 /* ---- input preparation (gimmvfi_r.py:230-231,329-337,349; raft/raft.py:111-112) ------ */
 /* bilinear resize of float planes, align_corners=False, rscale = (float)(1.0/scale_factor)

@@ -16,6 +16,8 @@
 #include <barrier>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -40,6 +42,7 @@ static inline float4 make_float4(float a, float b, float c, float d) { return fl
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 
 using std::isfinite;
+#define __builtin_amdgcn_readfirstlane(x) (x)
 typedef void* hipStream_t;
 typedef int hipError_t;
 static inline int hipGetLastError() { return 0; }
@@ -163,6 +166,21 @@ static inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     }
     emu::wave_sync();
     return c;
+}
+
+// ---- LDS-DMA emulation: global_load_lds_dwordx4 writes lane-linear at a WAVE-UNIFORM base -----------
+#include <cassert>
+static inline void emu_glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    uint32_t* s = emu::wave_scratch();
+    const int l = emu::tl_lane;
+    uint64_t b = reinterpret_cast<uint64_t>(lds_wave_base);
+    std::memcpy(&s[l * 16], &b, 8);
+    emu::wave_sync();
+    uint64_t b0;
+    std::memcpy(&b0, &s[0], 8);
+    if (b0 != b) { std::fprintf(stderr, "emu_glds16: LDS base is not wave-uniform\n"); std::abort(); }
+    emu::wave_sync();
+    std::memcpy(lds_wave_base + l * 16, gsrc, 16);
 }
 
 // ---- launches -----------------------------------------------------------------------------

@@ -34,7 +34,7 @@ def tol(rt, scale):
 
 
 def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.ACT_NONE, with_res=False,
-              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0):
+              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
@@ -61,7 +61,7 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
         res = _to_act(rt, r).to(dev)
     out = (rt.f32(N, Ho, Wo, Cout + 3, zero=True) if out_f32 else rt.act(N, Ho, Wo, Cout + 3, zero=True))
     rt.conv(lay, x0, View(out, 2, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
-            slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile)
+            slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile, algo=algo)
     xi = F.pad(x, (pw, pw, ph, ph), mode="reflect") if reflect else x
     ref = F.conv2d(xi, w, b, stride=stride, padding=0 if reflect else (ph, pw))
 

@@ -23,6 +23,13 @@ CONV_SHAPES = [
     (1, 7, 9, 48, 24, 3, 3, dict(split=32, with_res=True, act2=L.ACT_PRELU, out_f32=True)),
     (1, 5, 6, 35, 2, 1, 1, dict(act1=L.ACT_SIN, out_f32=True, out_scale=0.25)),
     (1, 12, 12, 8, 64, 5, 5, dict(stride=1, act1=L.ACT_SIGMOID, tile=128)),
+    # channel counts that are multiples of a K chunk -> LDS-DMA kernel (conv_igemm_glds.hip)
+    (1, 6, 10, 64, 70, 3, 3, dict(act1=L.ACT_RELU, with_res=True)),
+    (1, 5, 9, 128, 48, 1, 5, dict(split=64, act1=L.ACT_PRELU)),
+    (2, 7, 7, 64, 130, 3, 3, dict(stride=2, out_f32=True)),
+    (1, 9, 9, 64, 40, 3, 3, dict(reflect=True, with_res=True, act2=L.ACT_LRELU)),
+    (1, 6, 10, 64, 70, 3, 3, dict(act1=L.ACT_RELU, with_res=True, algo=1)),   # same shape, generic kernel
+    (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),  # 8-wave 256x256 tile
 ]
 
 

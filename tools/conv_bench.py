@@ -1,0 +1,64 @@
+"""A/B micro-benchmark of the convolution kernels on production shapes (GPU only).
+usage: python tools/conv_bench.py [precision]"""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "gimm-vfi_amd"))
+import torch  # noqa: E402
+
+from gimmvfi_hip import lib as L  # noqa: E402
+from gimmvfi_hip.ops import ConvLayer, Runtime, View  # noqa: E402
+
+SHAPES = [
+    # name, N, H, W, Cin, Cout, KH, KW, split
+    ("final.resblock 256->256 3x3 @256x448 B8", 8, 256, 448, 256, 256, 3, 3, None),
+    ("final.resblock 192+64->256 3x3", 8, 256, 448, 256, 256, 3, 3, 192),
+    ("final.side 64->64 3x3", 8, 256, 448, 64, 64, 3, 3, None),
+    ("raft gru 128+256->256 1x5 @32x56 B16", 16, 32, 56, 384, 256, 1, 5, 128),
+    ("raft convc2 256->192 3x3", 16, 32, 56, 256, 192, 3, 3, None),
+    ("init.resblock 128->128 3x3 @64x112 B8", 8, 64, 112, 128, 128, 3, 3, None),
+    ("upd_high 320->192 3x3 @64x112", 8, 64, 112, 320, 192, 3, 3, None),
+]
+
+
+def main():
+    prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    rt = Runtime(L.get(), prec, "cuda:0")
+    for name, N, H, W, Cin, Cout, KH, KW, split in SHAPES:
+        w = torch.randn(Cout, Cin, KH, KW) / (Cin * KH * KW) ** 0.5
+        lay = ConvLayer(rt, w, torch.randn(Cout))
+        x = torch.randn(N, H, W, Cin, device="cuda").to(rt.tdtype)
+        if split is None:
+            x0, x1 = View(x, 0, Cin), None
+        else:
+            xa = x[..., :split].contiguous()
+            xb = x[..., split:].contiguous()
+            x0, x1 = View(xa, 0, split), View(xb, 0, Cin - split)
+        out = rt.act(N, H, W, Cout)
+        flops = 2.0 * N * H * W * Cout * Cin * KH * KW
+        res = {}
+        outs = {}
+        for algo, tile in ((1, 0), (2, 128), (2, 256)):
+            if tile == 256 and Cout < 192:
+                continue
+            for _ in range(2):
+                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            res[(algo, tile)] = (ms, flops / ms / 1e9)
+            outs[(algo, tile)] = out.float().clone()
+        ref = outs[(1, 0)]
+        txt = " | ".join(f"a{k[0]}t{k[1]} {v[0]:7.3f} ms {v[1]:6.1f} TF/s d={float((outs[k]-ref).abs().max()):.1e}" for k, v in res.items())
+        print(f"{name:42s} {txt}")
+
+
+if __name__ == "__main__":
+    main()
