@@ -35,10 +35,13 @@ class GIMMVFI_R(nn.Module):
         super().__init__()
         self.config = config
         self.raft_iter = 20  # gimmvfi_r.py:41 (config.raft_iter is ignored by the reference too)
-        self.precision = precision or os.environ.get("GIMMVFI_PRECISION", "bf16")
+        cfg_prec = None
+        if config is not None:
+            cfg_prec = config.get("precision") if isinstance(config, dict) else getattr(config, "precision", None)
+        self.precision = precision or cfg_prec or os.environ.get("GIMMVFI_PRECISION", "bf16")
         self.coord_range = (-1.0, 1.0)
         if config is not None:
-            cr = config["coord_range"] if isinstance(config, dict) else getattr(config, "coord_range", None)
+            cr = config.get("coord_range") if isinstance(config, dict) else getattr(config, "coord_range", None)
             if cr is not None:
                 self.coord_range = (float(cr[0]), float(cr[1]))
         sd0 = random_state_dict(0)

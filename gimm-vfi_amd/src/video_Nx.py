@@ -1,0 +1,176 @@
+"""Nx video frame interpolation CLI -- drop-in for reference src/video_Nx.py (same flags, same outputs):
+
+    python src/video_Nx.py --source-path DIR --output-path DIR --ds-factor F --N K -m CFG.yaml -l CKPT --eval
+
+writes OUT/output.mp4 (side-by-side [original | interpolated], fps 2N) and OUT/flow.mp4 (colour-coded
+flow_t).  Differences: runs on the MI355X HIP kernels (no CuPy / CUDA), and under
+``python -m torch.distributed.run --nproc-per-node G`` the frame pairs are sharded over G GPUs with one
+RCCL gather of the uint8 result frames to rank 0.  Without OpenCV the frames are written as PNGs
+(OUT/output_frames, OUT/flow_frames) and encoded with ffmpeg when it is on PATH.
+``--random-init`` (addition) runs with seeded random weights when no checkpoint is available."""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import torch
+from PIL import Image
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from models import create_model  # noqa: E402
+from utils.flow_viz import flow_to_image  # noqa: E402
+from utils.setup import single_setup  # noqa: E402
+from utils.utils import InputPadder, set_seed  # noqa: E402
+
+from gimmvfi_hip import shard  # noqa: E402  (models/__init__ put the package root on sys.path)
+
+try:
+    import cv2
+except Exception:  # OpenCV is optional
+    cv2 = None
+try:
+    from tqdm import tqdm
+except Exception:
+    def tqdm(x):
+        return x
+
+
+def default_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-m", "--model-config", type=str, default="./configs/gimmvfi/gimmvfi_r_arb.yaml")
+    parser.add_argument("--source-path", type=str, default="")
+    parser.add_argument("--output-path", type=str, default="")
+    parser.add_argument("--N", type=int, default=8)
+    parser.add_argument("--ds-factor", type=float, default=1.0)
+    parser.add_argument("-r", "--result-path", type=str, default="./results.tmp")
+    parser.add_argument("-l", "--load-path", type=str, default="")
+    parser.add_argument("-p", "--postfix", type=str, default="")
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--eval", action="store_true")
+    parser.add_argument("--random-init", action="store_true", help="seeded random weights instead of a checkpoint")
+    parser.add_argument("--precision", type=str, default=None, choices=[None, "bf16", "fp32"])
+    return parser
+
+
+def parse_args(argv=None):
+    return default_parser().parse_known_args(argv)
+
+
+def load_image(img_path):
+    # reference video_Nx.py:46-50
+    raw = np.array(Image.open(img_path).convert("RGB"))
+    return (torch.from_numpy(raw.copy()).permute(2, 0, 1) / 255.0).to(torch.float).unsqueeze(0)
+
+
+def to_bgr_u8(img_chw):
+    """float CHW in [0,1] -> uint8 HWC BGR (truncation, reference video_Nx.py:140-148)."""
+    return (img_chw.detach().cpu().numpy().transpose(1, 2, 0) * 255.0)[:, :, ::-1].astype(np.uint8)
+
+
+def images_to_video(imgs, output_video_path, fps=15):
+    # reference video_Nx.py:53-84 (cv2.VideoWriter, ffmpeg for > 2048); PNG fallback without OpenCV
+    height, width, _ = imgs[0].shape
+    big = max(height, width // 2) > 2048
+    if cv2 is not None and not big:
+        video = cv2.VideoWriter(output_video_path, cv2.VideoWriter_fourcc(*"mp4v"), fps, (width, height))
+        for img in imgs:
+            video.write(img)
+        video.release()
+        return output_video_path
+    frame_dir = os.path.splitext(output_video_path)[0] + "_frames"
+    os.makedirs(frame_dir, exist_ok=True)
+    for idx, img in enumerate(imgs):
+        Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(os.path.join(frame_dir, f"{idx:04d}.png"))
+    if shutil.which("ffmpeg"):
+        subprocess.run(["ffmpeg", "-y", "-framerate", f"{fps}", "-i", f"{frame_dir}/%04d.png", "-c:v", "libx264",
+                        "-pix_fmt", "yuv420p", output_video_path])
+        shutil.rmtree(frame_dir, ignore_errors=True)
+        return output_video_path
+    return frame_dir
+
+
+def main(argv=None):
+    args, extra_args = parse_args(argv)
+    set_seed(args.seed)
+    config = single_setup(args, extra_args)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=device)
+
+    os.makedirs(args.output_path, exist_ok=True)
+    if args.precision is not None:
+        config.arch["precision"] = args.precision
+    model, _ = create_model(config.arch)
+    if args.load_path != "":
+        ckpt = torch.load(args.load_path, map_location="cpu")
+        model.load_state_dict(ckpt["state_dict"], strict=True)
+    elif args.random_init:
+        from gimmvfi_hip.params import random_state_dict
+
+        model.load_state_dict(random_state_dict(args.seed), strict=True)
+    elif args.eval:
+        raise ValueError("--load-path must be specified in evaluation or resume mode")
+    model = model.to(device).eval()
+
+    img_list = sorted(os.listdir(args.source_path))
+    num_pairs = len(img_list) - 1
+    N = args.N
+    p0, p1 = shard.pair_range(num_pairs, rank, world)
+    local_frames = []   # per pair: uint8 [N-1, 2, H, W, 3] (interpolated frame, flow image), BGR
+    ds_factor = args.ds_factor
+    for j in tqdm(range(p0, p1)):
+        I0 = load_image(os.path.join(args.source_path, img_list[j]))
+        I2 = load_image(os.path.join(args.source_path, img_list[j + 1]))
+        padder = InputPadder(I0.shape, 32)
+        I0p, I2p = padder.pad(I0, I2)
+        xs = torch.cat((I0p.unsqueeze(2), I2p.unsqueeze(2)), dim=2).to(device, non_blocking=True)
+        batch_size, s_shape = xs.shape[0], xs.shape[-2:]
+        with torch.no_grad():
+            coord_inputs = [
+                (model.sample_coord_input(batch_size, s_shape, [1 / N * i], device=xs.device, upsample_ratio=ds_factor), None)
+                for i in range(1, N)
+            ]
+            timesteps = [i * 1 / N * torch.ones(batch_size, device=xs.device, dtype=torch.float) for i in range(1, N)]
+            out = model(xs, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
+        frames = []
+        for i in range(N - 1):
+            pred = padder.unpad(out["imgt_pred"][i])[0]
+            flow = padder.unpad(out["flowt"][i]).squeeze()
+            fimg = flow_to_image(flow.detach().cpu().permute(1, 2, 0).numpy(), convert_to_bgr=True)
+            if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
+                fimg = np.array(Image.fromarray(fimg).resize((pred.shape[-1], pred.shape[-2]), Image.BILINEAR))
+            frames.append(np.stack([to_bgr_u8(pred), fimg], 0))
+        local_frames.append(np.stack(frames, 0))
+    if local_frames:
+        lf = torch.from_numpy(np.stack(local_frames, 0)).to(device)
+    else:
+        h, w = Image.open(os.path.join(args.source_path, img_list[0])).size[::-1]
+        lf = torch.zeros((0, N - 1, 2, h, w, 3), dtype=torch.uint8, device=device)
+    allf = shard.gather_frames(lf, num_pairs, rank, world)   # RCCL gather of the result frames
+    if rank == 0:
+        allf = allf.cpu().numpy()
+        originals = [to_bgr_u8(load_image(os.path.join(args.source_path, f))[0]) for f in img_list]
+        images, flows = [np.concatenate([originals[0], originals[0]], 1)], []
+        for j in range(num_pairs):
+            for i in range(N - 1):
+                images.append(np.concatenate([originals[j], allf[j, i, 0]], 1))   # cv2.hconcat([orig, interp])
+                flows.append(allf[j, i, 1])
+            images.append(np.concatenate([originals[j + 1], originals[j + 1]], 1))
+        o1 = images_to_video(images[:-1], os.path.join(args.output_path, "output.mp4"), fps=N * 2)
+        o2 = images_to_video(flows, os.path.join(args.output_path, "flow.mp4"), fps=N * 2)
+        print("=========================Interpolation Finished=========================")
+        print(len(images), o1, o2)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""Host-side logic on the CPU: pair sharding + result gather over gloo (world_size 2), the CLI's
+config / padding / flow-colour helpers, and the synthetic data generator."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gimmvfi_hip import shard
+from util import ROOT
+
+SRC = os.path.join(ROOT, "gimm-vfi_amd", "src")
+
+
+def test_pair_range_partitions_contiguously():
+    for m in (0, 1, 7, 8, 9, 31):
+        for w in (1, 2, 3, 8):
+            rs = [shard.pair_range(m, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, num_pairs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard.pair_range(num_pairs, rank, world)
+    # frame j of this rank's pairs is filled with the global pair index
+    local = torch.stack([torch.full((3, 4, 5, 3), j, dtype=torch.uint8) for j in range(a, b)]) if b > a else \
+        torch.zeros((0, 3, 4, 5, 3), dtype=torch.uint8)
+    out = shard.gather_frames(local, num_pairs, rank, world)
+    if rank == 0:
+        q.put(out.numpy())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_pairs", [5, 2, 1])
+def test_gather_frames_gloo_world2(num_pairs):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, num_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got.shape == (num_pairs, 3, 4, 5, 3)
+    for j in range(num_pairs):
+        assert (got[j] == j).all()
+
+
+def test_cli_helpers_config_padder_flowviz():
+    sys.path.insert(0, SRC)
+    try:
+        from utils.flow_viz import flow_to_image, make_colorwheel
+        from utils.setup import load_config
+        from utils.utils import InputPadder
+    finally:
+        sys.path.remove(SRC)
+    cfg = load_config(os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml"))
+    assert cfg.arch.type == "gimmvfi_r" and cfg.arch.hyponet.activation.siren_w0 == 1.0
+    assert cfg.arch.fwarp_type == "linear" and cfg.arch.raft_iter == 20 and cfg.arch.hyponet.output_bias == 0.5
+    x = torch.arange(2 * 3 * 45 * 70, dtype=torch.float32).reshape(2, 3, 45, 70)
+    pad = InputPadder(x.shape, 32)
+    xp = pad.pad(x)
+    assert xp.shape[-2:] == (64, 96)
+    assert torch.equal(pad.unpad(xp), x)
+    assert torch.equal(xp[..., 0, :], xp[..., 9, :])     # replicate padding, centred (9 rows on top)
+    wheel = make_colorwheel()
+    assert wheel.shape == (55, 3) and wheel[0].tolist() == [255, 0, 0] and wheel[15].tolist() == [255, 255, 0]
+    flow = np.stack(np.meshgrid(np.linspace(-3, 3, 16), np.linspace(-2, 2, 12)), -1).astype(np.float32)
+    img = flow_to_image(flow, convert_to_bgr=True)
+    assert img.shape == (12, 16, 3) and img.dtype == np.uint8
+    rgb = flow_to_image(flow)
+    assert (img[..., ::-1] == rgb).all()
+
+
+def test_synthetic_pairs_are_seeded_and_quantised():
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    a = synthetic_pairs(2, 64, 96, seed=5)
+    b = synthetic_pairs(2, 64, 96, seed=5)
+    assert torch.equal(a, b) and a.shape == (2, 3, 2, 64, 96)
+    assert float(a.min()) >= 0 and float(a.max()) <= 1
+    assert torch.equal(torch.round(a * 255), a * 255 + 0 * a) or float((torch.round(a * 255) - a * 255).abs().max()) < 1e-4
+    assert not torch.equal(a[0], a[1])
