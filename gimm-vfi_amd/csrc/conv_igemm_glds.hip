@@ -28,9 +28,24 @@ __device__ __forceinline__ f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __attribute__((aligned(16))) unsigned int gvfi_zero_page[16];   // zero-initialised
+// LDS-DMA issued through inline asm ON PURPOSE: with the builtin, hipcc treats the DMA as a pending LDS write
+// and puts `s_waitcnt vmcnt(0)` in front of the next ds_read of the same __shared__ array, which serialises
+// the prefetch of chunk k+1 behind the MFMAs of chunk k.  An asm statement is invisible to its waitcnt
+// bookkeeping (cdna_hip_programming.md section 5.7); completion is awaited explicitly by glds_wait() +
+// __syncthreads() at the top of the K loop.  M0 (LDS destination base) is saved/restored in the statement.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
 }
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #else
@@ -62,6 +77,7 @@ struct ConvArgs2 {
     int Mg;          // output pixels per weight group
     int MT, NT;      // tiles
     int per_xcd;     // ceil(MT*NT / 8)
+    int dbg;         // ablation switches for profiling (algo >> 4): 1 = no A DMA, 2 = no B DMA, 4 = no MFMA
     long long Ktot;  // weight row length in elements
 };
 
@@ -71,6 +87,17 @@ struct ConvArgs2 {
 // 8 consecutive output channels of one pixel: bias / activation / residual / GRU gate math on 8 values
 // and ONE 16-byte store (bf16) or two (f32), fully coalesced along the channel axis.  This keeps the
 // register footprint of the epilogue tiny (no spills with 128 accumulators) and replaces 2-byte stores.
+// two floats -> packed bf16x2 (round to nearest even); the native cast lets hipcc emit v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#ifndef GVFI_HOSTSIM
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+#else
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#endif
+}
 __device__ __forceinline__ void ld8(const void* base, long long idx, int is_f32, bool bf16_elems, float (&o)[8]) {
     if (is_f32 || !bf16_elems) {
         const float4 a = *(const float4*)((const float*)base + idx);
@@ -90,10 +117,10 @@ __device__ __forceinline__ void st8(void* base, long long idx, int is_f32, bool 
         *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
         uint4 u;
-        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        u.x = pack_bf16x2(v[0], v[1]);
+        u.y = pack_bf16x2(v[2], v[3]);
+        u.z = pack_bf16x2(v[4], v[5]);
+        u.w = pack_bf16x2(v[6], v[7]);
         *(uint4*)((bf16_t*)base + idx) = u;
     }
 }
@@ -106,21 +133,51 @@ __device__ __forceinline__ void act8(float (&v)[8], int act, const float* slope,
     for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], act, slope, cout0 + e);
 }
 
+// per-thread constants of its channel group (the group index is the same in every iteration of the
+// epilogue loop because GROUPS_PER_ROW divides the thread count): bias and PReLU slopes are loaded once
+struct GroupConst {
+    float bias[8], s1[8], s2[8];
+};
+__device__ __forceinline__ void act8s(float (&v)[8], int act, const float (&s)[8]) {
+    // one branch per 8 values, never per element
+    switch (act) {
+        case GVFI_ACT_NONE: break;
+        case GVFI_ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            break;
+        case GVFI_ACT_LRELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
+            break;
+        case GVFI_ACT_PRELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : s[e] * v[e];
+            break;
+        case GVFI_ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gvfi_sigmoid(v[e]);
+            break;
+        case GVFI_ACT_TANH:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            break;
+        default:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = sinf(v[e]);
+            break;
+    }
+}
+
 // one group of 8 channels [cout0, cout0+8) of output pixel `pix`; `n_valid` channels are real
 template <typename T>
-__device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, float (&v)[8], int cout0, int n_valid,
-                                               long long pix, bool vec) {
+__device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const GroupConst& gc, float (&v)[8], int cout0,
+                                               int n_valid, long long pix, bool vec) {
     constexpr bool BF = sizeof(T) == 2;
-    const int eT = (int)sizeof(T);
-    if (p.bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (e < n_valid) ? p.bias[cout0 + e] : 0.f;
-    }
+    for (int e = 0; e < 8; ++e) v[e] += gc.bias[e];
     if (p.epi_mode == GVFI_EPI_STD) {
-        if (p.act1 != GVFI_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act1, p.slope1, (e < n_valid) ? cout0 + e : cout0);
-        }
+        act8s(v, p.act1, gc.s1);
         if (p.res) {
             float r[8];
             if (vec) ld8(p.res, pix * p.ldr + cout0, p.res_f32, BF, r);
@@ -131,12 +188,11 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, float 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
-        if (p.act2 != GVFI_ACT_NONE) {
+        act8s(v, p.act2, gc.s2);
+        if (p.out_scale != 1.0f) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act2, p.slope2, (e < n_valid) ? cout0 + e : cout0);
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
         if (vec) st8(p.y, pix * p.ldy + cout0, p.y_f32, BF, v);
         else {
 #pragma unroll
@@ -188,7 +244,6 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, float 
             for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, 0, v[e]);
         }
     }
-    (void)eT;
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -253,7 +308,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     for (int i = 0; i < B_INSTR; ++i) {
         const int row = (wave * B_INSTR + i) * 8 + lrow;
         const int n = n0 + row;
-        b_src[i] = (n < p.Cout) ? wg + (long long)n * a.Ktot + (lslot ^ ((row >> 1) & 7)) * VE : (const T*)nullptr;
+        if (p.w_layout == 1)   // chunk-major, pre-swizzled image: [K chunk][Cout][128 B] == the LDS image, linear
+            b_src[i] = (n < p.Cout) ? wg + ((long long)n * 8 + lslot) * VE : (const T*)nullptr;
+        else
+            b_src[i] = (n < p.Cout) ? wg + (long long)n * a.Ktot + (lslot ^ ((row >> 1) & 7)) * VE : (const T*)nullptr;
     }
 
     f32x16 acc[MI][NI];
@@ -268,59 +326,91 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     const int fhalf = lane >> 5;
 
     int kh = 0, kw = 0, ck = 0;   // wave-uniform K walker of the NEXT chunk to stage
-    auto stage = [&](int kt, int buf) {
-        unsigned char* sa = smem + buf * STAGE;
-        unsigned char* sb = sa + BM * RB;
+    // per-chunk uniform staging state (set by stage_begin, consumed by stage_piece)
+    const T* st_xs = x0;
+    int st_ld = 0, st_cbase = 0, st_tapoff = 0, st_kh = 0, st_kw = 0;
+    long long st_kbase = 0;
+    unsigned char* st_sa = smem;
+    auto stage_begin = [&](int kt, int buf) {
+        st_sa = smem + buf * STAGE;
         const bool from0 = ck < a.chunks0;
-        const T* xs = from0 ? x0 : x1;
-        const int ld = from0 ? p.ld0 : p.ld1;
-        const int cbase = (from0 ? ck : ck - a.chunks0) * BKE;
-        const int tapoff = kh * p.W + kw;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-            const T* s = xs + (long long)(a_pix[i] + tapoff) * ld + (cbase + a_koff[i]);
-            glds16(ok ? (const void*)s : (const void*)zero, sa + (wave * A_INSTR + i) * 1024);
-        }
-        const long long kbase = (long long)kt * BKE;
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const void* s = b_src[i] ? (const void*)(b_src[i] + kbase) : (const void*)zero;
-            glds16(s, sb + (wave * B_INSTR + i) * 1024);
-        }
+        st_xs = from0 ? x0 : x1;
+        st_ld = from0 ? p.ld0 : p.ld1;
+        st_cbase = (from0 ? ck : ck - a.chunks0) * BKE;
+        st_tapoff = kh * p.W + kw;
+        st_kh = kh;
+        st_kw = kw;
+        st_kbase = p.w_layout == 1 ? (long long)kt * p.Cout * BKE : (long long)kt * BKE;
         if (++ck == a.chunks_tap) {
             ck = 0;
             if (++kw == p.KW) { kw = 0; ++kh; }
         }
     };
+    // one LDS-DMA instruction (1 KiB per wave): pieces [0, A_INSTR) are A rows, [A_INSTR, A_INSTR+B_INSTR) B rows
+    auto stage_piece = [&](int pc) {
+        if (pc < A_INSTR) {
+            if (a.dbg & 1) return;
+            const int i = pc;
+            const int iy = a_iy0[i] + st_kh, ix = a_ix0[i] + st_kw;
+            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const T* sp = st_xs + (long long)(a_pix[i] + st_tapoff) * st_ld + (st_cbase + a_koff[i]);
+            glds16(ok ? (const void*)sp : (const void*)zero, st_sa + (wave * A_INSTR + i) * 1024);
+        } else if (pc < A_INSTR + B_INSTR) {
+            if (a.dbg & 2) return;
+            const int i = pc - A_INSTR;
+            const void* sp = b_src[i] ? (const void*)(b_src[i] + st_kbase) : (const void*)zero;
+            glds16(sp, st_sa + BM * RB + (wave * B_INSTR + i) * 1024);
+        }
+    };
+    constexpr int NPIECE = A_INSTR + B_INSTR;
+    constexpr int PIECES_PER_KK = (NPIECE + 3) / 4;
 
-    stage(0, 0);
+    stage_begin(0, 0);
+#pragma unroll
+    for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc);
     for (int kt = 0; kt < a.KT; ++kt) {
         const int buf = kt & 1;
-        glds_wait();        // chunk kt has landed (issued one iteration ago)
+        glds_wait();        // chunk kt has landed (issued during the previous iteration)
         __syncthreads();    // ... for every wave; and every wave is done reading buffer buf^1
-        if (kt + 1 < a.KT) stage(kt + 1, buf ^ 1);   // prefetch overlaps the MFMAs below
+        const bool more = kt + 1 < a.KT;
+        if (more) stage_begin(kt + 1, buf ^ 1);
         const unsigned char* sa = smem + buf * STAGE;
         const unsigned char* sb = sa + BM * RB;
+        // The DMA pieces of chunk kt+1 are issued BETWEEN the MFMA groups of chunk kt: right after the barrier
+        // every wave of the workgroup is at the same point, and a burst of 8 DMA issues per wave (~150 cycles
+        // each) would leave the matrix pipe idle; spread out, each issue hides under the previous MFMAs.
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int slot = 2 * kk + fhalf;
             uint4 fa[MI], fb[NI];
+            if (!(a.dbg & 4)) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int row = wm * WM + i * 32 + frow;
+                    fa[i] = *(const uint4*)(sa + row * RB + ((slot ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int row = wn * WN + j * 32 + frow;
+                    fb[j] = *(const uint4*)(sb + row * RB + ((slot ^ ((row >> 1) & 7)) << 4));
+                }
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int row = wm * WM + i * 32 + frow;
-                fa[i] = *(const uint4*)(sa + row * RB + ((slot ^ ((row >> 1) & 7)) << 4));
+                if (!(a.dbg & 4)) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[i], fb[j]);
+                }
+                // after each half of the MFMA group issue one DMA piece of the next chunk
+                if (more && PIECES_PER_KK >= 1 && i == (MI - 1) / 2) {
+                    const int pc = kk * PIECES_PER_KK;
+                    if (pc < NPIECE) stage_piece(pc);
+                }
+                if (more && PIECES_PER_KK >= 2 && i == MI - 1) {
+                    const int pc = kk * PIECES_PER_KK + 1;
+                    if (pc < NPIECE) stage_piece(pc);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int row = wn * WN + j * 32 + frow;
-                fb[j] = *(const uint4*)(sb + row * RB + ((slot ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[i], fb[j]);
         }
     }
 
@@ -337,6 +427,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                          vec_ok(p.y2, p.ldy2, (int)sizeof(T)) && vec_ok(p.aux0, p.lda0, (int)sizeof(T)) &&
                          vec_ok(p.aux1, p.lda1, (int)sizeof(T)) &&
                          (p.bias == nullptr || true);
+    // this thread's channel group is fixed across the loop (NT % GROUPS_PER_ROW == 0): preload its constants
+    static_assert(NT % GROUPS_PER_ROW == 0, "group index must be loop invariant");
+    const int my_cg = tid % GROUPS_PER_ROW;
+    const int my_cout0 = n0 + my_cg * 8;
+    const int my_valid = (p.Cout - my_cout0) >= 8 ? 8 : (p.Cout - my_cout0 > 0 ? p.Cout - my_cout0 : 0);
+    GroupConst gc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool ok = e < my_valid;
+        gc.bias[e] = (ok && p.bias) ? p.bias[my_cout0 + e] : 0.f;
+        gc.s1[e] = (ok && p.act1 == GVFI_ACT_PRELU) ? p.slope1[my_cout0 + e] : 0.f;
+        gc.s2[e] = (ok && p.act2 == GVFI_ACT_PRELU) ? p.slope2[my_cout0 + e] : 0.f;
+    }
     __syncthreads();   // every wave is done reading the last staged chunk
 #pragma unroll 1
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -358,16 +461,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 #pragma unroll 1
         for (int idx = tid; idx < PASS_ROWS * GROUPS_PER_ROW; idx += NT) {
             const int row = idx / GROUPS_PER_ROW;
-            const int cg = idx - row * GROUPS_PER_ROW;
+            const int cg = my_cg;
             const long long m = m_tile0 + (long long)ps * PASS_ROWS + row;
-            const int cout0 = n0 + cg * 8;
-            if (m >= a.Mg || cout0 >= p.Cout) continue;
-            const int n_valid = (p.Cout - cout0) >= 8 ? 8 : (p.Cout - cout0);
+            const int cout0 = my_cout0;
+            if (m >= a.Mg || my_valid == 0) continue;
+            const int n_valid = my_valid;
             float vv[8];
             const float4 c0 = *(const float4*)(cs + row * BN + cg * 8);
             const float4 c1 = *(const float4*)(cs + row * BN + cg * 8 + 4);
             vv[0] = c0.x; vv[1] = c0.y; vv[2] = c0.z; vv[3] = c0.w; vv[4] = c1.x; vv[5] = c1.y; vv[6] = c1.z; vv[7] = c1.w;
-            epilogue_group<T>(p, vv, cout0, n_valid, (long long)g * a.Mg + m, vec_all && n_valid == 8);
+            epilogue_group<T>(p, gc, vv, cout0, n_valid, (long long)g * a.Mg + m, vec_all && n_valid == 8);
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
@@ -387,6 +490,7 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     a.MT = cdiv(a.Mg, BM);
     a.NT = cdiv(p.Cout, BN);
     a.per_xcd = cdiv((long long)a.MT * a.NT, 8);
+    a.dbg = p.algo >> 4;
     dim3 grid(a.per_xcd * 8, 1, groups);
     GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
     return (int)hipGetLastError();

@@ -46,6 +46,7 @@ class ConvParams(C.Structure):
         ("aux0", C.c_void_p), ("lda0", C.c_int),
         ("aux1", C.c_void_p), ("lda1", C.c_int),
         ("tile_hint", C.c_int),
+        ("w_layout", C.c_int),
         ("algo", C.c_int),
     ]
 

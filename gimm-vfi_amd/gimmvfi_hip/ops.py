@@ -6,6 +6,7 @@ C ABI.  ``Runtime`` carries the library handle, the element type of the
 activation tensors (bf16 fast path / fp32 validation path) and the device.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -61,6 +62,17 @@ class ConvLayer:
         pk = torch.zeros(cout, kh, kw, cp, dtype=torch.float32, device=w.device)
         pk[..., :cin] = w.detach().float().permute(0, 2, 3, 1)
         self.w = pk.to(rt.tdtype).contiguous().to(rt.device)
+        # second image for the LDS-DMA kernel: K-chunk major + pre-swizzled == the LDS tile, so the weight
+        # tile of a K chunk is one contiguous block (conv_igemm_glds.hip, w_layout = 1)
+        bke = 8 * rt.VE
+        self.w_glds = None
+        if cp % bke == 0 and cout > 32 and pad_mode == L.PAD_ZEROS and not os.environ.get("GVFI_NO_WGLDS"):
+            k = kh * kw * cp
+            wk = pk.reshape(cout, k // bke, 8, rt.VE)                         # [n][chunk][slot][ve]
+            sw = (torch.arange(cout, device=pk.device) >> 1) & 7                # (row>>1)&7 with row == n (tile bases are /16)
+            src_slot = torch.arange(8, device=pk.device)[None, :] ^ sw[:, None]    # dest slot s holds source slot s^sw
+            wk = torch.gather(wk, 2, src_slot[:, None, :, None].expand(cout, k // bke, 8, rt.VE))
+            self.w_glds = wk.permute(1, 0, 2, 3).contiguous().to(rt.tdtype).to(rt.device)   # [chunk][n][slot][ve]
         self.b = None if b is None else b.detach().float().contiguous().to(rt.device)
         self.slope = None if slope is None else slope.detach().float().contiguous().to(rt.device)
         self.cout, self.cin, self.cin_pad, self.kh, self.kw = cout, cin, cp, kh, kw
@@ -127,7 +139,13 @@ class Runtime:
         p.N, p.H, p.W = n, h, w_
         if layer is not None:
             assert p.c0 + p.c1 == layer.cin_pad, (p.c0, p.c1, layer.cin_pad)
-            p.w = layer.w.data_ptr()
+            bke_ = 8 * self.VE
+            use_glds = (algo & 15) != 1 and layer.w_glds is not None and p.c0 % bke_ == 0 and p.c1 % bke_ == 0
+            if use_glds:
+                p.w, p.w_layout = layer.w_glds.data_ptr(), 1
+                algo = 2 | (algo & ~15)
+            else:
+                p.w, p.w_layout = layer.w.data_ptr(), 0
             p.bias = None if layer.b is None else layer.b.data_ptr()
             kh, kw, st, (ph, pw), pm = layer.kh, layer.kw, layer.stride, layer.pad, layer.pad_mode
             p.Cout = layer.cout

@@ -65,6 +65,10 @@ typedef struct {
     const void* aux0; int lda0;         /* GRU: h                                           */
     const void* aux1; int lda1;         /* GRU_Q: z                                         */
     int tile_hint;                      /* 0 = auto, else Cout tile width 32/64/128         */
+    int w_layout;                       /* 0: [Cout][KH][KW][Cin];  1 (LDS-DMA kernel only): K-chunk major,  *
+                                         * [K/64][Cout][64] with the 16-byte groups of a row XOR-swizzled by *
+                                         * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
+                                         * contiguous copy (K chunk = 128 bytes)                             */
     int algo;                           /* 0 = auto, 1 = generic register-staged kernel,    *
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32) */
 } gvfi_conv_params;

@@ -24,8 +24,11 @@ SHAPES = [
 
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    only = sys.argv[2] if len(sys.argv) > 2 else None
     rt = Runtime(L.get(), prec, "cuda:0")
     for name, N, H, W, Cin, Cout, KH, KW, split in SHAPES:
+        if only is not None and only not in name:
+            continue
         w = torch.randn(Cout, Cin, KH, KW) / (Cin * KH * KW) ** 0.5
         lay = ConvLayer(rt, w, torch.randn(Cout))
         x = torch.randn(N, H, W, Cin, device="cuda").to(rt.tdtype)
@@ -39,7 +42,10 @@ def main():
         flops = 2.0 * N * H * W * Cout * Cin * KH * KW
         res = {}
         outs = {}
-        for algo, tile in ((1, 0), (2, 128), (2, 256)):
+        variants = ((1, 0), (2, 128), (2, 256))
+        if os.environ.get("ABLATE"):
+            variants = tuple((2 + 16 * m, 256) for m in (0, 1, 2, 3, 4, 7)) + tuple((2 + 16 * m, 128) for m in (0, 3, 4))
+        for algo, tile in variants:
             if tile == 256 and Cout < 192:
                 continue
             for _ in range(2):
@@ -55,7 +61,7 @@ def main():
             ms = e0.elapsed_time(e1) / reps
             res[(algo, tile)] = (ms, flops / ms / 1e9)
             outs[(algo, tile)] = out.float().clone()
-        ref = outs[(1, 0)]
+        ref = outs[(1, 0)] if (1, 0) in outs else next(iter(outs.values()))
         txt = " | ".join(f"a{k[0]}t{k[1]} {v[0]:7.3f} ms {v[1]:6.1f} TF/s d={float((outs[k]-ref).abs().max()):.1e}" for k, v in res.items())
         print(f"{name:42s} {txt}")
 
