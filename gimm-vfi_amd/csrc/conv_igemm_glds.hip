@@ -501,7 +501,7 @@ extern "C" int gvfi_conv2d_glds_eligible(const gvfi_conv_params* pp) {
     const gvfi_conv_params& p = *pp;
     const int bke = p.dtype == GVFI_F32 ? 32 : 64;
     if (p.c0 <= 0 || (p.c0 % bke) || (p.c1 % bke)) return 0;
-    if (p.Cout <= 32 || p.pad_mode != GVFI_PAD_ZEROS) return 0;
+    if (p.pad_mode != GVFI_PAD_ZEROS) return 0;
     return 1;
 }
 
@@ -513,12 +513,14 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     // tile width: 256 (8 waves, 256x256) for Cout >= 192 on large images, 128 (4 waves) for Cout > 64, else 64
     const long long M = (long long)p.N * p.Ho * p.Wo / (p.groups > 0 ? p.groups : 1);
     int tile = p.tile_hint;
-    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : 64);
+    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == GVFI_F32) {
         if (tile >= 256) return launch_glds<float, 256, 256, 2, 4>(p, st);
-        return tile >= 128 ? launch_glds<float, 128, 128, 2, 2>(p, st) : launch_glds<float, 128, 64, 2, 2>(p, st);
+        if (tile >= 128) return launch_glds<float, 128, 128, 2, 2>(p, st);
+        return tile >= 64 ? launch_glds<float, 128, 64, 2, 2>(p, st) : launch_glds<float, 128, 32, 4, 1>(p, st);
     }
     if (tile >= 256) return launch_glds<bf16_t, 256, 256, 2, 4>(p, st);
-    return tile >= 128 ? launch_glds<bf16_t, 128, 128, 2, 2>(p, st) : launch_glds<bf16_t, 128, 64, 2, 2>(p, st);
+    if (tile >= 128) return launch_glds<bf16_t, 128, 128, 2, 2>(p, st);
+    return tile >= 64 ? launch_glds<bf16_t, 128, 64, 2, 2>(p, st) : launch_glds<bf16_t, 128, 32, 4, 1>(p, st);
 }

@@ -64,7 +64,8 @@ class Engine:
         self._conv(sd, p + ".conv5", slope=p + ".prelu.weight")
 
     def _build_update(self, sd, p):
-        for k in ("convc1", "convc2", "convf1", "convf2", "conv", "gru.0", "gru.2", "feat_head.0", "feat_head.2",
+        self._conv(sd, f"{p}.convc1", cin_pad=self.rt.cp64(648))   # padded to a K chunk -> LDS-DMA kernel
+        for k in ("convc2", "convf1", "convf2", "conv", "gru.0", "gru.2", "feat_head.0", "feat_head.2",
                   "flow_head.0", "flow_head.2"):
             self._conv(sd, f"{p}.{k}")
 
@@ -77,7 +78,8 @@ class Engine:
         self._add("cnet.out_net", w[:128], b[:128])   # tanh half   raft/raft.py:134-136
         self._add("cnet.out_inp", w[128:], b[128:])   # relu half
         u = fe + ".update_block"
-        for k in ("encoder.convc1", "encoder.convc2", "encoder.convf1", "encoder.convf2", "encoder.conv",
+        self._conv(sd, f"{u}.encoder.convc1", cin_pad=self.rt.cp64(324))
+        for k in ("encoder.convc2", "encoder.convf1", "encoder.convf2", "encoder.conv",
                   "flow_head.conv1", "flow_head.conv2", "mask.0", "mask.2"):
             self._conv(sd, f"{u}.{k}")
         for n in ("1", "2"):
@@ -91,7 +93,7 @@ class Engine:
         for i in (1, 2, 3, 4, 5):
             self._conv(sd, f"{p}.upsample.{i}.0", slope=f"{p}.upsample.{i}.1.weight")
         self._conv(sd, p + ".upsample.6", bn=p + ".upsample.7")
-        self._conv(sd, p + ".convblock.0.0", slope=p + ".convblock.0.1.weight")
+        self._conv(sd, p + ".convblock.0.0", slope=p + ".convblock.0.1.weight", cin_pad=self.rt.cp64(272))
         for i in (1, 2, 3):
             self._build_resblock(sd, f"{p}.convblock.{i}")
         w, b = sd[p + ".convblock.4.weight"], sd[p + ".convblock.4.bias"]
@@ -101,7 +103,7 @@ class Engine:
         for i in (2, 3, 4, 5, 6):
             self._conv(sd, f"{p}.upsample.{i}.0", slope=f"{p}.upsample.{i}.1.weight")
         self._conv(sd, p + ".upsample.7", bn=p + ".upsample.8")
-        self._conv(sd, p + ".convblock.0.0", slope=p + ".convblock.0.1.weight")
+        self._conv(sd, p + ".convblock.0.0", slope=p + ".convblock.0.1.weight", cin_pad=self.rt.cp64(273))
         for i in (1, 2, 3):
             self._build_resblock(sd, f"{p}.convblock.{i}")
         self._conv(sd, p + ".convblock.4")
@@ -226,7 +228,7 @@ class Engine:
             taps["r01_corr_l0"] = pyr_a[0]
             taps["r01_corr_l3"] = pyr_a[3]
         coords = rt.coords_init(n, h8, w8)
-        corrf = rt.act(n, h8, w8, 324, zero=True)
+        corrf = rt.act(n, h8, w8, 324, zero=True, pitch=rt.cp64(324))
         flow8 = rt.act(n, h8, w8, 2, zero=True)
         c1 = rt.act(n, h8, w8, 256)
         corflo = rt.act(n, h8, w8, 256)
@@ -239,7 +241,7 @@ class Engine:
             rt.corr_lookup(pyr_a, coords[:B], corrf[:B], B, h8, w8, h8, w8)
             rt.corr_lookup(pyr_b, coords[B:], corrf[B:], B, h8, w8, h8, w8)
             rt.flow_pack(coords, flow8, View(xbuf, 254, 2))
-            rt.conv(Ls[u + ".encoder.convc1"], View(corrf, 0, 324), c1, act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.convc1"], corrf, c1, act1=A.ACT_RELU)
             rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
             rt.conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, act1=A.ACT_RELU)
             rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
@@ -267,7 +269,7 @@ class Engine:
         """modules/fi_components.py:199-222.  net: [B,h,w,128] (already down-sampled for the low block)."""
         rt, Ls = self.rt, self.layers
         c1 = rt.act(B, h, w, 256)
-        rt.conv(Ls[p + ".convc1"], View(corr, 0, 648), c1, act1=A.ACT_LRELU)
+        rt.conv(Ls[p + ".convc1"], corr, c1, act1=A.ACT_LRELU)
         corflo = rt.act(B, h, w, 256)
         rt.conv(Ls[p + ".convc2"], c1, View(corflo, 0, 192), act1=A.ACT_LRELU)
         flo = rt.act(B, h, w, 4, zero=True)
@@ -470,7 +472,7 @@ class Engine:
         rt.resize(ft0, 2, 0.25, mul=0.25, out=View(fl4in, 0, 2))
         rt.resize(ft1, 2, 0.25, mul=0.25, out=View(fl4in, 2, 2))
         # ---- NewInitDecoder  fi_components.py:255-276
-        f_in = rt.act(B, h4, w4, 272)
+        f_in = rt.act(B, h4, w4, 272, zero=True, pitch=rt.cp64(272))
         rt.warp(up8[:B], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
         rt.warp(up8[B:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
         rt.copy(View(fl4in, 0, 4), View(f_in, 256, 4), 4)
@@ -507,7 +509,7 @@ class Engine:
         c0, c1 = rt.f32(B, h8, w8, 2), rt.f32(B, h8, w8, 2)
         rt._chk(lib.lookup_coords(fl0.data_ptr(), fl1.data_ptr(), tv.data_ptr(), c0.data_ptr(), c1.data_ptr(), B, h8,
                                   w8, st()), "lookup_coords")
-        corr = rt.act(B, h8, w8, 648, zero=True)
+        corr = rt.act(B, h8, w8, 648, zero=True, pitch=rt.cp64(648))
         rt.corr_lookup(pyr, c0, View(corr, 0, 324), B, h8, w8, h8, w8)
         rt.corr_lookup(pyrT, c1, View(corr, 324, 324), B, h8, w8, h8, w8)
         flow_lr = rt.f32(B, h8, w8, 4)
@@ -515,7 +517,8 @@ class Engine:
         rt.copy(fl1, View(flow_lr, 2, 2), 2)
         net_lr = rt.resize(ft_4, 128, 0.5).t
         self._amt_update("amt_update4_low", net_lr, flow_lr, corr, B, h8, w8, st4, ft_4, low=True)
-        corr_up = rt.resize(View(corr, 0, 648), 648, 2.0).t
+        corr_up = rt.act(B, h4, w4, 648, zero=True, pitch=rt.cp64(648))
+        rt.resize(View(corr, 0, 648), 648, 2.0, out=View(corr_up, 0, 648))
         flow4 = rt.f32(B, h4, w4, 4)
         rt.copy(View(st4, 0, 4), flow4, 4)
         self._amt_update("amt_update4_high", ft_4, flow4, corr_up, B, h4, w4, st4, ft_4, low=False)
@@ -526,7 +529,7 @@ class Engine:
         fl0u = rt.resize(View(st4, 0, 2), 2, 4.0, mul=4.0).t
         fl1u = rt.resize(View(st4, 2, 2), 2, 4.0, mul=4.0).t
         mku = rt.resize(mask_4, 1, 4.0).t
-        fin = rt.act(B, H, W, 273, zero=True)
+        fin = rt.act(B, H, W, 273, zero=True, pitch=rt.cp64(273))
         rt.resize(ft_4, 128, 4.0, out=View(fin, 0, 128))
         rt.warp(up4[:B], 64, fl0u, View(fin, 128, 64))
         rt.warp(up4[B:], 64, fl1u, View(fin, 192, 64))
@@ -539,7 +542,7 @@ class Engine:
         rt.warp(View(img4[B:], 0, 3), 3, fl1u, View(fin, 270, 3))
         p = "amt_final_decoder.convblock"
         x = rt.act(B, H, W, 256)
-        rt.conv(Ls[p + ".0.0"], View(fin, 0, 273), x, act1=A.ACT_PRELU)
+        rt.conv(Ls[p + ".0.0"], fin, x, act1=A.ACT_PRELU)
         for i in (1, 2, 3):
             x = self._resblock(f"{p}.{i}", x, 256)
         dec = rt.f32(B, H, W, 24)

@@ -66,7 +66,7 @@ class ConvLayer:
         # tile of a K chunk is one contiguous block (conv_igemm_glds.hip, w_layout = 1)
         bke = 8 * rt.VE
         self.w_glds = None
-        if cp % bke == 0 and cout > 32 and pad_mode == L.PAD_ZEROS and not os.environ.get("GVFI_NO_WGLDS"):
+        if cp % bke == 0 and pad_mode == L.PAD_ZEROS and not os.environ.get("GVFI_NO_WGLDS"):
             k = kh * kw * cp
             wk = pk.reshape(cout, k // bke, 8, rt.VE)                         # [n][chunk][slot][ve]
             sw = (torch.arange(cout, device=pk.device) >> 1) & 7                # (row>>1)&7 with row == n (tile bases are /16)
@@ -103,9 +103,13 @@ class Runtime:
     def cp(self, c):
         return roundup(c, self.VE)
 
-    def act(self, n, h, w, c, zero=None):
+    def cp64(self, c):
+        """Channel count padded to one K chunk of the LDS-DMA convolution (128 bytes: 64 bf16 / 32 f32)."""
+        return roundup(c, 8 * self.VE)
+
+    def act(self, n, h, w, c, zero=None, pitch=None):
         """Activation tensor in the runtime element type with padded channel pitch."""
-        cpad = self.cp(c)
+        cpad = self.cp(c) if pitch is None else pitch
         z = (cpad != c) if zero is None else zero
         f = torch.zeros if z else torch.empty
         return f((n, h, w, cpad), dtype=self.tdtype, device=self.device)
@@ -195,13 +199,13 @@ class Runtime:
             e1.record()
             bn = tile if tile else (128 if p.Cout > 64 else (64 if p.Cout > 32 else 32))
             bke = 8 * self.VE
-            glds = algo == 2 or (algo == 0 and p.c0 % bke == 0 and p.c1 % bke == 0 and p.Cout > 32 and pm == L.PAD_ZEROS)
+            glds = (algo & 15) == 2 or (algo == 0 and p.c0 % bke == 0 and p.c1 % bke == 0 and pm == L.PAD_ZEROS)
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
             bm = 128
             if glds:
                 m_pix = n * p.Ho * p.Wo // max(groups, 1)
-                bn = tile if tile else (256 if (p.Cout >= 192 and m_pix >= 65536) else (128 if p.Cout > 64 else 64))
+                bn = tile if tile else (256 if (p.Cout >= 192 and m_pix >= 65536) else (128 if p.Cout > 64 else (64 if p.Cout > 32 else 32)))
                 bm = 256 if bn == 256 else 128
             tag = f"conv_igemm{'_glds' if glds else ''}_kernel<{'float' if self.dtype == L.F32 else 'bf16'},{bm},{bn}>"
             self.ev_log.append((tag, flops, e0, e1))

@@ -37,6 +37,8 @@ CONV_SHAPES = [
     (4, 128, 224, 256, 256, 3, 3, dict(act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),   # auto -> 256x256 tile
     (4, 128, 224, 256, 256, 3, 3, dict(split=192, tile=128)),                                # same, 128-wide tile
     (2, 64, 112, 128, 128, 3, 3, dict(algo=1, act1=L.ACT_LRELU)),                             # generic kernel on an aligned shape
+    (2, 64, 112, 256, 24, 3, 3, dict(out_f32=True)),                                         # decoder head, 128x32 LDS-DMA tile
+    (4, 32, 56, 256, 2, 3, 3, dict(out_f32=True, with_res=True)),                             # RAFT flow head
 ]
 
 
