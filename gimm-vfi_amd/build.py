@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 
 def _deps():
-    return [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "gimmvfi_hip.h")]
+    return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_mma.h"), os.path.join(HERE, "..", "include", "gimmvfi_hip.h")]
 
 
 def _compile(src):

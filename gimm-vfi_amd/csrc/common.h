@@ -21,6 +21,17 @@
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #define GVFI_LAUNCH_COOP(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+// dynamic LDS (up to the full 160 KiB of a CU needs the opt-in attribute)
+#define GVFI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define GVFI_LAUNCH_COOP_SHM(kernel, grid, block, shm, stream, ...)                                         \
+    do {                                                                                                    \
+        static int gvfi_attr_set_ = 0;                                                                      \
+        if (gvfi_attr_set_ < (int)(shm)) {                                                                  \
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shm)); \
+            gvfi_attr_set_ = (int)(shm);                                                                    \
+        }                                                                                                   \
+        hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                                  \
+    } while (0)
 #endif
 
 typedef uint16_t bf16_t;

@@ -279,6 +279,7 @@ template <typename T> static int dispatch_conv(const gvfi_conv_params& p, hipStr
 
 extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {
     const gvfi_conv_params& p = *pp;
+    if ((p.algo & 15) == 3) return gvfi_conv2d_patch(pp, stream);
     if ((p.algo & 15) == 2 || (p.algo == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds(pp, stream);
     if (p.w_layout != 0) return -5;   // the chunked weight image is only understood by the LDS-DMA kernel
     const int ve = p.dtype == GVFI_F32 ? 4 : 8;

@@ -1,0 +1,260 @@
+// Shared device helpers of the LDS-DMA convolution kernels (conv_igemm_glds.hip, conv_patch.hip):
+// MFMA wrappers, the inline-asm LDS-DMA, bf16 packing and the LDS-staged vector epilogue.
+#pragma once
+#include "common.h"
+
+#ifndef GVFI_HOSTSIM
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+static __device__ __attribute__((aligned(16))) unsigned int gvfi_zero_page[16];   // zero-initialised, one per TU
+// LDS-DMA issued through inline asm ON PURPOSE: with the builtin, hipcc treats the DMA as a pending LDS write
+// and puts `s_waitcnt vmcnt(0)` in front of the next ds_read of the same __shared__ array, which serialises
+// the prefetch of chunk k+1 behind the MFMAs of chunk k.  An asm statement is invisible to its waitcnt
+// bookkeeping (cdna_hip_programming.md section 5.7); completion is awaited explicitly by glds_wait() +
+// __syncthreads() at the top of the K loop.  M0 (LDS destination base) is saved/restored in the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+// Buffer-resource form of the LDS-DMA: the 128-bit descriptor (wave-uniform base of this K chunk) lives in SGPRs,
+// each lane only supplies a 32-bit byte offset, and offsets >= num_records return ZERO -- so image padding / ragged
+// rows need no zero page and no 64-bit per-lane address arithmetic: an out-of-range lane just uses offset ~0u.
+// M0 (LDS destination) is written in the same statement and not restored: nothing else in these kernels uses it.
+typedef int gvfi_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gvfi_i32x4 make_srd(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    gvfi_i32x4 r;
+    r.x = (int)(unsigned)(a & 0xffffffffull);
+    r.y = (int)(unsigned)((a >> 32) & 0xffffull);   // stride 0
+    r.z = 0x7fffff00;                               // num_records (bytes): offsets >= this read as zero
+    r.w = 0x00020000;
+    return r;
+}
+// LDS byte address of a __shared__ object (wave-uniform); add plain integers to it for sub-buffers
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p);
+}
+__device__ __forceinline__ void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned lds_addr) {
+    asm volatile(
+        // hipcc pads nothing inside an asm string: a descriptor SGPR written by the SALU just before this statement
+        // needs 5 wait states before a VMEM instruction reads it (and M0 needs 1): s_mov + s_nop 4 = 6 states.
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %0, %1, 0 offen lds\n\t"
+        "s_nop 0"
+        :
+        : "v"(voff), "s"(srd), "s"(lds_addr)
+        : "memory");
+}
+#define GVFI_DMA_OOB 0xffffff00u
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's LDS-DMA / vector-memory operations are still outstanding (they retire in order)
+template <int N> __device__ __forceinline__ void glds_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+#else
+static unsigned int gvfi_zero_page[16];
+static inline void glds16(const void* gsrc, unsigned char* lds_wave_base) { emu_glds16(gsrc, lds_wave_base); }
+struct gvfi_i32x4 { const unsigned char* base; };
+static inline gvfi_i32x4 make_srd(const void* base) { return gvfi_i32x4{(const unsigned char*)base}; }
+#define GVFI_DMA_OOB 0xffffff00u
+// host emulation: an "LDS address" is an offset from a per-thread-block base pointer registered by lds_address()
+inline thread_local unsigned char* gvfi_emu_lds_base = nullptr;
+static inline unsigned lds_address(const void* p) { gvfi_emu_lds_base = (unsigned char*)p; return 0u; }
+static inline void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned lds_addr) {
+    static const unsigned char zeros[16] = {0};
+    emu_glds16(voff >= 0x7fffff00u ? (const void*)zeros : (const void*)(srd.base + voff), gvfi_emu_lds_base + lds_addr);
+}
+static inline void glds_wait() {}
+template <int N> static inline void glds_wait_n() {}
+#endif
+
+template <typename T> struct Mma2;
+template <> struct Mma2<bf16_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+        acc = mfma_bf16_32x32x16(a, b, acc);
+    }
+};
+template <> struct Mma2<float> {
+    static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+        acc = mfma_f32_32x32x2(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc);
+        acc = mfma_f32_32x32x2(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc);
+        acc = mfma_f32_32x32x2(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc);
+        acc = mfma_f32_32x32x2(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc);
+    }
+};
+
+
+// two floats -> packed bf16x2 (round to nearest even); the native cast lets hipcc emit v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#ifndef GVFI_HOSTSIM
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+#else
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#endif
+}
+__device__ __forceinline__ void ld8(const void* base, long long idx, int is_f32, bool bf16_elems, float (&o)[8]) {
+    if (is_f32 || !bf16_elems) {
+        const float4 a = *(const float4*)((const float*)base + idx);
+        const float4 b = *(const float4*)((const float*)base + idx + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+        const uint4 u = *(const uint4*)((const bf16_t*)base + idx);
+        o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16));
+        o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
+        o[4] = bf2f((bf16_t)(u.z & 0xffff)); o[5] = bf2f((bf16_t)(u.z >> 16));
+        o[6] = bf2f((bf16_t)(u.w & 0xffff)); o[7] = bf2f((bf16_t)(u.w >> 16));
+    }
+}
+__device__ __forceinline__ void st8(void* base, long long idx, int is_f32, bool bf16_elems, const float (&v)[8]) {
+    if (is_f32 || !bf16_elems) {
+        *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        uint4 u;
+        u.x = pack_bf16x2(v[0], v[1]);
+        u.y = pack_bf16x2(v[2], v[3]);
+        u.z = pack_bf16x2(v[4], v[5]);
+        u.w = pack_bf16x2(v[6], v[7]);
+        *(uint4*)((bf16_t*)base + idx) = u;
+    }
+}
+__device__ __forceinline__ bool vec_ok(const void* ptr, int ld, int elem_bytes) {
+    return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && ((ld * elem_bytes) & 15) == 0);
+}
+__device__ __forceinline__ void act8(float (&v)[8], int act, const float* slope, int cout0) {
+    if (act == GVFI_ACT_NONE) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], act, slope, cout0 + e);
+}
+
+// per-thread constants of its channel group (the group index is the same in every iteration of the
+// epilogue loop because GROUPS_PER_ROW divides the thread count): bias and PReLU slopes are loaded once
+struct GroupConst {
+    float bias[8], s1[8], s2[8];
+};
+__device__ __forceinline__ void act8s(float (&v)[8], int act, const float (&s)[8]) {
+    // one branch per 8 values, never per element
+    switch (act) {
+        case GVFI_ACT_NONE: break;
+        case GVFI_ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            break;
+        case GVFI_ACT_LRELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
+            break;
+        case GVFI_ACT_PRELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : s[e] * v[e];
+            break;
+        case GVFI_ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gvfi_sigmoid(v[e]);
+            break;
+        case GVFI_ACT_TANH:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            break;
+        default:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = sinf(v[e]);
+            break;
+    }
+}
+
+// one group of 8 channels [cout0, cout0+8) of output pixel `pix`; `n_valid` channels are real
+template <typename T>
+__device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const GroupConst& gc, float (&v)[8], int cout0,
+                                               int n_valid, long long pix, bool vec) {
+    constexpr bool BF = sizeof(T) == 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += gc.bias[e];
+    if (p.epi_mode == GVFI_EPI_STD) {
+        act8s(v, p.act1, gc.s1);
+        if (p.res) {
+            float r[8];
+            if (vec) ld8(p.res, pix * p.ldr + cout0, p.res_f32, BF, r);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = (e < n_valid) ? ld_any<T>(p.res, pix * p.ldr + cout0 + e, p.res_f32) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        act8s(v, p.act2, gc.s2);
+        if (p.out_scale != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        }
+        if (vec) st8(p.y, pix * p.ldy + cout0, p.y_f32, BF, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, p.y_f32, v[e]);
+        }
+    } else if (p.epi_mode == GVFI_EPI_GRU_ZR) {
+        const int half = p.Cout >> 1;   // groups never straddle the z / r halves (half % 8 == 0 checked on the host)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gvfi_sigmoid(v[e]);
+        if (cout0 < half) {
+            if (vec) st8(p.y, pix * p.ldy + cout0, 0, BF, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, 0, v[e]);
+            }
+        } else {
+            const int c0 = cout0 - half;
+            float h[8];
+            if (vec) ld8(p.aux0, pix * p.lda0 + c0, 0, BF, h);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (e < n_valid) ? ld_any<T>(p.aux0, pix * p.lda0 + c0 + e, 0) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= h[e];
+            if (vec) st8(p.y2, pix * p.ldy2 + c0, 0, BF, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y2, pix * p.ldy2 + c0 + e, 0, v[e]);
+            }
+        }
+    } else {  // GVFI_EPI_GRU_Q
+        float h[8], z[8];
+        if (vec) {
+            ld8(p.aux0, pix * p.lda0 + cout0, 0, BF, h);
+            ld8(p.aux1, pix * p.lda1 + cout0, 0, BF, z);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = (e < n_valid) ? ld_any<T>(p.aux0, pix * p.lda0 + cout0 + e, 0) : 0.f;
+                z[e] = (e < n_valid) ? ld_any<T>(p.aux1, pix * p.lda1 + cout0 + e, 0) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (1.f - z[e]) * h[e] + z[e] * tanhf(v[e]);
+        if (vec) st8(p.y, pix * p.ldy + cout0, 0, BF, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, 0, v[e]);
+        }
+    }
+}
+

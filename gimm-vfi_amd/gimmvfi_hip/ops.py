@@ -144,10 +144,13 @@ class Runtime:
         if layer is not None:
             assert p.c0 + p.c1 == layer.cin_pad, (p.c0, p.c1, layer.cin_pad)
             bke_ = 8 * self.VE
-            use_glds = (algo & 15) != 1 and layer.w_glds is not None and p.c0 % bke_ == 0 and p.c1 % bke_ == 0
-            if use_glds:
+            want = algo & 15
+            aligned = layer.w_glds is not None and p.c0 % bke_ == 0 and p.c1 % bke_ == 0
+            if want in (0, 2) and aligned and not (algo & 128):
                 p.w, p.w_layout = layer.w_glds.data_ptr(), 1
                 algo = 2 | (algo & ~15)
+            elif want == 3 and aligned:
+                p.w, p.w_layout = layer.w_glds.data_ptr(), 1
             else:
                 p.w, p.w_layout = layer.w.data_ptr(), 0
             p.bias = None if layer.b is None else layer.b.data_ptr()

@@ -70,13 +70,17 @@ typedef struct {
                                          * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
                                          * contiguous copy (K chunk = 128 bytes)                             */
     int algo;                           /* 0 = auto, 1 = generic register-staged kernel,    *
-                                         * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32) */
+                                         * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32),  *
+                                         * 3 = direct patch kernel (stride 1, 'same', zeros)      */
 } gvfi_conv_params;
 
 int gvfi_conv2d(const gvfi_conv_params* p, void* stream);
 /* the two kernels behind gvfi_conv2d (exposed for A/B measurements) */
 int gvfi_conv2d_glds_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
+/* direct (input-patch-in-LDS) kernel for stride-1 'same' convolutions; _eligible returns the K-chunk bytes or 0 */
+int gvfi_conv2d_patch_eligible(const gvfi_conv_params* p);
+int gvfi_conv2d_patch(const gvfi_conv_params* p, void* stream);
 
 /* ---- input preparation (gimmvfi_r.py:230-231,329-337,349; raft/raft.py:111-112) ------ */
 /* bilinear resize of float planes, align_corners=False, rscale = (float)(1.0/scale_factor)

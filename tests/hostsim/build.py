@@ -15,7 +15,7 @@ CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 def _compile(src):
     obj = os.path.join(OUT, os.path.basename(src) + ".o")
-    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(HERE, "hip_emu.h"),
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_mma.h"), os.path.join(HERE, "hip_emu.h"),
             os.path.join(ROOT, "include", "gimmvfi_hip.h")]
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in deps):
         return obj

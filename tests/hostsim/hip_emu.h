@@ -70,6 +70,7 @@ struct BlockShared {
     }
 };
 inline thread_local BlockShared* tl_bs = nullptr;
+inline unsigned char* dyn_smem = nullptr;   // dynamic LDS of the running (coop) launch
 inline thread_local int tl_lane = 0, tl_wave = 0;
 inline uint32_t* wave_scratch() { return tl_bs->xchg.data() + (size_t)tl_wave * 64 * 16; }
 inline void wave_sync() { tl_bs->wave_bar[tl_wave]->arrive_and_wait(); }
@@ -233,4 +234,13 @@ template <typename F> static void emu_launch_simple(dim3 grid, dim3 block, F f) 
     for (auto& x : th) x.join();
 }
 #define GVFI_LAUNCH_COOP(kernel, grid, block, stream, ...) emu_launch_coop(grid, block, [=] { kernel(__VA_ARGS__); })
+#define GVFI_DYN_SMEM(name) unsigned char* name = emu::dyn_smem
+#define GVFI_LAUNCH_COOP_SHM(kernel, grid, block, shm, stream, ...)                       \
+    do {                                                                                  \
+        std::vector<uint32_t> gvfi_dyn_((size_t)(shm) / 4 + 64, 0xdeadbeefu);             \
+        emu::dyn_smem = reinterpret_cast<unsigned char*>(                                 \
+            (reinterpret_cast<uintptr_t>(gvfi_dyn_.data()) + 63) & ~(uintptr_t)63);       \
+        emu_launch_coop(grid, block, [=] { kernel(__VA_ARGS__); });                       \
+        emu::dyn_smem = nullptr;                                                          \
+    } while (0)
 #define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) emu_launch_simple(grid, block, [=] { kernel(__VA_ARGS__); })

@@ -19,6 +19,9 @@ SHAPES = [
     ("raft convc2 256->192 3x3", 16, 32, 56, 256, 192, 3, 3, None),
     ("init.resblock 128->128 3x3 @64x112 B8", 8, 64, 112, 128, 128, 3, 3, None),
     ("upd_high 320->192 3x3 @64x112", 8, 64, 112, 320, 192, 3, 3, None),
+    ("cnn_enc 32->32 3x3 @256x448 B16", 16, 256, 448, 32, 32, 3, 3, None),
+    ("final.up 32->64 3x3 @256x448 B16", 16, 256, 448, 32, 64, 3, 3, None),
+    ("final.head 256->24 3x3 @256x448 B8", 8, 256, 448, 256, 24, 3, 3, None),
 ]
 
 
@@ -42,14 +45,19 @@ def main():
         flops = 2.0 * N * H * W * Cout * Cin * KH * KW
         res = {}
         outs = {}
-        variants = ((1, 0), (2, 128), (2, 256))
+        variants = ((1, 0), (2, 128), (2, 256), (2 + 128, 128), (2 + 128, 256))
         if os.environ.get("ABLATE"):
             variants = tuple((2 + 16 * m, 256) for m in (0, 1, 2, 3, 4, 7)) + tuple((2 + 16 * m, 128) for m in (0, 3, 4))
         for algo, tile in variants:
             if tile == 256 and Cout < 192:
                 continue
-            for _ in range(2):
-                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
+            if tile == 128 and Cout <= 64:
+                tile = 0
+            try:
+                for _ in range(2):
+                    rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
+            except RuntimeError:
+                continue
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 5
