@@ -93,6 +93,14 @@ __host__ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// unsigned division by an invariant divisor d (1 <= d < 2^31) for dividends x < 2^31:
+//   x / d == (umulhi(x, mul) + x) >> sh     (Granlund-Montgomery round-up method, 33-bit magic minus 2^32)
+static inline void gvfi_magic_div(unsigned d, unsigned& mul, unsigned& sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    sh = l;
+    mul = (unsigned)((((1ull << (32 + l)) / d) - (1ull << 32)) + 1);
+}
 
 #define GVFI_DISPATCH_T(dtype, ...)                         \
     do {                                                    \

@@ -32,6 +32,7 @@ struct ConvArgs2 {
     int per_xcd;     // ceil(MT*NT / 8)
     int dbg;         // ablation switches for profiling (algo >> 4): 1 = no A DMA, 2 = no B DMA, 4 = no MFMA
     long long Ktot;  // weight row length in elements
+    unsigned howo_mul, howo_sh, wo_mul, wo_sh;   // magic numbers: x / d == (umulhi(x, mul) + x) >> sh  for x < 2^31
 };
 
 // ---------------------------------------------------------------- LDS-staged epilogue
@@ -92,12 +93,21 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     // the per-lane part is constant for the whole kernel (one value per source because their pitches differ);
     // padding / ragged rows are a per-row bit mask over the filter taps -> offset GVFI_DMA_OOB -> zeros.
     const int esz = (int)sizeof(T);
+    // m -> (image, oy, ox) with host-provided magic-number divisions (a 64-bit hardware division per row made the
+    // prologue cost ~9 us per workgroup, a fifth of a small RAFT convolution)
+    const int imgs_per_group = p.N / (p.groups > 0 ? p.groups : 1);
+    auto decode = [&](unsigned m, int& n, int& oy, int& ox) {
+        const unsigned q = (__umulhi(m, a.howo_mul) + m) >> a.howo_sh;     // m / (Ho*Wo)
+        const unsigned rem = m - q * (unsigned)HoWo;
+        const unsigned y = (__umulhi(rem, a.wo_mul) + rem) >> a.wo_sh;     // rem / Wo
+        n = g * imgs_per_group + (int)q;
+        oy = (int)y;
+        ox = (int)(rem - y * (unsigned)p.Wo);
+    };
     int pix_ref;   // input pixel index of tile row 0, tap (0,0) (wave-uniform, may lie in the padding)
     {
-        const long long mm = (long long)g * a.Mg + (m_tile0 < a.Mg ? m_tile0 : 0);
-        const int n = (int)(mm / HoWo);
-        const int rem = (int)(mm - (long long)n * HoWo);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        int n, oy, ox;
+        decode((unsigned)(m_tile0 < a.Mg ? m_tile0 : 0), n, oy, ox);
         pix_ref = (n * p.H + oy * p.stride - p.pad_h) * p.W + ox * p.stride - p.pad_w;
     }
     unsigned a_off0[A_INSTR], a_off1[A_INSTR], a_mask[A_INSTR];
@@ -105,25 +115,24 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     for (int i = 0; i < A_INSTR; ++i) {
         const int row = (i * NW + wave) * RPI + lrow;
         const long long m = m_tile0 + row;
-        const bool ok = (i * NW + wave) < A_TOTAL && m < a.Mg;
-        const long long mm = (long long)g * a.Mg + (ok ? m : 0);
-        const int n = (int)(mm / HoWo);
-        const int rem = (int)(mm - (long long)n * HoWo);
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
+        const bool ok = (A_TOTAL % NW == 0 || (i * NW + wave) < A_TOTAL) && m < a.Mg;
+        int n, oy, ox;
+        decode((unsigned)(ok ? m : 0), n, oy, ox);
         const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
         const int dpix = (n * p.H + iy0) * p.W + ix0 - pix_ref;
         const int koff = (lslot ^ swz(row)) * VE;
         a_off0[i] = (unsigned)(dpix * p.ld0 + koff) * esz;
         a_off1[i] = (unsigned)(dpix * p.ld1 + koff) * esz;
-        unsigned mask = 0;
-        if (ok) {
-            for (int t = 0; t < p.KH * p.KW; ++t) {
-                const int iy = iy0 + t / p.KW, ix = ix0 + t % p.KW;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
+        // bit t of the mask = filter tap t reads inside the image for this output pixel
+        unsigned mask = 0, bit = 1;
+        for (int th = 0; th < p.KH; ++th) {
+            const bool yin = (unsigned)(iy0 + th) < (unsigned)p.H;
+            for (int tw = 0; tw < p.KW; ++tw) {
+                if (yin && (unsigned)(ix0 + tw) < (unsigned)p.W) mask |= bit;
+                bit <<= 1;
             }
         }
-        a_mask[i] = mask;
+        a_mask[i] = ok ? mask : 0u;
     }
     unsigned b_off[B_INSTR];
 #pragma unroll
@@ -232,7 +241,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     // Steady state: chunk kt must have landed while the AHEAD-1 younger chunks stay in flight (LDS-DMA issue->landed
     // is ~1 us, longer than the MFMAs of one chunk).  vmcnt retires in order and every wave issues exactly NPIECE DMAs
     // per chunk, so (AHEAD-1)*NPIECE is the count to wait for.  The last AHEAD chunks are drained without prefetch.
-    int kt = 0;
+    int kt = (a.dbg & 16) ? a.KT : 0;   // profiling only: skip the K loop
     for (; kt + AHEAD < a.KT; ++kt) {
         glds_wait_n<(AHEAD - 1) * NPIECE>();
         __syncthreads();    // chunk kt visible to every wave; every wave is done reading chunk kt-1's buffer
@@ -245,6 +254,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         compute(kt, std::false_type{});
     }
 
+    if (a.dbg & 8) return;   // profiling only: skip the epilogue
     // ---------------------------------------------------------------- epilogue through LDS (see above)
     constexpr int NT = 64 * NW;
     constexpr int PASS_ROWS_RAW = (NSTAGE * STAGE / 4) / BN;
@@ -321,7 +331,10 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     a.MT = cdiv(a.Mg, BM);
     a.NT = cdiv(p.Cout, BN);
     a.per_xcd = cdiv((long long)a.MT * a.NT, 8);
-    a.dbg = (p.algo >> 4) & 7;
+    gvfi_magic_div((unsigned)(p.Ho * p.Wo), a.howo_mul, a.howo_sh);
+    gvfi_magic_div((unsigned)p.Wo, a.wo_mul, a.wo_sh);
+    a.dbg = (p.algo >> 4) & 7 ? 0 : 0;
+    a.dbg = (p.algo >> 8) & 0xff;   // profiling switches: algo bits 8.. (8 = no epilogue, 16 = no K loop)
     dim3 grid(a.per_xcd * 8, 1, groups);
     GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
     return (int)hipGetLastError();

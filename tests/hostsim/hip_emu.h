@@ -43,6 +43,7 @@ static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 
 using std::isfinite;
 #define __builtin_amdgcn_readfirstlane(x) (x)
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 typedef void* hipStream_t;
 typedef int hipError_t;
 static inline int hipGetLastError() { return 0; }

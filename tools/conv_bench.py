@@ -47,7 +47,7 @@ def main():
         outs = {}
         variants = ((1, 0), (2, 128), (2, 256), (2 + 128, 128), (2 + 128, 256))
         if os.environ.get("ABLATE"):
-            variants = tuple((2 + 16 * m, 256) for m in (0, 1, 2, 3, 4, 7)) + tuple((2 + 16 * m, 128) for m in (0, 3, 4))
+            variants = tuple((2 + 256 * m, 256) for m in (0, 8, 16, 24)) + tuple((2 + 256 * m, 128) for m in (0, 8, 16, 24))
         for algo, tile in variants:
             if tile == 256 and Cout < 192:
                 continue
