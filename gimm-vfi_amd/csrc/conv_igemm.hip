@@ -267,14 +267,33 @@ static int launch_conv(const gvfi_conv_params& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-template <typename T> static int dispatch_conv(const gvfi_conv_params& p, hipStream_t stream) {
-    int tile = p.tile_hint;
+static int generic_tile(const gvfi_conv_params& p) {
+    int tile = p.tile_hint & 1023;
     if (tile == 0) tile = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
-    switch (tile) {
+    return tile >= 128 ? 128 : (tile >= 64 ? 64 : 32);
+}
+
+template <typename T> static int dispatch_conv(const gvfi_conv_params& p, hipStream_t stream) {
+    switch (generic_tile(p)) {
         case 128: return launch_conv<T, 128, 128, 2, 2, 4>(p, stream);
         case 64: return launch_conv<T, 128, 64, 2, 2, 4>(p, stream);
         default: return launch_conv<T, 128, 32, 4, 1, 4>(p, stream);
     }
+}
+
+// Which kernel gvfi_conv2d would launch for *pp: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch), BM, BN, K-chunk bytes, LDS stages}.
+extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
+    const gvfi_conv_params& p = *pp;
+    if ((p.algo & 15) == 3) {
+        const int kb = gvfi_conv2d_patch_eligible(pp);
+        if (!kb) return -2;
+        plan[0] = 3; plan[1] = 0; plan[2] = p.Cout > 32 ? 64 : 32; plan[3] = kb; plan[4] = 1;
+        return 0;
+    }
+    if ((p.algo & 15) == 2 || (p.algo == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds_plan(pp, plan);
+    if (p.w_layout != 0) return -5;
+    plan[0] = 1; plan[1] = 128; plan[2] = generic_tile(p); plan[3] = 64; plan[4] = 2;
+    return 0;
 }
 
 extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {

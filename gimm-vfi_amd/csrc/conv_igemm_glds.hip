@@ -333,7 +333,6 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     a.per_xcd = cdiv((long long)a.MT * a.NT, 8);
     gvfi_magic_div((unsigned)(p.Ho * p.Wo), a.howo_mul, a.howo_sh);
     gvfi_magic_div((unsigned)p.Wo, a.wo_mul, a.wo_sh);
-    a.dbg = (p.algo >> 4) & 7 ? 0 : 0;
     a.dbg = (p.algo >> 8) & 0xff;   // profiling switches: algo bits 8.. (8 = no epilogue, 16 = no K loop)
     dim3 grid(a.per_xcd * 8, 1, groups);
     GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
@@ -352,32 +351,72 @@ extern "C" int gvfi_conv2d_glds_eligible(const gvfi_conv_params* pp) {
     return 0;
 }
 
-extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
+// One place decides the tile: plan = {algo, BM, BN, KB(bytes), NSTAGE} for an eligible problem (also reported by
+// gvfi_conv2d_plan).  256x256 (8 waves) for Cout >= 192 on large images, else {128,64} x {128, 64, 32} (4 waves);
+// 128-byte K chunks when the channel counts allow it, else 64-byte chunks.  tile_hint = BN | BM << 10 (0 = auto),
+// algo bits 4..6 = ring depth override.
+extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     const gvfi_conv_params& p = *pp;
     const int kb = gvfi_conv2d_glds_eligible(pp);
     if (!kb) return -2;
+    const long long M = (long long)p.N * p.Ho * p.Wo / (p.groups > 0 ? p.groups : 1);
+    int tile = p.tile_hint & 1023, bm = p.tile_hint >> 10, ns = (p.algo >> 4) & 7;
+    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
+    tile = tile >= 256 ? 256 : (tile >= 128 ? 128 : (tile >= 64 ? 64 : 32));
+    int k = 64;
+    if (tile == 256) k = p.w_layout == 0 ? 64 : 128;
+    else if (kb == 128 && !(p.algo & 128)) k = 128;
+    else if (p.w_layout != 0) return -5;
+    if (tile == 256) { bm = 256; ns = k == 64 ? 4 : 2; }
+    else if (tile == 128 && k == 128) {
+        // 64-row tiles / deeper rings are selectable for A/B runs (tools/conv_bench.py SMALLM=1); measured on the
+        // small-M RAFT shapes they do not beat 128 rows x 2 stages (2 workgroups per CU), which stays the default
+        if (bm == 0) bm = 128;
+        bm = bm <= 64 ? 64 : 128;
+        if (ns == 0) ns = bm == 64 ? 3 : 2;
+        ns = ns < 2 ? 2 : (ns > 4 ? 4 : ns);
+    } else {
+        bm = 128;
+        ns = (k == 64 && tile >= 64) ? 4 : 2;
+    }
+    plan[0] = 2;
+    plan[1] = bm;
+    plan[2] = tile;
+    plan[3] = k;
+    plan[4] = ns;
+    return 0;
+}
+
+extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
+    const gvfi_conv_params& p = *pp;
+    int plan[5];
+    const int rc = gvfi_conv2d_glds_plan(pp, plan);
+    if (rc) return rc;
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15)) return -3;
     if (p.groups > 1 && (p.N % p.groups)) return -4;
-    // tile width: 256 (8 waves, 256x256) for Cout >= 192 on large images, 128 (4 waves) for Cout > 64, else 64 / 32
-    const long long M = (long long)p.N * p.Ho * p.Wo / (p.groups > 0 ? p.groups : 1);
-    int tile = p.tile_hint;
-    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
     hipStream_t st = (hipStream_t)stream;
-    // ring depth: 256x256 -> 4 x 32 KiB chunks of 64-byte rows (prefetch distance 3); 4-wave tiles -> 3 x 128-byte
-    // chunks when the channel count allows it, else 4 x 64-byte chunks
+    const int bm = plan[1], tile = plan[2], k = plan[3], ns = plan[4];
 #define GLDS_DISPATCH(TT)                                                                                     \
-    if (tile >= 256) {                                                                                        \
-        if (p.w_layout == 0) return launch_glds<TT, 256, 256, 2, 4, 64, 4>(p, st);                            \
+    if (tile == 256) {                                                                                        \
+        if (k == 64) return launch_glds<TT, 256, 256, 2, 4, 64, 4>(p, st);                                    \
         return launch_glds<TT, 256, 256, 2, 4, 128, 2>(p, st);                                                \
     }                                                                                                         \
-    if (kb == 128 && !(p.algo & 128)) {                                                                        \
-        if (tile >= 128) return launch_glds<TT, 128, 128, 2, 2, 128, 2>(p, st);                               \
-        if (tile >= 64) return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                 \
+    if (k == 128) {                                                                                           \
+        if (tile == 128) {                                                                                    \
+            if (bm == 64) {                                                                                   \
+                if (ns == 2) return launch_glds<TT, 64, 128, 2, 2, 128, 2>(p, st);                            \
+                if (ns == 3) return launch_glds<TT, 64, 128, 2, 2, 128, 3>(p, st);                            \
+                return launch_glds<TT, 64, 128, 2, 2, 128, 4>(p, st);                                         \
+            }                                                                                                 \
+            if (ns == 2) return launch_glds<TT, 128, 128, 2, 2, 128, 2>(p, st);                               \
+            if (ns == 3) return launch_glds<TT, 128, 128, 2, 2, 128, 3>(p, st);                               \
+            return launch_glds<TT, 128, 128, 2, 2, 128, 4>(p, st);                                            \
+        }                                                                                                     \
+        if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                 \
         return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);                                                 \
     }                                                                                                         \
-    if (p.w_layout != 0) return -5;                                                                           \
-    if (tile >= 128) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
-    if (tile >= 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                      \
+    if (tile == 128) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
+    if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                      \
     return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }
     GLDS_DISPATCH(bf16_t)

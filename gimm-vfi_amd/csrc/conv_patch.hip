@@ -307,7 +307,7 @@ extern "C" int gvfi_conv2d_patch(const gvfi_conv_params* pp, void* stream) {
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15)) return -3;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)p.N * p.H * p.W;
-    int tile = p.tile_hint;
+    int tile = p.tile_hint & 1023;
     if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256 && kb == 128) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
 #define PATCH_DISPATCH(TT)                                                                              \
     if (kb == 128) {                                                                                    \

@@ -72,62 +72,150 @@ extern "C" int gvfi_prep_images(const float* img_xs, void* act, float* img4, int
     return (int)hipGetLastError();
 }
 
-// ------------------------------------------------------------------ InstanceNorm2d
-#define IN_CHUNK 1024
+// ------------------------------------------------------------------ InstanceNorm2d   raft/extractor.py:17-25,168-220
+// (nn.InstanceNorm2d defaults: biased variance over H*W per (n, c), eps = 1e-5, no affine)
+// Both passes are pure HBM streams: 16-byte vectors (8 bf16 / 4 f32 channels of one pixel per lane), the
+// statistics pass reduces the pixel lanes of a workgroup through LDS and issues one atomic pair per channel.
+#define IN_CHUNK 2048
+template <typename T> struct alignas(16) Vec16 { T e[Elem<T>::VE]; };
+
 template <typename T>
 __global__ void instnorm_stats_kernel(const T* __restrict__ x, int ld, int C, int HW, float* __restrict__ stats) {
-    // block = one chunk of IN_CHUNK pixels of one image; thread = (pixel lane, channel)
+    constexpr int VE = Elem<T>::VE;
+    __shared__ float red[2][GVFI_BLOCK * VE];
     const int n = blockIdx.y;
-    const int lanes = blockDim.x / C;          // pixel lanes (>= 1 because C <= blockDim.x)
-    const int c = threadIdx.x % C;
-    const int pl = threadIdx.x / C;
-    if (pl >= lanes) return;
+    const int G = C / VE;                      // channel groups per pixel
+    const int lanes = blockDim.x / G;          // pixel lanes (>= 1 because C <= blockDim.x)
+    const int cg = threadIdx.x % G;
+    const int pl = threadIdx.x / G;
     const long long p0 = (long long)blockIdx.x * IN_CHUNK;
     long long p1 = p0 + IN_CHUNK;
     if (p1 > HW) p1 = HW;
-    float s = 0.f, ss = 0.f;
-    for (long long p = p0 + pl; p < p1; p += lanes) {
-        const float v = Elem<T>::ld(x + ((long long)n * HW + p) * ld + c);
-        s += v;
-        ss += v * v;
+    float s[VE], ss[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s[e] = ss[e] = 0.f;
+    if (pl < lanes) {
+        for (long long p = p0 + pl; p < p1; p += lanes) {
+            const Vec16<T> v = *(const Vec16<T>*)(x + ((long long)n * HW + p) * ld + cg * VE);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float f = Elem<T>::ld(&v.e[e]);
+                s[e] += f;
+                ss[e] += f * f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            red[0][pl * C + cg * VE + e] = s[e];
+            red[1][pl * C + cg * VE + e] = ss[e];
+        }
     }
-    atomicAdd(&stats[((long long)n * C + c) * 2 + 0], s);
-    atomicAdd(&stats[((long long)n * C + c) * 2 + 1], ss);
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int l = 0; l < lanes; ++l) {
+            a0 += red[0][l * C + threadIdx.x];
+            a1 += red[1][l * C + threadIdx.x];
+        }
+        atomicAdd(&stats[((long long)n * C + threadIdx.x) * 2 + 0], a0);
+        atomicAdd(&stats[((long long)n * C + threadIdx.x) * 2 + 1], a1);
+    }
 }
 extern "C" int gvfi_instnorm_stats(const void* x, int ld, int C, int N, int HW, float* stats, int dtype, void* stream) {
-    if (C > GVFI_BLOCK) return -2;
+    const int ve = dtype == GVFI_F32 ? 4 : 8;
+    if (C > GVFI_BLOCK || (C % ve) || (ld % ve) || ((uintptr_t)x & 15)) return -2;
     dim3 grid((unsigned)((HW + IN_CHUNK - 1) / IN_CHUNK), (unsigned)N);
-    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((instnorm_stats_kernel<T>), grid, dim3(GVFI_BLOCK), (hipStream_t)stream,
-                                              (const T*)x, ld, C, HW, stats));
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((instnorm_stats_kernel<T>), grid, dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                            (const T*)x, ld, C, HW, stats));
     return (int)hipGetLastError();
 }
 template <typename T>
 __global__ void instnorm_apply_kernel(const T* __restrict__ x, int ld, int C, long long total, int HW,
                                       const float* __restrict__ stats, int relu, const T* __restrict__ res, int ldr,
                                       T* __restrict__ out, int ldo) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int VE = Elem<T>::VE;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (pixel, channel group)
     if (idx >= total) return;
-    const int c = (int)(idx % C);
-    const long long pix = idx / C;
+    const int G = C / VE;
+    const int c0 = (int)(idx % G) * VE;
+    const long long pix = idx / G;
     const int n = (int)(pix / HW);
     const float inv = 1.0f / (float)HW;
-    const float mean = stats[((long long)n * C + c) * 2] * inv;
-    float var = stats[((long long)n * C + c) * 2 + 1] * inv - mean * mean;
-    if (var < 0.f) var = 0.f;
-    float v = (Elem<T>::ld(x + pix * ld + c) - mean) / sqrtf(var + 1e-5f);
-    if (relu && v < 0.f) v = 0.f;
-    if (res) {
-        v += Elem<T>::ld(res + pix * ldr + c);
-        if (v < 0.f) v = 0.f;
+    const Vec16<T> v = *(const Vec16<T>*)(x + pix * ld + c0);
+    Vec16<T> r, o;
+    if (res) r = *(const Vec16<T>*)(res + pix * ldr + c0);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const float2 st = *(const float2*)(stats + ((long long)n * C + c0 + e) * 2);
+        const float mean = st.x * inv;
+        float var = st.y * inv - mean * mean;
+        if (var < 0.f) var = 0.f;
+        float f = (Elem<T>::ld(&v.e[e]) - mean) / sqrtf(var + 1e-5f);
+        if (relu && f < 0.f) f = 0.f;
+        if (res) {
+            f += Elem<T>::ld(&r.e[e]);
+            if (f < 0.f) f = 0.f;
+        }
+        Elem<T>::st(&o.e[e], f);
     }
-    Elem<T>::st(out + pix * ldo + c, v);
+    *(Vec16<T>*)(out + pix * ldo + c0) = o;
 }
 extern "C" int gvfi_instnorm_apply(const void* x, int ld, int C, int N, int HW, const float* stats, int relu,
                                    const void* res, int ldr, void* out, int ldo, int dtype, void* stream) {
-    const long long total = (long long)N * HW * C;
+    const int ve = dtype == GVFI_F32 ? 4 : 8;
+    if ((C % ve) || (ld % ve) || (ldo % ve) || (res && (ldr % ve)) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
+        ((uintptr_t)res & 15))
+        return -2;
+    const long long total = (long long)N * HW * (C / ve);
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((instnorm_apply_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, (const T*)x, ld, C, total, HW, stats, relu,
                                               (const T*)res, ldr, (T*)out, ldo));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ im2col for tiny channel counts
+// A 7x7 convolution over 2..4 channels (raft/update.py:100,107; modules/fi_components.py:177) has K = 98..196 real
+// products per output; run as a padded-channel implicit GEMM it spends 4x that.  The patch matrix of such a layer
+// is small (K <= 256 per pixel at 1/8 or 1/4 resolution), so it is materialised once, K ordered (kh, kw, c) and
+// zero-padded to a whole K chunk, and the layer becomes a 1x1 convolution on the LDS-DMA kernel.
+template <typename T>
+__global__ void im2col_kernel(const T* __restrict__ x, int ld, int c, int H, int W, int KH, int KW, int pad_h,
+                              int pad_w, int Ho, int Wo, T* __restrict__ out, int ldo, long long total) {
+    constexpr int VE = Elem<T>::VE;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (pixel, group of VE patch entries)
+    if (idx >= total) return;
+    const int G = ldo / VE;
+    const int g = (int)(idx % G);
+    const long long pix = idx / G;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const long long n = pix / ((long long)Wo * Ho);
+    const int K = KH * KW * c;
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const int k = g * VE + e;
+        float v = 0.f;
+        if (k < K) {
+            const int tap = k / c, ch = k - tap * c;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            const int iy = oy - pad_h + kh, ix = ox - pad_w + kw;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = Elem<T>::ld(x + ((n * H + iy) * W + ix) * ld + ch);
+        }
+        Elem<T>::st(&o.e[e], v);
+    }
+    *(Vec16<T>*)(out + pix * ldo + g * VE) = o;
+}
+extern "C" int gvfi_im2col(const void* x, int ld, int c, int N, int H, int W, int KH, int KW, int pad_h, int pad_w,
+                           void* out, int ldo, int dtype, void* stream) {
+    const int ve = dtype == GVFI_F32 ? 4 : 8;
+    const int Ho = H + 2 * pad_h - KH + 1, Wo = W + 2 * pad_w - KW + 1;
+    if (c <= 0 || Ho <= 0 || Wo <= 0 || (ldo % ve) || ldo < KH * KW * c || ((uintptr_t)out & 15)) return -2;
+    const long long total = (long long)N * Ho * Wo * (ldo / ve);
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((im2col_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                              (const T*)x, ld, c, H, W, KH, KW, pad_h, pad_w, Ho, Wo, (T*)out, ldo,
+                                              total));
     return (int)hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import lib as L
-from .ops import ConvLayer, Runtime, V, View
+from .ops import ConvLayer, PatchConvLayer, Runtime, V, View
 
 A = L  # activation / epilogue constants
 
@@ -40,6 +40,9 @@ class Engine:
     def _add(self, name, w, b, **kw):
         self.layers[name] = ConvLayer(self.rt, w, b, **kw)
 
+    def _patch_conv(self, sd, key):
+        self.layers[key] = PatchConvLayer(self.rt, sd[key + ".weight"], sd[key + ".bias"])
+
     def _conv(self, sd, key, name=None, bn=None, slope=None, **kw):
         w, b = sd[key + ".weight"], sd[key + ".bias"]
         if bn is not None:
@@ -65,7 +68,8 @@ class Engine:
 
     def _build_update(self, sd, p):
         self._conv(sd, f"{p}.convc1", cin_pad=self.rt.cp64(648))   # padded to a K chunk -> LDS-DMA kernel
-        for k in ("convc2", "convf1", "convf2", "conv", "gru.0", "gru.2", "feat_head.0", "feat_head.2",
+        self._patch_conv(sd, f"{p}.convf1")        # 4 -> 128, 7x7: im2col + 1x1
+        for k in ("convc2", "convf2", "conv", "gru.0", "gru.2", "feat_head.0", "feat_head.2",
                   "flow_head.0", "flow_head.2"):
             self._conv(sd, f"{p}.{k}")
 
@@ -79,7 +83,8 @@ class Engine:
         self._add("cnet.out_inp", w[128:], b[128:])   # relu half
         u = fe + ".update_block"
         self._conv(sd, f"{u}.encoder.convc1", cin_pad=self.rt.cp64(324))
-        for k in ("encoder.convc2", "encoder.convf1", "encoder.convf2", "encoder.conv",
+        self._patch_conv(sd, f"{u}.encoder.convf1")   # 2 -> 128, 7x7: im2col + 1x1
+        for k in ("encoder.convc2", "encoder.convf2", "encoder.conv",
                   "flow_head.conv1", "flow_head.conv2", "mask.0", "mask.2"):
             self._conv(sd, f"{u}.{k}")
         for n in ("1", "2"):
@@ -237,13 +242,14 @@ class Engine:
         rh = rt.act(n, h8, w8, 128)
         fh = rt.act(n, h8, w8, 256)
         u = fe + ".update_block"
+        fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
         for it in range(iters):
             rt.corr_lookup(pyr_a, coords[:B], corrf[:B], B, h8, w8, h8, w8)
             rt.corr_lookup(pyr_b, coords[B:], corrf[B:], B, h8, w8, h8, w8)
             rt.flow_pack(coords, flow8, View(xbuf, 254, 2))
             rt.conv(Ls[u + ".encoder.convc1"], corrf, c1, act1=A.ACT_RELU)
             rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, act1=A.ACT_RELU)
+            rt.patch_conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, scratch=fcol, act1=A.ACT_RELU)
             rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
             rt.conv(Ls[u + ".encoder.conv"], corflo, View(xbuf, 128, 126), act1=A.ACT_RELU)
             hc, hn = hA, hB
@@ -275,7 +281,7 @@ class Engine:
         flo = rt.act(B, h, w, 4, zero=True)
         rt.copy(View(flow4_f32, 0, 4), View(flo, 0, 4), 4)
         f1 = rt.act(B, h, w, 128)
-        rt.conv(Ls[p + ".convf1"], View(flo, 0, 4), f1, act1=A.ACT_LRELU)
+        rt.patch_conv(Ls[p + ".convf1"], View(flo, 0, 4), f1, act1=A.ACT_LRELU)
         rt.conv(Ls[p + ".convf2"], f1, View(corflo, 192, 64), act1=A.ACT_LRELU)
         inp = rt.act(B, h, w, 192)          # [inp(188) | flow(4)] ; net(128) is the second conv source
         rt.conv(Ls[p + ".conv"], corflo, View(inp, 0, 188), act1=A.ACT_LRELU)

@@ -59,16 +59,22 @@ class GIMMVFI_R(nn.Module):
                 node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
         self._engine = None
         self._engine_key = None
+        # hipGraph replay of the whole forward (one graph per input signature): the launch list is ~1000 kernels,
+        # so eager mode is host-bound as soon as the kernels are fast.  GIMMVFI_GRAPH=0 disables it.
+        self.use_graph = os.environ.get("GIMMVFI_GRAPH", "1") != "0"
+        self._graphs = {}
 
     # ---- engine cache invalidation: weights are folded/packed for the kernels lazily
     def load_state_dict(self, state_dict, strict=True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
         self._engine = None
+        self._graphs = {}
         return r
 
     def _apply(self, fn, *a, **kw):
         r = super()._apply(fn, *a, **kw)
         self._engine = None
+        self._graphs = {}
         return r
 
     def engine(self, device=None, runtime=None):
@@ -92,7 +98,54 @@ class GIMMVFI_R(nn.Module):
         assert isinstance(coord, list)
         assert len(t) == len(coord)
         iters = self.raft_iter  # gimmvfi_r.py:127-132 hard-codes 20
-        return self.engine(img_xs.device).forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
+        eng = self.engine(img_xs.device)
+        if not (self.use_graph and img_xs.is_cuda and eng.rt.ev_log is None):
+            return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
+        return self._forward_graph(eng, img_xs, coord, t, iters, ds_factor)
+
+    def _forward_graph(self, eng, img_xs, coord, t, iters, ds_factor):
+        """Capture once per input signature, then replay; inputs are copied into the graph's static buffers and
+        the outputs are returned as fresh tensors (clones), like the eager path."""
+        for c in coord:
+            assert isinstance(c, tuple) and c[1] is None, "sub-sampled coordinates are a training feature"
+        key = (tuple(img_xs.shape), str(img_xs.device), tuple(tuple(c[0].shape) for c in coord), len(t), ds_factor)
+        ent = self._graphs.get(key)
+        if ent is None:
+            dev = img_xs.device
+            sx = img_xs.detach().to(torch.float32).contiguous().clone()
+            sc = [c[0].detach().to(device=dev, dtype=torch.float32).contiguous().clone() for c in coord]
+            st = [ti.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous().clone() for ti in t]
+            coords = [(c, None) for c in sc]
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):   # warm-up outside capture (one-time attribute / allocator work)
+                eng.forward(sx, coords, st, iters=iters, ds_factor=ds_factor)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = eng.forward(sx, coords, st, iters=iters, ds_factor=ds_factor)
+            ent = (g, sx, sc, st, out)
+            self._graphs[key] = ent
+        g, sx, sc, st, out = ent
+        sx.copy_(img_xs)
+        for a, c in zip(sc, coord):
+            a.copy_(c[0])
+        for a, ti in zip(st, t):
+            a.copy_(ti.reshape(-1))
+        g.replay()
+
+        def fresh(o):
+            if isinstance(o, torch.Tensor):
+                return o.clone()
+            if isinstance(o, (list, tuple)):
+                return type(o)(fresh(v) for v in o)
+            if isinstance(o, dict):
+                return {k: fresh(v) for k, v in o.items()}
+            return o
+
+        return fresh(out)
 
     def sample_coord_input(self, batch_size, s_shape, t_ids, coord_range=None, upsample_ratio=1.0, device=None):
         """modules/coord_sampler.py:15-43,73-91 (list t_ids) -> (B, T, H', W', 3) ordered (t, y, x).

@@ -81,6 +81,20 @@ class ConvLayer:
         self.pad_mode = pad_mode
 
 
+class PatchConvLayer:
+    """A KHxKW stride-1 zero-padded convolution over a few channels, run as im2col (gvfi_im2col) + 1x1 convolution:
+    K = KH*KW*cin real products, padded once to a whole K chunk instead of padding every tap's channels."""
+
+    def __init__(self, rt, w, b, slope=None):
+        cout, cin, kh, kw = w.shape
+        self.kh, self.kw, self.cin, self.cout = kh, kw, cin, cout
+        self.kpad = roundup(kh * kw * cin, 8 * rt.VE)
+        w2 = torch.zeros(cout, self.kpad, 1, 1, dtype=torch.float32, device=w.device)
+        w2[:, :kh * kw * cin, 0, 0] = w.detach().float().permute(0, 2, 3, 1).reshape(cout, -1)   # K order (kh, kw, c)
+        self.inner = ConvLayer(rt, w2, b, slope=slope)
+        self.inner.cin = kh * kw * cin      # real products per output (FLOP accounting)
+
+
 class Runtime:
     def __init__(self, lib, precision, device):
         self.lib = lib
@@ -95,6 +109,7 @@ class Runtime:
         self.on_gpu = self.device.type == "cuda"
         self.n_launch = 0
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
+        self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
 
     # ------------------------------------------------------------------ memory
     def stream(self):
@@ -200,17 +215,14 @@ class Runtime:
             e0.record()
             self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
             e1.record()
-            bn = tile if tile else (128 if p.Cout > 64 else (64 if p.Cout > 32 else 32))
-            bke = 8 * self.VE
-            glds = (algo & 15) == 2 or (algo == 0 and p.c0 % bke == 0 and p.c1 % bke == 0 and pm == L.PAD_ZEROS)
+            plan = (C.c_int * 5)()
+            self._chk(self.lib.conv2d_plan(C.byref(p), plan), "conv2d_plan")   # the library says which kernel it ran
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
-            bm = 128
-            if glds:
-                m_pix = n * p.Ho * p.Wo // max(groups, 1)
-                bn = tile if tile else (256 if (p.Cout >= 192 and m_pix >= 65536) else (128 if p.Cout > 64 else (64 if p.Cout > 32 else 32)))
-                bm = 256 if bn == 256 else 128
-            tag = f"conv_igemm{'_glds' if glds else ''}_kernel<{'float' if self.dtype == L.F32 else 'bf16'},{bm},{bn}>"
+            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel"}[plan[0]]
+            tag = f"{kname}<{'float' if self.dtype == L.F32 else 'bf16'},{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
+            if self.ev_shapes:
+                tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"
             self.ev_log.append((tag, flops, e0, e1))
         return out
 
@@ -260,6 +272,16 @@ class Runtime:
         c = self.f32(n, h, w, 2)
         self._chk(self.lib.coords_init(c.data_ptr(), n, h, w, self.stream()), "coords_init")
         return c
+
+    def patch_conv(self, layer, src, out, scratch=None, **kw):
+        """conv of a PatchConvLayer: im2col into `scratch` [N,H,W,kpad] then a 1x1 convolution."""
+        src = V(src)
+        n, h, w = src.t.shape[:3]
+        if scratch is None:
+            scratch = torch.empty((n, h, w, layer.kpad), dtype=self.tdtype, device=self.device)
+        self._chk(self.lib.im2col(src.ptr, src.ld, layer.cin, n, h, w, layer.kh, layer.kw, layer.kh // 2, layer.kw // 2,
+                                  scratch.data_ptr(), layer.kpad, self.dtype, self.stream()), "im2col")
+        return self.conv(layer.inner, scratch, out, **kw)
 
     def flow_pack(self, coords1, dst0, dst1):
         n, h, w = coords1.shape[:3]

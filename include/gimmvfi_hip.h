@@ -64,17 +64,22 @@ typedef struct {
     void* y2; int ldy2;                 /* GRU_ZR: r*h destination                          */
     const void* aux0; int lda0;         /* GRU: h                                           */
     const void* aux1; int lda1;         /* GRU_Q: z                                         */
-    int tile_hint;                      /* 0 = auto, else Cout tile width 32/64/128         */
+    int tile_hint;                      /* 0 = auto, else BN | BM << 10: Cout tile width 32/64/128/256 and (LDS-DMA kernel,
+                                         * BN = 128) pixel tile height 64/128 */
     int w_layout;                       /* 0: [Cout][KH][KW][Cin];  1 (LDS-DMA kernel only): K-chunk major,  *
                                          * [K/64][Cout][64] with the 16-byte groups of a row XOR-swizzled by *
                                          * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
                                          * contiguous copy (K chunk = 128 bytes)                             */
-    int algo;                           /* 0 = auto, 1 = generic register-staged kernel,    *
+    int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32),  *
                                          * 3 = direct patch kernel (stride 1, 'same', zeros)      */
 } gvfi_conv_params;
 
 int gvfi_conv2d(const gvfi_conv_params* p, void* stream);
+/* which kernel gvfi_conv2d would launch: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch), BM, BN, K-chunk bytes,
+ * LDS stages} */
+int gvfi_conv2d_plan(const gvfi_conv_params* p, int* plan);
+int gvfi_conv2d_glds_plan(const gvfi_conv_params* p, int* plan);
 /* the two kernels behind gvfi_conv2d (exposed for A/B measurements) */
 int gvfi_conv2d_glds_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
@@ -103,6 +108,12 @@ int gvfi_avgpool2_f32(const float* src, float* dst, long long maps, int h, int w
 int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3,
                      const float* coords /*[N,h,w,2] (x,y)*/, void* out, int ldo, int dtype,
                      int N, int h, int w, int h2, int w2, int radius, void* stream);
+
+/* patch matrix of a stride-1 zero-padded KHxKW convolution over c (tiny) channels: out[n,oy,ox, (kh*KW+kw)*c + ch],
+ * zero-filled up to ldo (a whole K chunk); turns raft/update.py:100,107 (convf1, 2 -> 128, 7x7) and
+ * modules/fi_components.py:177 (4 -> 128, 7x7) into 1x1 convolutions for gvfi_conv2d */
+int gvfi_im2col(const void* x, int ld, int c, int N, int H, int W, int KH, int KW, int pad_h, int pad_w,
+                void* out, int ldo, int dtype, void* stream);
 
 /* ---- RAFT glue (raft/raft.py:77-97,139-161) ------------------------------------------- */
 int gvfi_coords_init(float* coords, int N, int h, int w, void* stream);

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 import gimmvfi_r_oracle as orc
 from gimmvfi_hip import lib as L
-from gimmvfi_hip.ops import ConvLayer, View
+from gimmvfi_hip.ops import ConvLayer, PatchConvLayer, View
 
 
 def _dev(rt):
@@ -145,6 +145,22 @@ def instnorm_case(rt, N=2, H=9, W=11, C=24):
     for got, ref in ((o1, F.relu(n)), (o2, F.relu(r + F.relu(n))), (o3, n)):
         err = float((got.float().cpu().permute(0, 3, 1, 2)[:, :C] - ref).abs().max())
         assert err <= tol(rt, 4.0), err
+
+
+def patch_conv_case(rt, N=2, H=10, W=13, Cin=2, Cout=24, KH=7, KW=7):
+    """im2col + 1x1 (gvfi_im2col) == the zero-padded KHxKW convolution (raft/update.py:100,107)."""
+    g = torch.Generator().manual_seed(11)
+    x = _rounded(rt, torch.randn(N, Cin, H, W, generator=g))
+    w = _rounded(rt, torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    dev = _dev(rt)
+    lay = PatchConvLayer(rt, w, b)
+    xa = _to_act(rt, x).to(dev)
+    out = rt.act(N, H, W, Cout)
+    rt.patch_conv(lay, View(xa, 0, Cin), out, act1=L.ACT_RELU)
+    ref = F.relu(F.conv2d(x, w, b, padding=(KH // 2, KW // 2)))
+    err = float((out.float().cpu().permute(0, 3, 1, 2)[:, :Cout] - ref).abs().max())
+    assert err <= tol(rt, 4.0), err
 
 
 def resize_warp_shuffle_case(rt):

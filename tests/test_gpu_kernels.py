@@ -60,6 +60,11 @@ def test_corr_volume_grouped_gemm(rt):
     kc.corr_volume_case(rt, B=2, h=32, w=56, C=256, seed=3)
 
 
+def test_patch_conv(rt):
+    kc.patch_conv_case(rt)
+    kc.patch_conv_case(rt, N=1, H=9, W=8, Cin=4, Cout=16)
+
+
 def test_instnorm(rt):
     kc.instnorm_case(rt)
     kc.instnorm_case(rt, N=2, H=64, W=112, C=96)

@@ -17,6 +17,9 @@ SHAPES = [
     ("final.side 64->64 3x3", 8, 256, 448, 64, 64, 3, 3, None),
     ("raft gru 128+256->256 1x5 @32x56 B16", 16, 32, 56, 384, 256, 1, 5, 128),
     ("raft convc2 256->192 3x3", 16, 32, 56, 256, 192, 3, 3, None),
+    ("raft gruq 128+256->128 5x1", 16, 32, 56, 384, 128, 5, 1, 128),
+    ("raft fh1 128->256 3x3", 16, 32, 56, 128, 256, 3, 3, None),
+    ("raft convc1 324(384)->256 1x1", 16, 32, 56, 384, 256, 1, 1, None),
     ("init.resblock 128->128 3x3 @64x112 B8", 8, 64, 112, 128, 128, 3, 3, None),
     ("upd_high 320->192 3x3 @64x112", 8, 64, 112, 320, 192, 3, 3, None),
     ("cnn_enc 32->32 3x3 @256x448 B16", 16, 256, 448, 32, 32, 3, 3, None),
@@ -46,12 +49,14 @@ def main():
         res = {}
         outs = {}
         variants = ((1, 0), (2, 128), (2, 256), (2 + 128, 128), (2 + 128, 256))
+        if os.environ.get("SMALLM"):   # BM / ring depth sweep for the small-M (RAFT) shapes
+            variants = tuple((2 + 16 * ns, 128 | (bm << 10)) for bm in (128, 64) for ns in (2, 3, 4))
         if os.environ.get("ABLATE"):
-            variants = tuple((2 + 256 * m, 256) for m in (0, 8, 16, 24)) + tuple((2 + 256 * m, 128) for m in (0, 8, 16, 24))
+            variants = tuple((2 + 256 * m, 256) for m in (0, 8, 16, 24)) + tuple((2 + 256 * m, 128 | (128 << 10)) for m in (0, 8, 16, 24))
         for algo, tile in variants:
-            if tile == 256 and Cout < 192:
+            if (tile & 1023) == 256 and Cout < 192:
                 continue
-            if tile == 128 and Cout <= 64:
+            if (tile & 1023) == 128 and Cout <= 64:
                 tile = 0
             try:
                 for _ in range(2):
@@ -70,7 +75,7 @@ def main():
             res[(algo, tile)] = (ms, flops / ms / 1e9)
             outs[(algo, tile)] = out.float().clone()
         ref = outs[(1, 0)] if (1, 0) in outs else next(iter(outs.values()))
-        txt = " | ".join(f"a{k[0]}t{k[1]} {v[0]:7.3f} ms {v[1]:6.1f} TF/s d={float((outs[k]-ref).abs().max()):.1e}" for k, v in res.items())
+        txt = " | ".join(f"a{k[0]}t{k[1] & 1023}m{k[1] >> 10} {v[0]:7.3f} ms {v[1]:6.1f} TF/s d={float((outs[k]-ref).abs().max()):.1e}" for k, v in res.items())
         print(f"{name:42s} {txt}")
 
 
