@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import lib as L
-from .ops import ConvLayer, PatchConvLayer, Runtime, V, View
+from .ops import ConvLayer, InrMlp, PatchConvLayer, Runtime, V, View
 
 A = L  # activation / epilogue constants
 
@@ -128,6 +128,7 @@ class Engine:
         self._conv(sd, "res_conv.3.layers.2")
         self._conv(sd, "res_conv.5", pad_mode=L.PAD_REFLECT)
         # INR: weights L2-normalised along fan_in once (constant at inference)  modules/hyponet.py:124-128
+        inr = []
         for i in range(5):
             wb = sd[f"hyponet.params_dict.linear_wb{i}"].float()
             w = torch.nn.functional.normalize(wb[:-1], dim=0)
@@ -135,6 +136,9 @@ class Engine:
             if i == 4:
                 b = b + 0.5  # output_bias, hyponet.py:143
             self._add(f"inr.{i}", w.t().reshape(w.shape[1], w.shape[0], 1, 1).contiguous(), b)
+            inr.append((w.t().contiguous(), b))
+        # bf16 mode: the five layers run as ONE kernel with register-resident activations (csrc/inr_mlp.hip)
+        self.inr_mlp = InrMlp(self.rt, inr) if InrMlp.supported(self.rt, inr) else None
 
     # ------------------------------------------------------------------ building blocks
     def _enc(self, x, p, norm, B2):
@@ -406,16 +410,19 @@ class Engine:
             # INR   modules/hyponet.py:71-146
             if (Hc, Wc) != (H, W):
                 lat = rt.resize(lat, 32, None, size=(Hc, Wc)).t
-            xin = rt.act(B, Hc, Wc, 35, zero=True)
-            rt._chk(lib.inr_pack(lat.data_ptr(), lat.shape[-1], 32, cg.data_ptr(), xin.data_ptr(), xin.shape[-1],
-                                 xin.shape[-1], B * Hc * Wc, rt.dtype, st()), "inr_pack")
-            hcur = View(xin, 0, 35)
-            for li in range(4):
-                hn = rt.act(B, Hc, Wc, 128)
-                rt.conv(Ls[f"inr.{li}"], hcur, hn, act1=A.ACT_SIN)
-                hcur = hn
             ninr = rt.f32(B, Hc, Wc, 2)
-            rt.conv(Ls["inr.4"], hcur, ninr)
+            if self.inr_mlp is not None:
+                rt.inr_mlp(self.inr_mlp, View(lat, 0, 32), cg, ninr)
+            else:
+                xin = rt.act(B, Hc, Wc, 35, zero=True)
+                rt._chk(lib.inr_pack(lat.data_ptr(), lat.shape[-1], 32, cg.data_ptr(), xin.data_ptr(), xin.shape[-1],
+                                     xin.shape[-1], B * Hc * Wc, rt.dtype, st()), "inr_pack")
+                hcur = View(xin, 0, 35)
+                for li in range(4):
+                    hn = rt.act(B, Hc, Wc, 128)
+                    rt.conv(Ls[f"inr.{li}"], hcur, hn, act1=A.ACT_SIN)
+                    hcur = hn
+                rt.conv(Ls["inr.4"], hcur, ninr)
             flow_t = rt.f32(B, Hc, Wc, 2)
             ninr_nchw = rt.f32(B, 2, 1, Hc, Wc)
             rt._chk(lib.flow_unnormalize(ninr.data_ptr(), scaler.data_ptr(), flow_t.data_ptr(), ninr_nchw.data_ptr(),

@@ -95,6 +95,33 @@ class PatchConvLayer:
         self.inner.cin = kh * kw * cin      # real products per output (FLOP accounting)
 
 
+class InrMlp:
+    """Packed weights of the fused hypo-network kernel (gvfi_inr_mlp): layers = [(w [out,in], b [out])] x 5 with
+    dims 35 -> 128 -> 128 -> 128 -> 128 -> 2.  The packing is the library's own host routine."""
+
+    DIMS = [(128, 35), (128, 128), (128, 128), (128, 128), (2, 128)]
+
+    @staticmethod
+    def supported(rt, layers):
+        return rt.precision == "bf16" and [tuple(w.shape) for w, _ in layers] == InrMlp.DIMS
+
+    def __init__(self, rt, layers):
+        assert InrMlp.supported(rt, layers)
+        ws = [w.detach().float().cpu().contiguous() for w, _ in layers]
+        bs = [b.detach().float().cpu().contiguous() for _, b in layers]
+        nb, nf = C.c_int(), C.c_int()
+        rt.lib.inr_mlp_pack_sizes(C.byref(nb), C.byref(nf))
+        wfrag = torch.zeros(nb.value // 2, dtype=torch.bfloat16)
+        bias = torch.zeros(nf.value, dtype=torch.float32)
+        wp = (C.c_void_p * 5)(*[t.data_ptr() for t in ws])
+        bp = (C.c_void_p * 5)(*[t.data_ptr() for t in bs])
+        rc = rt.lib.inr_mlp_pack(wp, bp, wfrag.data_ptr(), bias.data_ptr())
+        if rc != 0:
+            raise RuntimeError(f"gvfi_inr_mlp_pack failed with code {rc}")
+        self.wfrag = wfrag.to(rt.device)
+        self.bias = bias.to(rt.device)
+
+
 class Runtime:
     def __init__(self, lib, precision, device):
         self.lib = lib
@@ -282,6 +309,14 @@ class Runtime:
         self._chk(self.lib.im2col(src.ptr, src.ld, layer.cin, n, h, w, layer.kh, layer.kw, layer.kh // 2, layer.kw // 2,
                                   scratch.data_ptr(), layer.kpad, self.dtype, self.stream()), "im2col")
         return self.conv(layer.inner, scratch, out, **kw)
+
+    def inr_mlp(self, mlp, lat, coord, out):
+        """out[B,H,W,2] (f32) = hypo-network(lat[..., :32], coord[B,1,H,W,3])."""
+        lat = V(lat)
+        npix = out.numel() // 2
+        self._chk(self.lib.inr_mlp(lat.ptr, lat.ld, coord.data_ptr(), mlp.wfrag.data_ptr(), mlp.bias.data_ptr(),
+                                   out.data_ptr(), npix, self.dtype, self.stream()), "inr_mlp")
+        return out
 
     def flow_pack(self, coords1, dst0, dst1):
         n, h, w = coords1.shape[:3]

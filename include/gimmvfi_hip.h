@@ -144,6 +144,16 @@ int gvfi_softsplat_normalize(const float* acc, int C, void* dst, int ldd, long l
 /* dst[.,0:C]=latent, dst[.,C:C+3]=coord(t,y,x), rest 0 up to pad */
 int gvfi_inr_pack(const void* lat, int ldl, int C, const float* coord, void* dst, int ldd, int pad,
                   long long npix, int dtype, void* stream);
+/* fused hypo-network (modules/hyponet.py:71-146 with the GIMM-VFI-R config: 5 layers, 32 latent + 3 coordinates ->
+ * 128 -> 128 -> 128 -> 128 -> 2, sin activations, F.normalize'd weights and output_bias folded by the caller):
+ * out[npix,2] (float) from lat[npix, ldl] (first 32 channels, bf16) and coord[npix,3] (float).  bf16 mode only
+ * (returns -2 for GVFI_F32: run the layers through gvfi_conv2d).  wfrag / bias are the images built by
+ * gvfi_inr_mlp_pack (host function, no GPU work) from row-major [out][in] float weights w[0..4] and biases b[0..4];
+ * their sizes come from gvfi_inr_mlp_pack_sizes. */
+int gvfi_inr_mlp_pack_sizes(int* wfrag_bytes, int* bias_floats);
+int gvfi_inr_mlp_pack(const float* const* w, const float* const* b, void* wfrag_bf16, float* bias);
+int gvfi_inr_mlp(const void* lat, int ldl, const float* coord, const void* wfrag, const float* bias,
+                 float* out, long long npix, int dtype, void* stream);
 
 /* ---- generic NHWC glue (modules/fi_utils.py:19-49,67-70; F.pixel_shuffle) --------------- */
 /* bilinear resize (align_corners=False, rscale = 1/scale_factor), dst = mul * resize(src) */

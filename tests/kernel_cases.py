@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 import gimmvfi_r_oracle as orc
 from gimmvfi_hip import lib as L
-from gimmvfi_hip.ops import ConvLayer, PatchConvLayer, View
+from gimmvfi_hip.ops import ConvLayer, InrMlp, PatchConvLayer, View
 
 
 def _dev(rt):
@@ -161,6 +161,33 @@ def patch_conv_case(rt, N=2, H=10, W=13, Cin=2, Cout=24, KH=7, KW=7):
     ref = F.relu(F.conv2d(x, w, b, padding=(KH // 2, KW // 2)))
     err = float((out.float().cpu().permute(0, 3, 1, 2)[:, :Cout] - ref).abs().max())
     assert err <= tol(rt, 4.0), err
+
+
+def inr_mlp_case(rt, B=1, H=9, W=61):
+    """fused hypo-network (gvfi_inr_mlp) vs the layer chain of modules/hyponet.py:71-146 with bf16-rounded
+    weights, inputs and hidden activations (what the layer-by-layer bf16 path computes)."""
+    assert rt.precision == "bf16"
+    g = torch.Generator().manual_seed(12)
+    dims = InrMlp.DIMS
+    layers = []
+    for o, i in dims:
+        w = F.normalize(torch.randn(o, i, generator=g), dim=1)
+        layers.append((w, torch.randn(o, generator=g) * 0.3))
+    lat = _rounded(rt, torch.randn(B, H, W, 32, generator=g))
+    coord = torch.rand(B, 1, H, W, 3, generator=g) * 2 - 1
+    dev = _dev(rt)
+    mlp = InrMlp(rt, layers)
+    lat_d = rt.act(B, H, W, 32, zero=True, pitch=40)
+    lat_d[..., :32] = lat.to(lat_d.dtype)
+    out = rt.f32(B, H, W, 2)
+    rt.inr_mlp(mlp, View(lat_d.to(dev), 0, 32), coord.to(dev).contiguous(), out)
+    hcur = torch.cat([lat, _rounded(rt, coord[:, 0])], -1).reshape(-1, 35)
+    for li, (w, b) in enumerate(layers):
+        hcur = hcur @ _rounded(rt, w).t() + b
+        if li < 4:
+            hcur = _rounded(rt, torch.sin(hcur))
+    err = float((out.cpu().reshape(-1, 2) - hcur).abs().max())
+    assert err <= 2e-2, err    # bf16 hidden activations: a 1-ulp flip of a hidden unit moves the output ~4e-3
 
 
 def resize_warp_shuffle_case(rt):

@@ -63,6 +63,13 @@ def test_patch_conv(rt):
     kc.patch_conv_case(rt, N=1, H=9, W=8, Cin=4, Cout=16)
 
 
+def test_inr_mlp(rt):
+    if rt.precision != "bf16":
+        pytest.skip("fused hypo-network is the bf16 path; fp32 runs layer by layer")
+    kc.inr_mlp_case(rt)
+    kc.inr_mlp_case(rt, B=2, H=16, W=40)
+
+
 def test_instnorm(rt):
     kc.instnorm_case(rt)
 
