@@ -281,15 +281,9 @@ template <typename T> static int dispatch_conv(const gvfi_conv_params& p, hipStr
     }
 }
 
-// Which kernel gvfi_conv2d would launch for *pp: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch), BM, BN, K-chunk bytes, LDS stages}.
+// Which kernel gvfi_conv2d would launch for *pp: plan[5] = {algo (1 generic, 2 LDS-DMA), BM, BN, K-chunk bytes, LDS stages}.
 extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
     const gvfi_conv_params& p = *pp;
-    if ((p.algo & 15) == 3) {
-        const int kb = gvfi_conv2d_patch_eligible(pp);
-        if (!kb) return -2;
-        plan[0] = 3; plan[1] = 0; plan[2] = p.Cout > 32 ? 64 : 32; plan[3] = kb; plan[4] = 1;
-        return 0;
-    }
     if ((p.algo & 15) == 2 || (p.algo == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds_plan(pp, plan);
     if (p.w_layout != 0) return -5;
     plan[0] = 1; plan[1] = 128; plan[2] = generic_tile(p); plan[3] = 64; plan[4] = 2;
@@ -298,7 +292,6 @@ extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
 
 extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {
     const gvfi_conv_params& p = *pp;
-    if ((p.algo & 15) == 3) return gvfi_conv2d_patch(pp, stream);
     if ((p.algo & 15) == 2 || (p.algo == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds(pp, stream);
     if (p.w_layout != 0) return -5;   // the chunked weight image is only understood by the LDS-DMA kernel
     const int ve = p.dtype == GVFI_F32 ? 4 : 8;

@@ -73,6 +73,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     if (v >= a.MT * a.NT) return;
     const int mt = v / a.NT, nt = v - mt * a.NT;
     const int g = blockIdx.z;
+#ifndef GVFI_HOSTSIM
+    if ((a.dbg & 64) && bid < 256) {   // experiment: de-phase the CUs so their store bursts do not coincide
+        for (int i = 0; i < ((bid * 37) & 63); ++i) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -216,18 +221,26 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     auto compute = [&](int kt, auto dma_tag) {
         constexpr bool DMA = decltype(dma_tag)::value;
         const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
+        // fragments are double-buffered by hand: the ds_reads of k-step kk+1 are issued BEFORE the MFMAs of k-step kk
+        // and the scheduler may not move them back (left alone, hipcc re-uses one fragment set and every MFMA group
+        // waits a full LDS round trip, ~45% of the K loop).  rows i*32 further down share the swizzle term
+        // (32 rows = a multiple of its period): immediate offsets.
+        uint4 fa[2][MI], fb[2][NI];
+        auto load_frags = [&](int kk, int buf) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[buf][i] = *(const uint4*)(sa + a_rd[kk] + i * 32 * RB);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[buf][j] = *(const uint4*)(sa + b_rd[kk] + j * 32 * RB);
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            uint4 fa[MI], fb[NI];
-            // rows i*32 further down share the swizzle term (32 rows = a multiple of its period): immediate offsets
-#pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(sa + a_rd[kk] + i * 32 * RB);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) fb[j] = *(const uint4*)(sa + b_rd[kk] + j * 32 * RB);
+            if (kk + 1 < KK) load_frags(kk + 1, (kk + 1) & 1);
+            GVFI_SCHED_BARRIER();
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
                 if (DMA) {
                     constexpr int NSLOT = KK * MI;
                     const int slot_id = kk * MI + i;
@@ -236,6 +249,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                         if (pc % NSLOT == slot_id) stage_piece(pc);
                 }
             }
+            GVFI_SCHED_BARRIER();
         }
     };
     // Steady state: chunk kt must have landed while the AHEAD-1 younger chunks stay in flight (LDS-DMA issue->landed
@@ -311,6 +325,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             const float4 c0 = *(const float4*)(cs + row * BN + cg * 8);
             const float4 c1 = *(const float4*)(cs + row * BN + cg * 8 + 4);
             vv[0] = c0.x; vv[1] = c0.y; vv[2] = c0.z; vv[3] = c0.w; vv[4] = c1.x; vv[5] = c1.y; vv[6] = c1.z; vv[7] = c1.w;
+            if ((a.dbg & 32) && vv[0] != 12345.678f) continue;   // profiling only: LDS staging without math / stores
             epilogue_group<T>(p, gc, vv, cout0, n_valid, (long long)g * a.Mg + m, vec_all && n_valid == 8);
         }
         if (ps + 1 < NPASS) __syncthreads();
@@ -375,6 +390,8 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
         bm = bm <= 64 ? 64 : 128;
         if (ns == 0) ns = bm == 64 ? 3 : 2;
         ns = ns < 2 ? 2 : (ns > 4 ? 4 : ns);
+    } else if (tile == 128 && k == 64 && bm == 256) {
+        ns = 3;      // 256 x 128, 4 waves, 72 KiB: two workgroups per CU (one's epilogue overlaps the other's K loop)
     } else {
         bm = 128;
         ns = (k == 64 && tile >= 64) ? 4 : 2;
@@ -415,6 +432,7 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
         if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                 \
         return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);                                                 \
     }                                                                                                         \
+    if (tile == 128 && bm == 256) return launch_glds<TT, 256, 128, 2, 2, 64, 3>(p, st);                       \
     if (tile == 128) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
     if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                      \
     return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);

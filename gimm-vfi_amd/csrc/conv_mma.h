@@ -1,4 +1,4 @@
-// Shared device helpers of the LDS-DMA convolution kernels (conv_igemm_glds.hip, conv_patch.hip):
+// Shared device helpers of the MFMA kernels (conv_igemm_glds.hip, inr_mlp.hip):
 // MFMA wrappers, the inline-asm LDS-DMA, bf16 packing and the LDS-staged vector epilogue.
 #pragma once
 #include "common.h"
@@ -81,6 +81,13 @@ static inline void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned lds_addr) {
 }
 static inline void glds_wait() {}
 template <int N> static inline void glds_wait_n() {}
+#endif
+
+// instruction-scheduling fence: nothing is moved across it (keeps hand-written software pipelining in place)
+#ifndef GVFI_HOSTSIM
+#define GVFI_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GVFI_SCHED_BARRIER() ((void)0)
 #endif
 
 template <typename T> struct Mma2;

@@ -120,6 +120,7 @@ class InrMlp:
             raise RuntimeError(f"gvfi_inr_mlp_pack failed with code {rc}")
         self.wfrag = wfrag.to(rt.device)
         self.bias = bias.to(rt.device)
+        self.layers = list(zip(ws, bs))   # un-packed copies (host): kept for inspection / test restatements
 
 
 class Runtime:
@@ -191,8 +192,6 @@ class Runtime:
             if want in (0, 2) and aligned and not (algo & 128):
                 p.w, p.w_layout = layer.w_glds.data_ptr(), 1
                 algo = 2 | (algo & ~15)
-            elif want == 3 and aligned:
-                p.w, p.w_layout = layer.w_glds.data_ptr(), 1
             else:
                 p.w, p.w_layout = layer.w.data_ptr(), 0
             p.bias = None if layer.b is None else layer.b.data_ptr()
@@ -246,7 +245,7 @@ class Runtime:
             self._chk(self.lib.conv2d_plan(C.byref(p), plan), "conv2d_plan")   # the library says which kernel it ran
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
-            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel"}[plan[0]]
+            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel"}[plan[0]]
             tag = f"{kname}<{'float' if self.dtype == L.F32 else 'bf16'},{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"

@@ -71,21 +71,19 @@ typedef struct {
                                          * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
                                          * contiguous copy (K chunk = 128 bytes)                             */
     int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
-                                         * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32),  *
-                                         * 3 = direct patch kernel (stride 1, 'same', zeros)      */
+                                         * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32);   *
+                                         * bits 4..6: LDS ring depth override (A/B runs), bit 7: *
+                                         * force 64-byte K chunks, bits 8..: profiling switches   */
 } gvfi_conv_params;
 
 int gvfi_conv2d(const gvfi_conv_params* p, void* stream);
-/* which kernel gvfi_conv2d would launch: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch), BM, BN, K-chunk bytes,
+/* which kernel gvfi_conv2d would launch: plan[5] = {algo (1 generic, 2 LDS-DMA), BM, BN, K-chunk bytes,
  * LDS stages} */
 int gvfi_conv2d_plan(const gvfi_conv_params* p, int* plan);
 int gvfi_conv2d_glds_plan(const gvfi_conv_params* p, int* plan);
 /* the two kernels behind gvfi_conv2d (exposed for A/B measurements) */
 int gvfi_conv2d_glds_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
-/* direct (input-patch-in-LDS) kernel for stride-1 'same' convolutions; _eligible returns the K-chunk bytes or 0 */
-int gvfi_conv2d_patch_eligible(const gvfi_conv_params* p);
-int gvfi_conv2d_patch(const gvfi_conv_params* p, void* stream);
 
 /* ---- input preparation (gimmvfi_r.py:230-231,329-337,349; raft/raft.py:111-112) ------ */
 /* bilinear resize of float planes, align_corners=False, rscale = (float)(1.0/scale_factor)

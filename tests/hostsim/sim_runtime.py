@@ -71,6 +71,21 @@ class SimRuntime(Runtime):
         return self._torch_conv(layer, V(x0), V(out), None if x1 is None else V(x1), act1, res, act2, out_scale,
                                 slope1, slope2, epi, y2, aux0, aux1, groups, w_raw, cout)
 
+    def inr_mlp(self, mlp, lat, coord, out):
+        """Fused hypo-network: emulated kernel for unit shapes, else an independent torch statement of the same
+        arithmetic (bf16-rounded weights and hidden activations, fp32 accumulation) from the un-packed layers."""
+        if self.emulate_conv:
+            return super().inr_mlp(mlp, lat, coord, out)
+        lat = V(lat)
+        bf = lambda t: t.to(torch.bfloat16).float()
+        h = torch.cat([self._sl(lat, 32), bf(coord[:, 0])], -1).reshape(-1, 35)
+        for li, (w, b) in enumerate(mlp.layers):
+            h = h @ bf(w.float().cpu()).t() + b.float().cpu()
+            if li < 4:
+                h = bf(torch.sin(h))
+        out.copy_(h.reshape(out.shape))
+        return out
+
     def _sl(self, v, c=None):
         c = v.c if c is None else c
         return v.t[..., v.coff:v.coff + c].float()

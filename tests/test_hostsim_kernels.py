@@ -32,14 +32,11 @@ CONV_SHAPES = [
     (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),  # 8-wave 256x256 tile
     (1, 9, 11, 128, 24, 3, 3, dict(out_f32=True)),        # Cout <= 32 on the LDS-DMA kernel (128x32 tile)
     (2, 6, 7, 64, 2, 3, 3, dict(out_f32=True, with_res=True)),
-    # direct patch kernel (conv_patch.hip): 2-D tiles, ragged image sizes, two sources, 64-byte K chunks
-    (1, 9, 40, 64, 70, 3, 3, dict(algo=3, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
-    (2, 5, 33, 128, 48, 1, 5, dict(algo=3, split=64, act1=L.ACT_RELU)),
-    (1, 6, 20, 128, 24, 5, 1, dict(algo=3, out_f32=True)),
-    (1, 7, 36, 32, 32, 3, 3, dict(algo=3, act1=L.ACT_LRELU)),
-    (1, 10, 34, 96, 40, 3, 3, dict(algo=3, with_res=True)),
-    (1, 11, 37, 64, 200, 3, 3, dict(algo=3, tile=256, act1=L.ACT_PRELU)),
-    (1, 8, 32, 128, 130, 5, 5, dict(algo=3)),
+    # selectable LDS-DMA variants: 64-row tiles, 3/4-deep rings (counted vmcnt), 256x128 with 64-byte chunks
+    (1, 9, 40, 64, 70, 3, 3, dict(algo=2 + 16 * 3, tile=128 | (64 << 10), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
+    (1, 8, 10, 128, 130, 1, 5, dict(algo=2 + 16 * 2, tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
+    (1, 9, 12, 64, 130, 3, 3, dict(algo=2 + 16 * 4, tile=128 | (128 << 10))),
+    (1, 17, 19, 32, 100, 3, 3, dict(algo=2 + 128, tile=128 | (256 << 10), act1=L.ACT_LRELU)),
 ]
 
 

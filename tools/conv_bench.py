@@ -23,6 +23,8 @@ SHAPES = [
     ("init.resblock 128->128 3x3 @64x112 B8", 8, 64, 112, 128, 128, 3, 3, None),
     ("upd_high 320->192 3x3 @64x112", 8, 64, 112, 320, 192, 3, 3, None),
     ("cnn_enc 32->32 3x3 @256x448 B16", 16, 256, 448, 32, 32, 3, 3, None),
+    ("fnet 64->64 3x3 @128x224 B16", 16, 128, 224, 64, 64, 3, 3, None),
+    ("fnet 96->96 3x3 @64x112 B16", 16, 64, 112, 96, 96, 3, 3, None),
     ("final.up 32->64 3x3 @256x448 B16", 16, 256, 448, 32, 64, 3, 3, None),
     ("final.head 256->24 3x3 @256x448 B8", 8, 256, 448, 256, 24, 3, 3, None),
 ]
@@ -51,8 +53,14 @@ def main():
         variants = ((1, 0), (2, 128), (2, 256), (2 + 128, 128), (2 + 128, 256))
         if os.environ.get("SMALLM"):   # BM / ring depth sweep for the small-M (RAFT) shapes
             variants = tuple((2 + 16 * ns, 128 | (bm << 10)) for bm in (128, 64) for ns in (2, 3, 4))
+        if os.environ.get("T256x128"):
+            variants = ((2, 256), (2 + 128, 128 | (256 << 10)), (2 + 128, 128 | (128 << 10)), (2, 128 | (128 << 10)))
+        if os.environ.get("BN64"):
+            variants = ((2, 128 | (128 << 10)), (2, 64), (2, 32))
+        if os.environ.get("ONLY256"):     # single variant for PMC passes
+            variants = ((2, 256),)
         if os.environ.get("ABLATE"):
-            variants = tuple((2 + 256 * m, 256) for m in (0, 8, 16, 24)) + tuple((2 + 256 * m, 128 | (128 << 10)) for m in (0, 8, 16, 24))
+            variants = tuple((2 + 256 * m, 256) for m in (0, 0, 64, 8, 16, 24, 32)) + tuple((2 + 256 * m, 128 | (128 << 10)) for m in (0, 8, 16, 24))
         for algo, tile in variants:
             if (tile & 1023) == 256 and Cout < 192:
                 continue
