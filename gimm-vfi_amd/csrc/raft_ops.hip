@@ -29,6 +29,11 @@ extern "C" int gvfi_avgpool2_f32(const float* src, float* dst, long long maps, i
 // (x = cx/2^l + (i-r),  y = cy/2^l + (j-r)):  the FIRST window index moves x (the reference adds
 // meshgrid(dy,dx) to (x,y) coordinates).  grid_sample(align_corners=True, zeros padding) semantics
 // including the normalise/un-normalise round trip of raft/utils/utils.py:66-80.
+// One thread = one (query, level, dx) column of the window: its 2r+1 outputs (dy = -r..r) share the two source
+// columns x0, x0+1, so the 2r+2 rows are loaded once (20 loads for 9 outputs instead of 36) and the outputs are 9
+// consecutive channels.  Every output is computed with exactly the reference's per-tap float expression; when the
+// normalise/un-normalise rounding moves a tap's row off the cached run, that tap falls back to direct loads.
+#define CORR_MAX_WIN 9
 template <typename T>
 __global__ void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                    const float* __restrict__ l2, const float* __restrict__ l3,
@@ -37,40 +42,70 @@ __global__ void corr_lookup_kernel(const float* __restrict__ l0, const float* __
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int win = 2 * radius + 1;
-    const int per_q = 4 * win * win;
-    const int ch = (int)(idx % per_q);
-    const long long q = idx / per_q;  // global query index (n*h*w + y*w + x)
-    const int l = ch / (win * win);
-    const int ij = ch - l * win * win;
-    const int i = ij / win, j = ij - i * win;
+    const int i = (int)(idx % win);
+    const int l = (int)((idx / win) & 3);
+    const long long q = idx / (4 * win);  // global query index (n*h*w + y*w + x)
     const int hl = h2 >> l, wl = w2 >> l;
     const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + q * (long long)hl * wl;
     const float sc = 1.0f / (float)(1 << l);
-    const float cx = coords[q * 2 + 0] * sc + (float)(i - radius);
-    const float cy = coords[q * 2 + 1] * sc + (float)(j - radius);
+    const float qx = coords[q * 2 + 0] * sc, qy = coords[q * 2 + 1] * sc;
     // bilinear_sampler: normalise to [-1,1] then grid_sample un-normalises (align_corners=True)
+    const float cx = qx + (float)(i - radius);
     const float xn = 2.f * cx / (float)(wl - 1) - 1.f;
-    const float yn = 2.f * cy / (float)(hl - 1) - 1.f;
     const float ix = ((xn + 1.f) * 0.5f) * (float)(wl - 1);
-    const float iy = ((yn + 1.f) * 0.5f) * (float)(hl - 1);
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    const float ax = ix - x0f, ay = iy - y0f;
-    float v = 0.f;
+    const float x0f = floorf(ix);
+    const int x0 = (int)x0f;
+    const float ax = ix - x0f;
     const bool xin0 = x0 >= 0 && x0 < wl, xin1 = x0 + 1 >= 0 && x0 + 1 < wl;
-    const bool yin0 = y0 >= 0 && y0 < hl, yin1 = y0 + 1 >= 0 && y0 + 1 < hl;
-    if (xin0 && yin0) v += (1.f - ax) * (1.f - ay) * base[(long long)y0 * wl + x0];
-    if (xin1 && yin0) v += ax * (1.f - ay) * base[(long long)y0 * wl + x0 + 1];
-    if (xin0 && yin1) v += (1.f - ax) * ay * base[(long long)(y0 + 1) * wl + x0];
-    if (xin1 && yin1) v += ax * ay * base[(long long)(y0 + 1) * wl + x0 + 1];
-    Elem<T>::st(out + q * ldo + ch, v);
+    auto row_of = [&](int j, float& ay) {
+        const float cy = qy + (float)(j - radius);
+        const float yn = 2.f * cy / (float)(hl - 1) - 1.f;
+        const float iy = ((yn + 1.f) * 0.5f) * (float)(hl - 1);
+        const float y0f = floorf(iy);
+        ay = iy - y0f;
+        return (int)y0f;
+    };
+    auto fetch = [&](int y, float& a, float& b) {
+        const bool yin = y >= 0 && y < hl;
+        a = (yin && xin0) ? base[(long long)y * wl + x0] : 0.f;
+        b = (yin && xin1) ? base[(long long)y * wl + x0 + 1] : 0.f;
+    };
+    float ay0;
+    const int ybase = row_of(0, ay0);
+    float ca[CORR_MAX_WIN + 1], cb[CORR_MAX_WIN + 1];
+#pragma unroll
+    for (int k = 0; k <= CORR_MAX_WIN; ++k)
+        if (k <= win) fetch(ybase + k, ca[k], cb[k]);
+    T* o = out + q * ldo + l * win * win + i * win;
+#pragma unroll
+    for (int j = 0; j < CORR_MAX_WIN; ++j) {
+        if (j >= win) break;
+        float ay;
+        const int y0 = row_of(j, ay);
+        float v00, v01, v10, v11;
+        if (y0 == ybase + j) {
+            v00 = ca[j]; v01 = cb[j]; v10 = ca[j + 1]; v11 = cb[j + 1];
+        } else {
+            fetch(y0, v00, v01);
+            fetch(y0 + 1, v10, v11);
+        }
+        // same accumulation order as the per-tap statement: (x0,y0), (x1,y0), (x0,y1), (x1,y1); absent taps add 0
+        float v = 0.f;
+        const bool yin0 = y0 >= 0 && y0 < hl, yin1 = y0 + 1 >= 0 && y0 + 1 < hl;
+        if (xin0 && yin0) v += (1.f - ax) * (1.f - ay) * v00;
+        if (xin1 && yin0) v += ax * (1.f - ay) * v01;
+        if (xin0 && yin1) v += (1.f - ax) * ay * v10;
+        if (xin1 && yin1) v += ax * ay * v11;
+        Elem<T>::st(o + j, v);
+    }
 }
 extern "C" int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3,
                                 const float* coords, void* out, int ldo, int dtype, int N, int h, int w, int h2,
                                 int w2, int radius, void* stream) {
     const int win = 2 * radius + 1;
-    const long long total = (long long)N * h * w * 4 * win * win;
+    const long long total = (long long)N * h * w * 4 * win;
     if ((h2 >> 3) < 2 || (w2 >> 3) < 2) return -2;  // coarsest level must be >= 2x2 (reference divides by W-1)
+    if (win > CORR_MAX_WIN) return -2;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((corr_lookup_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, l0, l1, l2, l3, coords, (T*)out, ldo, total, h2, w2,
                                               radius));

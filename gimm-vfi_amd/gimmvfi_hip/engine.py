@@ -228,8 +228,10 @@ class Engine:
         rt.conv(Ls["cnet.out_net"], c128, hA, act1=A.ACT_TANH)
         rt.conv(Ls["cnet.out_inp"], c128, View(xbuf, 0, 128), act1=A.ACT_RELU)
         # correlation pyramids: direction 0->1 for images [0,B), 1->0 for [B,2B)
-        pyr_a = self._corr_pyramids(fmap[:B], fmap[B:], B, h8, w8)
-        pyr_b = self._corr_pyramids(fmap[B:], fmap[:B], B, h8, w8)
+        # correlation pyramids of both directions in one grouped GEMM: image i against its partner (i +- B)
+        fswap = torch.cat([fmap[B:], fmap[:B]], 0)
+        pyr_ab = self._corr_pyramids(fmap, fswap, n, h8, w8)
+        pyr_a = [p[:B * h8 * w8] for p in pyr_ab]
         if taps is not None:
             taps["r01_fmap1"] = fmap[:B]
             taps["r01_net0"] = hA[:B].clone()
@@ -248,13 +250,16 @@ class Engine:
         u = fe + ".update_block"
         fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
         for it in range(iters):
-            rt.corr_lookup(pyr_a, coords[:B], corrf[:B], B, h8, w8, h8, w8)
-            rt.corr_lookup(pyr_b, coords[B:], corrf[B:], B, h8, w8, h8, w8)
+            rt.corr_lookup(pyr_ab, coords, corrf, n, h8, w8, h8, w8)
             rt.flow_pack(coords, flow8, View(xbuf, 254, 2))
-            rt.conv(Ls[u + ".encoder.convc1"], corrf, c1, act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
-            rt.patch_conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, scratch=fcol, act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
+            # the correlation and flow branches of the motion encoder are independent and each under-fills the chip
+            # (224-448 workgroups): fork the flow branch onto a second stream (a parallel branch of the hipGraph)
+            with rt.fork() as branch:
+                rt.conv(Ls[u + ".encoder.convc1"], corrf, c1, act1=A.ACT_RELU)
+                rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
+                with branch:
+                    rt.patch_conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, scratch=fcol, act1=A.ACT_RELU)
+                    rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
             rt.conv(Ls[u + ".encoder.conv"], corflo, View(xbuf, 128, 126), act1=A.ACT_RELU)
             hc, hn = hA, hB
             for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73
@@ -336,8 +341,9 @@ class Engine:
         h4, w4 = H // 4, W // 4
         g = rt.act(n, h8, w8, 256)
         rt.conv(Ls["amt_fproj"], fmap, g)
-        pyr = self._corr_pyramids(g[:B], g[B:], B, h8, w8)      # corr
-        pyrT = self._corr_pyramids(g[B:], g[:B], B, h8, w8)     # corr_T (raft/corr.py:32)
+        pyr2 = self._corr_pyramids(g, torch.cat([g[B:], g[:B]], 0), n, h8, w8)
+        pyr = [p[:B * h8 * w8] for p in pyr2]       # corr
+        pyrT = [p[B * h8 * w8:] for p in pyr2]      # corr_T (raft/corr.py:32)
         feat4 = rt.act(n, h4, w4, 128)
         rt.conv(Ls["amt_second_last_cproj"], cfeats[1], feat4)
         feat8 = rt.act(n, h8, w8, 256)

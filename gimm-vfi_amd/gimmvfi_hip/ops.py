@@ -123,6 +123,47 @@ class InrMlp:
         self.layers = list(zip(ws, bs))   # un-packed copies (host): kept for inspection / test restatements
 
 
+class _Fork:
+    """`with rt.fork() as branch:` ... `with branch:` runs the inner block on a second HIP stream that starts after
+    everything enqueued so far and is joined when the outer block exits (a fork/join in a captured hipGraph).
+    Buffers touched inside must be allocated before the fork (no allocator traffic on the side stream)."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.side = None
+        self.ctx = None
+
+    def __enter__(self):
+        if self.rt.on_gpu and self.rt.ev_log is None:
+            if self.rt._side is None:
+                self.rt._side = torch.cuda.Stream(device=self.rt.device)
+            self.side = self.rt._side
+            self.side.wait_stream(torch.cuda.current_stream(self.rt.device))
+        return _Branch(self)
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            torch.cuda.current_stream(self.rt.device).wait_stream(self.side)
+        return False
+
+
+class _Branch:
+    def __init__(self, fork):
+        self.fork = fork
+        self.ctx = None
+
+    def __enter__(self):
+        if self.fork.side is not None:
+            self.ctx = torch.cuda.stream(self.fork.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class Runtime:
     def __init__(self, lib, precision, device):
         self.lib = lib
@@ -138,10 +179,14 @@ class Runtime:
         self.n_launch = 0
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
+        self._side = None        # second stream for fork()
 
     # ------------------------------------------------------------------ memory
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else 0
+
+    def fork(self):
+        return _Fork(self)
 
     def cp(self, c):
         return roundup(c, self.VE)
