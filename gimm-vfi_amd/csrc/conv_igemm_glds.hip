@@ -178,6 +178,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     unsigned st_tapbit = 1u;
     const unsigned smem_lds = lds_address(smem);
     unsigned st_sa = smem_lds;
+    // K order: channel chunk OUTER, filter tap INNER.  While a chunk's taps are walked, the workgroups of an XCD only
+    // touch that chunk's 128-byte slice of their input pixels (1/chunks_tap of the footprint), so the 9 shifted
+    // re-reads of a 3x3 filter hit the XCD's L2; with the tap outside, every re-read of the 256->256 layer had gone
+    // back to the fabric (FETCH_SIZE 5x the input, profiles/).  The chunk-major weight image is packed in this order.
     auto stage_begin = [&](int kt) {
         st_sa = smem_lds + (kt % NSTAGE) * STAGE;
         st_from0 = ck < a.chunks0;
@@ -185,12 +189,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         const int ld = st_from0 ? p.ld0 : p.ld1;
         const int cbase = (st_from0 ? ck : ck - a.chunks0) * BKE;
         st_srd_a = make_srd(xs + ((long long)(pix_ref + kh * p.W + kw) * ld + cbase));
-        st_srd_b = make_srd(wg + (p.w_layout == 1 ? (long long)kt * p.Cout * BKE : (long long)kt * BKE));
+        st_srd_b = make_srd(wg + (p.w_layout == 1 ? (long long)kt * p.Cout * BKE
+                                                  : (long long)(tap * a.chunks_tap + ck) * BKE));
         st_tapbit = 1u << tap;
-        if (++ck == a.chunks_tap) {
-            ck = 0;
-            ++tap;
-            if (++kw == p.KW) { kw = 0; ++kh; }
+        ++tap;
+        if (++kw == p.KW) {
+            kw = 0;
+            if (++kh == p.KH) { kh = 0; tap = 0; ++ck; }
         }
     };
     // one LDS-DMA instruction (1 KiB per wave): pieces [0, A_INSTR) are A rows, [A_INSTR, NPIECE) B rows

@@ -68,7 +68,8 @@ class ConvLayer:
         self.w_glds = None
         if cp % bke == 0 and pad_mode == L.PAD_ZEROS and not os.environ.get("GVFI_NO_WGLDS"):
             k = kh * kw * cp
-            wk = pk.reshape(cout, k // bke, 8, rt.VE)                         # [n][chunk][slot][ve]
+            # K chunks in the kernel's walk order: channel chunk outer, filter tap inner (L2 locality of the taps)
+            wk = pk.reshape(cout, kh * kw, cp // bke, 8, rt.VE).permute(0, 2, 1, 3, 4).reshape(cout, k // bke, 8, rt.VE)
             sw = (torch.arange(cout, device=pk.device) >> 1) & 7                # (row>>1)&7 with row == n (tile bases are /16)
             src_slot = torch.arange(8, device=pk.device)[None, :] ^ sw[:, None]    # dest slot s holds source slot s^sw
             wk = torch.gather(wk, 2, src_slot[:, None, :, None].expand(cout, k // bke, 8, rt.VE))

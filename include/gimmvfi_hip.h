@@ -69,7 +69,8 @@ typedef struct {
     int w_layout;                       /* 0: [Cout][KH][KW][Cin];  1 (LDS-DMA kernel only): K-chunk major,  *
                                          * [K/64][Cout][64] with the 16-byte groups of a row XOR-swizzled by *
                                          * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
-                                         * contiguous copy (K chunk = 128 bytes)                             */
+                                         * contiguous copy (K chunk = 128 bytes).  Chunk index =               *
+                                         * channel_chunk * KH*KW + tap (the kernel walks the taps innermost)   */
     int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32);   *
                                          * bits 4..6: LDS ring depth override (A/B runs), bit 7: *
