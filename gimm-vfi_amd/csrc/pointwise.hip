@@ -240,8 +240,54 @@ __global__ void resize_nhwc_kernel(const void* __restrict__ src, int lds, int sr
     const float v = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
     st_any<T>(dst, pix * ldd + c, dst_f32, mul * v);
 }
+// same arithmetic, one 16-byte channel vector (8 bf16 / 4 f32) per thread: used whenever both tensors have the
+// runtime element type and vector-aligned pitches (every feature-map resize of the path)
+template <typename T>
+__global__ void resize_nhwc_vec_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int C,
+                                       long long total, int H, int W, int Ho, int Wo, float rscale, float mul) {
+    constexpr int VE = Elem<T>::VE;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int G = C / VE;
+    const int c = (int)(idx % G) * VE;
+    long long pix = idx / G;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const long long n = pix / ((long long)Wo * Ho);
+    const Lerp ly = src_index(oy, rscale, H), lx = src_index(ox, rscale, W);
+    const long long b = n * (long long)H * W;
+    const Vec16<T> a00 = *(const Vec16<T>*)(src + (b + (long long)ly.i0 * W + lx.i0) * lds + c);
+    const Vec16<T> a01 = *(const Vec16<T>*)(src + (b + (long long)ly.i0 * W + lx.i1) * lds + c);
+    const Vec16<T> a10 = *(const Vec16<T>*)(src + (b + (long long)ly.i1 * W + lx.i0) * lds + c);
+    const Vec16<T> a11 = *(const Vec16<T>*)(src + (b + (long long)ly.i1 * W + lx.i1) * lds + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const float v00 = Elem<T>::ld(&a00.e[e]), v01 = Elem<T>::ld(&a01.e[e]);
+        const float v10 = Elem<T>::ld(&a10.e[e]), v11 = Elem<T>::ld(&a11.e[e]);
+        const float v = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
+        Elem<T>::st(&o.e[e], mul * v);
+    }
+    *(Vec16<T>*)(dst + pix * ldd + c) = o;
+}
+template <typename T> static bool vec_tensors_ok(const void* a, int lda, int a_f32, const void* b, int ldb, int b_f32, int C) {
+    constexpr int VE = Elem<T>::VE;
+    const bool a_t = sizeof(T) == 4 ? true : !a_f32, b_t = sizeof(T) == 4 ? true : !b_f32;   // tensor holds T elements
+    return a_t && b_t && C % VE == 0 && lda % VE == 0 && ldb % VE == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+}
 extern "C" int gvfi_resize_nhwc(const void* src, int lds, int src_f32, void* dst, int ldd, int dst_f32, int C, int N,
                                 int H, int W, int Ho, int Wo, float rscale, float mul, int dtype, void* stream) {
+    {
+        bool vec = false;
+        GVFI_DISPATCH_T(dtype, vec = (vec_tensors_ok<T>(src, lds, src_f32, dst, ldd, dst_f32, C)));
+        if (vec) {
+            const long long totv = (long long)N * Ho * Wo * (C / (dtype == GVFI_F32 ? 4 : 8));
+            GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((resize_nhwc_vec_kernel<T>), grid1d(totv), dim3(GVFI_BLOCK),
+                                                      (hipStream_t)stream, (const T*)src, lds, (T*)dst, ldd, C, totv, H,
+                                                      W, Ho, Wo, rscale, mul));
+            return (int)hipGetLastError();
+        }
+    }
     const long long total = (long long)N * Ho * Wo * C;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((resize_nhwc_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, src, lds, src_f32, dst, ldd, dst_f32, C, total, H, W,
@@ -279,8 +325,58 @@ __global__ void warp_nhwc_kernel(const void* __restrict__ src, int lds, int src_
         v += ax * ay * ld_any<T>(src, (b + (long long)(y0 + 1) * W + x0 + 1) * lds + c, src_f32);
     st_any<T>(dst, pix * ldd + c, dst_f32, v);
 }
+template <typename T>
+__global__ void warp_nhwc_vec_kernel(const T* __restrict__ src, int lds, const float* __restrict__ flow, int ldf,
+                                     float fmul, T* __restrict__ dst, int ldd, int C, long long total, int H, int W) {
+    constexpr int VE = Elem<T>::VE;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int G = C / VE;
+    const int c = (int)(idx % G) * VE;
+    const long long pix = idx / G;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    float fx = (float)x + fmul * flow[pix * ldf + 0];
+    float fy = (float)y + fmul * flow[pix * ldf + 1];
+    fx = fminf(fmaxf(fx, 0.f), (float)(W - 1));
+    fy = fminf(fmaxf(fy, 0.f), (float)(H - 1));
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float ax = fx - x0f, ay = fy - y0f;
+    const long long b = n * (long long)H * W;
+    const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
+    const T* p00 = src + (b + (long long)y0 * W + x0) * lds + c;
+    const Vec16<T> a00 = *(const Vec16<T>*)p00;
+    Vec16<T> a01 = a00, a10 = a00, a11 = a00;
+    if (xin) a01 = *(const Vec16<T>*)(p00 + lds);
+    if (yin) a10 = *(const Vec16<T>*)(p00 + (long long)W * lds);
+    if (xin && yin) a11 = *(const Vec16<T>*)(p00 + (long long)(W + 1) * lds);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        float v = 0.f;
+        v += (1.f - ax) * (1.f - ay) * Elem<T>::ld(&a00.e[e]);
+        if (xin) v += ax * (1.f - ay) * Elem<T>::ld(&a01.e[e]);
+        if (yin) v += (1.f - ax) * ay * Elem<T>::ld(&a10.e[e]);
+        if (xin && yin) v += ax * ay * Elem<T>::ld(&a11.e[e]);
+        Elem<T>::st(&o.e[e], v);
+    }
+    *(Vec16<T>*)(dst + pix * ldd + c) = o;
+}
 extern "C" int gvfi_warp_nhwc(const void* src, int lds, int src_f32, const float* flow, int ldf, float fmul, void* dst,
                               int ldd, int dst_f32, int C, int N, int H, int W, int dtype, void* stream) {
+    {
+        bool vec = false;
+        GVFI_DISPATCH_T(dtype, vec = (vec_tensors_ok<T>(src, lds, src_f32, dst, ldd, dst_f32, C)));
+        if (vec) {
+            const long long totv = (long long)N * H * W * (C / (dtype == GVFI_F32 ? 4 : 8));
+            GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((warp_nhwc_vec_kernel<T>), grid1d(totv), dim3(GVFI_BLOCK),
+                                                      (hipStream_t)stream, (const T*)src, lds, flow, ldf, fmul, (T*)dst,
+                                                      ldd, C, totv, H, W));
+            return (int)hipGetLastError();
+        }
+    }
     const long long total = (long long)N * H * W * C;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((warp_nhwc_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, src, lds, src_f32, flow, ldf, fmul, dst, ldd,
