@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     static_assert(MI >= 1 && NI >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile");
     static_assert((NSTAGE - 2) * NPIECE <= 63, "vmcnt range");
     // counted waits assume every wave issues exactly NPIECE DMAs per chunk
-    static_assert(NSTAGE == 2 || (A_TOTAL % NW == 0 && B_TOTAL % NW == 0), "ring needs whole pieces per wave");
+    // (a wave without its own B rows re-stages another wave's rows -- same bytes to the same LDS address -- so that
+    // every wave issues exactly NPIECE DMAs per chunk)
+    static_assert(NSTAGE == 2 || A_TOTAL % NW == 0, "ring needs whole A pieces per wave");
     auto swz = [](int row) { return KB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];   // ring of K chunks
@@ -142,9 +144,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     unsigned b_off[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
-        const int row = (i * NW + wave) * RPI + lrow;
+        const int row = ((i * NW + wave) % B_TOTAL) * RPI + lrow;
         const int n = n0 + row;
-        const bool ok = (i * NW + wave) < B_TOTAL && n < p.Cout;
+        const bool ok = n < p.Cout;
         if (p.w_layout == 1)   // chunk-major, pre-swizzled image: [K chunk][Cout][128 B] == the LDS image (KB = 128)
             b_off[i] = ok ? (unsigned)((n * SL + lslot) * VE * esz) : GVFI_DMA_OOB;
         else
@@ -207,8 +209,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             bufdma16((a_mask[i] & st_tapbit) ? off : GVFI_DMA_OOB, st_srd_a, st_sa + ((i * NW + wave) * RPI) * RB);
         } else if (pc < NPIECE) {
             const int i = pc - A_INSTR;
-            if (B_TOTAL % NW != 0 && (i * NW + wave) >= B_TOTAL) return;
-            bufdma16(b_off[i], st_srd_b, st_sa + BM * RB + ((i * NW + wave) * RPI) * RB);
+            bufdma16(b_off[i], st_srd_b, st_sa + BM * RB + (((i * NW + wave) % B_TOTAL) * RPI) * RB);
         }
     };
 
@@ -398,8 +399,12 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     } else if (tile == 128 && k == 64 && bm == 256) {
         ns = 3;      // 256 x 128, 4 waves, 72 KiB: two workgroups per CU (one's epilogue overlaps the other's K loop)
     } else {
+        // narrow tiles do little MFMA work per chunk (2-8 per wave): the DMA round trip, not the matrix pipe, sets
+        // the pace, so they take the deepest ring that keeps >= 2 workgroups per CU
         bm = 128;
-        ns = (k == 64 && tile >= 64) ? 4 : 2;
+        if (k == 64) ns = (tile >= 64 || ns == 4) ? 4 : 2;
+        else if (tile == 64) ns = ns == 3 ? 3 : 2;
+        else ns = (ns >= 2 && ns <= 4) ? ns : 2;
     }
     plan[0] = 2;
     plan[1] = bm;
@@ -434,12 +439,18 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
             if (ns == 3) return launch_glds<TT, 128, 128, 2, 2, 128, 3>(p, st);                               \
             return launch_glds<TT, 128, 128, 2, 2, 128, 4>(p, st);                                            \
         }                                                                                                     \
-        if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                 \
+        if (tile == 64) {                                                                                     \
+            if (ns == 3) return launch_glds<TT, 128, 64, 2, 2, 128, 3>(p, st);                                \
+            return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                             \
+        }                                                                                                     \
+        if (ns == 3) return launch_glds<TT, 128, 32, 4, 1, 128, 3>(p, st);                                    \
+        if (ns == 4) return launch_glds<TT, 128, 32, 4, 1, 128, 4>(p, st);                                    \
         return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);                                                 \
     }                                                                                                         \
     if (tile == 128 && bm == 256) return launch_glds<TT, 256, 128, 2, 2, 64, 3>(p, st);                       \
     if (tile == 128) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
     if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                      \
+    if (ns == 4) return launch_glds<TT, 128, 32, 4, 1, 64, 4>(p, st);                                         \
     return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }
     GLDS_DISPATCH(bf16_t)

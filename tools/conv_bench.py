@@ -27,6 +27,7 @@ SHAPES = [
     ("fnet 96->96 3x3 @64x112 B16", 16, 64, 112, 96, 96, 3, 3, None),
     ("final.up 32->64 3x3 @256x448 B16", 16, 256, 448, 32, 64, 3, 3, None),
     ("final.head 256->24 3x3 @256x448 B8", 8, 256, 448, 256, 24, 3, 3, None),
+    ("raft fh2 256->2 3x3 @32x56 B16", 16, 32, 56, 256, 2, 3, 3, None),
 ]
 
 
@@ -55,6 +56,10 @@ def main():
             variants = tuple((2 + 16 * ns, 128 | (bm << 10)) for bm in (128, 64) for ns in (2, 3, 4))
         if os.environ.get("T256x128"):
             variants = ((2, 256), (2 + 128, 128 | (256 << 10)), (2 + 128, 128 | (128 << 10)), (2, 128 | (128 << 10)))
+        if os.environ.get("ABLATE0"):   # prologue / K loop / epilogue split on the auto tile
+            variants = tuple((2 + 256 * m, 0) for m in (0, 8, 16, 24, 32))
+        if os.environ.get("RING"):      # ring depth sweep on the narrow tiles
+            variants = tuple((2 + 16 * ns, 0) for ns in (2, 3, 4))
         if os.environ.get("BN64"):
             variants = ((2, 128 | (128 << 10)), (2, 64), (2, 32))
         if os.environ.get("ONLY256"):     # single variant for PMC passes
