@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=448)
+    ap.add_argument("--ds", type=float, default=1.0, help="DS_SCALE of the reference CLI (flow estimated at ds x resolution)")
+    ap.add_argument("--n-interp", type=int, default=2, help="N of 'Nx interpolation': N-1 frames per pair (t = i/N)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default=None, help="write a per-conv-shape time table (markdown) to this path")
@@ -60,17 +62,21 @@ def main():
     model.load_state_dict(random_state_dict(0), strict=True)
     model = model.to(dev).eval()
     x = synthetic_pairs(B, H, W, seed=100 + rank).to(dev)
-    coords = [(model.sample_coord_input(B, (H, W), [0.5], device=dev), None)]
-    ts = [0.5 * torch.ones(B, device=dev)]
+    # src/video_Nx.py:164-181: one coordinate grid / timestep per inserted frame, flow at ds x resolution
+    NI = args.n_interp
+    ds = None if args.ds == 1.0 else args.ds
+    coords = [(model.sample_coord_input(B, (H, W), [i / NI], device=dev, upsample_ratio=args.ds), None) for i in range(1, NI)]
+    ts = [(i / NI) * torch.ones(B, device=dev) for i in range(1, NI)]
     eng = model.engine(dev)
     rt = eng.rt
     gather_buf = None
     if world > 1 and rank == 0:
-        gather_buf = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
+        shp = (B, H, W, 3) if NI == 2 else (B, NI - 1, H, W, 3)
+        gather_buf = [torch.empty(shp, dtype=torch.uint8, device=dev) for _ in range(world)]
 
     def step():
-        out = model(x, coords, t=ts)
-        frames = rt.frames_to_u8(out["imgt_pred"][0])
+        out = model(x, coords, t=ts, ds_factor=ds)
+        frames = rt.frames_to_u8(out["imgt_pred"][0]) if NI == 2 else torch.stack([rt.frames_to_u8(f) for f in out["imgt_pred"]], 1)
         if world > 1:
             dist.gather(frames, gather_buf, dst=0)   # the path's only collective: result gather to rank 0
         return frames
@@ -97,7 +103,7 @@ def main():
         rt.ev_shapes = bool(args.shapes)
         ev_steps = max(1, min(args.steps, 3))
         for _ in range(ev_steps):
-            model(x, coords, t=ts)
+            model(x, coords, t=ts, ds_factor=ds)
         torch.cuda.synchronize()
         rt.ev_log = None
     if world > 1:
@@ -106,7 +112,7 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        frames = world * B * args.steps       # one interpolated frame per pair per step (t = 0.5)
+        frames = world * B * (NI - 1) * args.steps       # N-1 interpolated frames per pair per step
         value = frames / dt
         # ---- roofline of the dominant kernel from the event log of the timed steps
         agg = {}
@@ -136,7 +142,7 @@ def main():
         # MI355X_MICROARCH.md + WRITE_SIZE), valid for the default workload's 256->256 3x3 layer only
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r1_hotconv_pmc_hbm.json")
-        if os.path.isfile(pmc_path) and tag.startswith("conv_igemm_glds_kernel<bf16,256,256") and (B, H, W) == (8, 256, 448):
+        if os.path.isfile(pmc_path) and tag.startswith("conv_igemm_glds_kernel<bf16,256,256") and (B, H, W, NI, ds) == (8, 256, 448, 2, None):
             traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]
         roofline = {
             "bound": "mfma", "kernel": tag, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -155,7 +161,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"GIMM-VFI-R {W}x{H} batch={B} pairs/GPU, t=0.5, DS_SCALE=1, seeded random-init weights",
+            "config": {"workload": f"GIMM-VFI-R {W}x{H} batch={B} pairs/GPU, {NI}x interpolation (t=i/{NI}), DS_SCALE={args.ds:g}, "
+                                   "seeded random-init weights",
                        "pairs_per_step_per_gpu": B, "raft_iters": 20, "parallelism": f"pair-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

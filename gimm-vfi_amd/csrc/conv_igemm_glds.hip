@@ -390,11 +390,13 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     else if (p.w_layout != 0) return -5;
     if (tile == 256) { bm = 256; ns = k == 64 ? 4 : 2; }
     else if (tile == 128 && k == 128) {
-        // 64-row tiles / deeper rings are selectable for A/B runs (tools/conv_bench.py SMALLM=1); measured on the
-        // small-M RAFT shapes they do not beat 128 rows x 2 stages (2 workgroups per CU), which stays the default
-        if (bm == 0) bm = 128;
+        // 128 rows x 2 stages (2 workgroups per CU) is the default; when that grid would not even give every CU one
+        // workgroup (RAFT at 1/8 resolution with Cout <= 128: 224 tiles) 64-row tiles double the workgroups
+        // (measured +10-15 % there, -10-20 % on larger grids; tools/conv_bench.py SMALLM=1)
+        const long long blocks128 = (M + 127) / 128 * ((p.Cout + 127) / 128) * (p.groups > 0 ? p.groups : 1);
+        if (bm == 0) bm = blocks128 <= 256 ? 64 : 128;
         bm = bm <= 64 ? 64 : 128;
-        if (ns == 0) ns = bm == 64 ? 3 : 2;
+        if (ns == 0) ns = 2;
         ns = ns < 2 ? 2 : (ns > 4 ? 4 : ns);
     } else if (tile == 128 && k == 64 && bm == 256) {
         ns = 3;      // 256 x 128, 4 waves, 72 KiB: two workgroups per CU (one's epilogue overlaps the other's K loop)

@@ -105,6 +105,27 @@ def test_full_size_properties_bf16_vs_fp32_and_batch_consistency(sd):
     assert o32["flowt"][0].shape == (B, 2, H, W) and one["flowt"][0].shape == (2, H, W)
 
 
+def test_2k_ds_half_8x_properties(sd):
+    """BASELINE.json configs[2] shape: one 2K pair (2048x1024), DS_SCALE = 0.5, 8x interpolation (7 timesteps).
+    Size-independent properties: every frame finite, bf16 vs fp32-mode PSNR >= 40 dB per timestep, flows at the
+    down-scaled working resolution."""
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    B, H, W, N = 1, 1024, 2048, 8
+    x = synthetic_pairs(B, H, W, seed=7)
+    coords = [(orc.sample_coord_input(B, (H, W), [i / N], 0.5), None) for i in range(1, N)]
+    ts = [(i / N) * torch.ones(B) for i in range(1, N)]
+    m32, m16 = _model(sd, "fp32"), _model(sd, "bf16")
+    o16 = _run(m16, x, coords, ts, ds=0.5)
+    o32 = _run(m32, x, coords, ts, ds=0.5)
+    assert len(o16["imgt_pred"]) == N - 1
+    for i in range(N - 1):
+        f16, f32 = o16["imgt_pred"][i].float().cpu(), o32["imgt_pred"][i].float().cpu()
+        assert f16.shape == (B, 3, H, W) and torch.isfinite(f16).all()
+        assert psnr(f16, f32) >= 40.0, (i, psnr(f16, f32))
+        assert o16["flowt"][i].shape[-2:] == (H // 2, W // 2)
+
+
 def test_cli_video_Nx_random_init(tmp_path, sd):
     """Drop-in CLI (src/video_Nx.py flags) end to end on synthetic PNG frames (non-/32 size -> padder)."""
     import os
