@@ -213,6 +213,28 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         }
     };
 
+    // this thread's epilogue channel group is fixed (NT % GROUPS_PER_ROW == 0): its bias / PReLU slopes are loaded once.
+    // 4-wave tiles have registers to spare, so they fetch them HERE, before the K loop (a dependent ~1.5 us global
+    // load chain otherwise sits between the last MFMA and the first store of every small RAFT convolution)
+    constexpr int NT = 64 * NW;
+    constexpr int GROUPS_PER_ROW = BN / 8;
+    static_assert(NT % GROUPS_PER_ROW == 0, "group index must be loop invariant");
+    constexpr bool GC_EARLY = NW <= 4;
+    const int my_cg = tid % GROUPS_PER_ROW;
+    const int my_cout0 = n0 + my_cg * 8;
+    const int my_valid = (p.Cout - my_cout0) >= 8 ? 8 : (p.Cout - my_cout0 > 0 ? p.Cout - my_cout0 : 0);
+    GroupConst gc;
+    auto load_gc = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = e < my_valid;
+            gc.bias[e] = (ok && p.bias) ? p.bias[my_cout0 + e] : 0.f;
+            gc.s1[e] = (ok && p.act1 == GVFI_ACT_PRELU) ? p.slope1[my_cout0 + e] : 0.f;
+            gc.s2[e] = (ok && p.act2 == GVFI_ACT_PRELU) ? p.slope2[my_cout0 + e] : 0.f;
+        }
+    };
+    if (GC_EARLY) load_gc();
+
     // ---- prologue: fill the ring with chunks 0 .. AHEAD-1
 #pragma unroll
     for (int q = 0; q < AHEAD; ++q) {
@@ -276,11 +298,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 
     if (a.dbg & 8) return;   // profiling only: skip the epilogue
     // ---------------------------------------------------------------- epilogue through LDS (see above)
-    constexpr int NT = 64 * NW;
     constexpr int PASS_ROWS_RAW = (NSTAGE * STAGE / 4) / BN;
     constexpr int PASS_ROWS = PASS_ROWS_RAW >= BM ? BM : (PASS_ROWS_RAW / 32) * 32;
     constexpr int NPASS = (BM + PASS_ROWS - 1) / PASS_ROWS;
-    constexpr int GROUPS_PER_ROW = BN / 8;
     float* cs = (float*)smem;
     const int eY = p.y_f32 ? 4 : (int)sizeof(T);
     // vector path needs 16-byte aligned rows on every tensor the epilogue touches
@@ -288,19 +308,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                          vec_ok(p.y2, p.ldy2, (int)sizeof(T)) && vec_ok(p.aux0, p.lda0, (int)sizeof(T)) &&
                          vec_ok(p.aux1, p.lda1, (int)sizeof(T)) &&
                          (p.bias == nullptr || true);
-    // this thread's channel group is fixed across the loop (NT % GROUPS_PER_ROW == 0): preload its constants
-    static_assert(NT % GROUPS_PER_ROW == 0, "group index must be loop invariant");
-    const int my_cg = tid % GROUPS_PER_ROW;
-    const int my_cout0 = n0 + my_cg * 8;
-    const int my_valid = (p.Cout - my_cout0) >= 8 ? 8 : (p.Cout - my_cout0 > 0 ? p.Cout - my_cout0 : 0);
-    GroupConst gc;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const bool ok = e < my_valid;
-        gc.bias[e] = (ok && p.bias) ? p.bias[my_cout0 + e] : 0.f;
-        gc.s1[e] = (ok && p.act1 == GVFI_ACT_PRELU) ? p.slope1[my_cout0 + e] : 0.f;
-        gc.s2[e] = (ok && p.act2 == GVFI_ACT_PRELU) ? p.slope2[my_cout0 + e] : 0.f;
-    }
+    if (!GC_EARLY) load_gc();
     __syncthreads();   // every wave is done reading the last staged chunk
 #pragma unroll 1
     for (int ps = 0; ps < NPASS; ++ps) {
