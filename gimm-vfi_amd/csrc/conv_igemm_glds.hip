@@ -75,13 +75,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     if (v >= a.MT * a.NT) return;
     const int mt = v / a.NT, nt = v - mt * a.NT;
     const int g = blockIdx.z;
-#ifndef GVFI_HOSTSIM
-    if ((a.dbg & 64) && bid < 256) {   // experiment: de-phase the CUs so their store bursts do not coincide
-        for (int i = 0; i < ((bid * 37) & 63); ++i) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
 
     const int tid = threadIdx.x;
+    // profiling only (algo bit 8+7): wave 0 of every workgroup stamps s_memtime at the phase boundaries into
+    // aux1[bid*8 + k] (k: 0 start, 1 prologue done, 2 first chunk landed, 3 K loop done, 4 staged, 5 stores issued)
+    auto stamp = [&](int k) {
+#ifndef GVFI_HOSTSIM
+        if ((a.dbg & 128) && tid == 0) ((unsigned long long*)p.aux1)[(long long)bid * 8 + k] = __builtin_readcyclecounter();
+#endif
+    };
+    stamp(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> SGPR (M0 bases)
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -229,8 +232,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         for (int e = 0; e < 8; ++e) {
             const bool ok = e < my_valid;
             gc.bias[e] = (ok && p.bias) ? p.bias[my_cout0 + e] : 0.f;
-            gc.s1[e] = (ok && p.act1 == GVFI_ACT_PRELU) ? p.slope1[my_cout0 + e] : 0.f;
-            gc.s2[e] = (ok && p.act2 == GVFI_ACT_PRELU) ? p.slope2[my_cout0 + e] : 0.f;
+            // negative-side slope of the none / ReLU / LeakyReLU / PReLU family: act(v) = max(v,0) + s * min(v,0)
+            // (exact for every member: s = 1, 0, 0.1, slope[c]); the generic path reads it for PReLU only
+            gc.s1[e] = p.act1 == GVFI_ACT_PRELU ? (ok ? p.slope1[my_cout0 + e] : 0.f)
+                                                : (p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f));
+            gc.s2[e] = p.act2 == GVFI_ACT_PRELU ? (ok ? p.slope2[my_cout0 + e] : 0.f)
+                                                : (p.act2 == GVFI_ACT_NONE ? 1.f : (p.act2 == GVFI_ACT_LRELU ? 0.1f : 0.f));
         }
     };
     if (GC_EARLY) load_gc();
@@ -283,10 +290,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     // Steady state: chunk kt must have landed while the AHEAD-1 younger chunks stay in flight (LDS-DMA issue->landed
     // is ~1 us, longer than the MFMAs of one chunk).  vmcnt retires in order and every wave issues exactly NPIECE DMAs
     // per chunk, so (AHEAD-1)*NPIECE is the count to wait for.  The last AHEAD chunks are drained without prefetch.
+    stamp(1);
     int kt = (a.dbg & 16) ? a.KT : 0;   // profiling only: skip the K loop
     for (; kt + AHEAD < a.KT; ++kt) {
         glds_wait_n<(AHEAD - 1) * NPIECE>();
         __syncthreads();    // chunk kt visible to every wave; every wave is done reading chunk kt-1's buffer
+        if (kt == 0) stamp(2);
         stage_begin(kt + AHEAD);   // goes into the buffer chunk kt-1 occupied
         compute(kt, std::true_type{});
     }
@@ -296,11 +305,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         compute(kt, std::false_type{});
     }
 
+    stamp(3);
     if (a.dbg & 8) return;   // profiling only: skip the epilogue
     // ---------------------------------------------------------------- epilogue through LDS (see above)
+    // the fp32 C tile is staged in NPASS passes of PASS_ROWS rows; in every pass EACH wave stages 1/NPASS of its
+    // accumulator blocks, so no wave carries all its accumulators through a whole store loop (register pressure of
+    // the 8-wave tile); staged row lr of pass ps <-> tile row tile_row(ps, lr)
     constexpr int PASS_ROWS_RAW = (NSTAGE * STAGE / 4) / BN;
-    constexpr int PASS_ROWS = PASS_ROWS_RAW >= BM ? BM : (PASS_ROWS_RAW / 32) * 32;
-    constexpr int NPASS = (BM + PASS_ROWS - 1) / PASS_ROWS;
+    constexpr int NPASS = PASS_ROWS_RAW >= BM ? 1 : 2;
+    constexpr int PASS_ROWS = BM / NPASS;
+    constexpr int IPP = MI / NPASS;                // 32-row accumulator blocks per wave and pass
+    static_assert(MI % NPASS == 0 && PASS_ROWS <= PASS_ROWS_RAW, "epilogue staging does not fit");
+    auto tile_row = [&](int ps, int lr) { return (lr / (IPP * 32)) * WM + ps * IPP * 32 + (lr % (IPP * 32)); };
     float* cs = (float*)smem;
     const int eY = p.y_f32 ? 4 : (int)sizeof(T);
     // vector path needs 16-byte aligned rows on every tensor the epilogue touches
@@ -309,29 +325,106 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                          vec_ok(p.aux1, p.lda1, (int)sizeof(T)) &&
                          (p.bias == nullptr || true);
     if (!GC_EARLY) load_gc();
+#ifndef GVFI_HOSTSIM
+    // Make the compiler wait for the bias / slope loads HERE.  Their first real use is inside the store loop; the
+    // s_waitcnt vmcnt(0) it would put there also waits, in every iteration, for the previous iteration's global
+    // store to be acknowledged (stores share the counter): ~1500 cycles x 8-16 iterations per tile, 15 % of the
+    // hot convolution and a quarter of a small RAFT one (tools/conv_timeline.py).
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(gc.bias[e]), "v"(gc.s1[e]), "v"(gc.s2[e]));
+#endif
+    const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && my_valid == 8 && !p.y_f32 &&
+                      !(p.res && p.res_f32) && p.act1 <= GVFI_ACT_PRELU && p.act2 <= GVFI_ACT_PRELU;
     __syncthreads();   // every wave is done reading the last staged chunk
-#pragma unroll 1
+#pragma unroll   // at most 2 passes; unrolled so that a pass's staged accumulators are dead registers afterwards
     for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int row0 = wm * WM + i * 32;
-            if (row0 / PASS_ROWS != ps) continue;
+            if (i / IPP != ps) continue;
+            const int lrow0 = wm * (IPP * 32) + (i - ps * IPP) * 32;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int col = wn * WN + j * 32 + frow;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 - ps * PASS_ROWS + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    const int row = lrow0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                     cs[row * BN + col] = acc[i][j][r];
                 }
             }
         }
         __syncthreads();
+        if (ps == 0) stamp(4);
+        if (fast) {
+            // ---- slim store loop of the common case (bf16 in/out, bias, none/ReLU/LeakyReLU/PReLU, optional bf16
+            // residual + second activation, scale): ~40 VALU instructions per 8 channels instead of the ~150 of the
+            // generic body below, which had made the epilogue VALU-issue bound (10 k cycles per 128x128 tile)
+            constexpr int ITERS = (PASS_ROWS * GROUPS_PER_ROW) / NT;
+            static_assert((PASS_ROWS * GROUPS_PER_ROW) % NT == 0, "whole iterations");
+            constexpr int ROWS_PER_IT = NT / GROUPS_PER_ROW;
+            const int row_a = tid / GROUPS_PER_ROW;       // staged row of iteration 0; iteration it adds it * ROWS_PER_IT
+            const long long pix0 = (long long)g * a.Mg + m_tile0;
+            bf16_t* yp = (bf16_t*)p.y + pix0 * p.ldy + my_cout0;
+            const bf16_t* rp = (const bf16_t*)p.res + pix0 * p.ldr + my_cout0;
+            const float* cp = cs + row_a * BN + my_cg * 8;
+            const bool has_res = p.res != nullptr, has_a2 = p.act2 != GVFI_ACT_NONE, has_sc = p.out_scale != 1.0f;
+            // residual vectors are fetched PF iterations at a time, all in flight together (the 8-wave tile, still
+            // holding the other pass's accumulators, only has registers for 4)
+            constexpr int PF = NT > 256 ? (ITERS < 4 ? ITERS : 4) : ITERS;
+            static_assert(ITERS % PF == 0, "prefetch chunks");
+#pragma unroll
+            for (int c = 0; c < ITERS / PF; ++c) {
+                uint4 rpre[PF];
+                if (has_res) {
+#pragma unroll
+                    for (int q = 0; q < PF; ++q) {
+                        const int it = c * PF + q;
+                        const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
+                        if (m_tile0 + tr < a.Mg) rpre[q] = *(const uint4*)(rp + (long long)tr * p.ldr);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const int it = c * PF + q;
+                    const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
+                    if (m_tile0 + tr >= a.Mg) continue;
+                    const float4 c0 = *(const float4*)(cp + it * ROWS_PER_IT * BN);
+                    const float4 c1 = *(const float4*)(cp + it * ROWS_PER_IT * BN + 4);
+                    float vv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = vv[e] + gc.bias[e];
+                        vv[e] = fmaxf(t, 0.f) + gc.s1[e] * fminf(t, 0.f);
+                    }
+                    if (has_res) {
+                        float r[8];
+                        unpack_bf16x8(rpre[q], r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vv[e] += r[e];
+                    }
+                    if (has_a2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vv[e] = fmaxf(vv[e], 0.f) + gc.s2[e] * fminf(vv[e], 0.f);
+                    }
+                    if (has_sc) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vv[e] *= p.out_scale;
+                    }
+                    uint4 u;
+                    u.x = pack_bf16x2(vv[0], vv[1]);
+                    u.y = pack_bf16x2(vv[2], vv[3]);
+                    u.z = pack_bf16x2(vv[4], vv[5]);
+                    u.w = pack_bf16x2(vv[6], vv[7]);
+                    *(uint4*)(yp + (long long)tr * p.ldy) = u;
+                }
+            }
+            if (ps + 1 < NPASS) __syncthreads();
+            continue;
+        }
 #pragma unroll 1
         for (int idx = tid; idx < PASS_ROWS * GROUPS_PER_ROW; idx += NT) {
             const int row = idx / GROUPS_PER_ROW;
             const int cg = my_cg;
-            const long long m = m_tile0 + (long long)ps * PASS_ROWS + row;
+            const long long m = m_tile0 + tile_row(ps, row);
             const int cout0 = my_cout0;
             if (m >= a.Mg || my_valid == 0) continue;
             const int n_valid = my_valid;
@@ -339,11 +432,17 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             const float4 c0 = *(const float4*)(cs + row * BN + cg * 8);
             const float4 c1 = *(const float4*)(cs + row * BN + cg * 8 + 4);
             vv[0] = c0.x; vv[1] = c0.y; vv[2] = c0.z; vv[3] = c0.w; vv[4] = c1.x; vv[5] = c1.y; vv[6] = c1.z; vv[7] = c1.w;
-            if ((a.dbg & 32) && vv[0] != 12345.678f) continue;   // profiling only: LDS staging without math / stores
             epilogue_group<T>(p, gc, vv, cout0, n_valid, (long long)g * a.Mg + m, vec_all && n_valid == 8);
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
+    stamp(5);
+#ifndef GVFI_HOSTSIM
+    if (a.dbg & 128) {   // profiling only: time until this wave's stores are acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(6);
+    }
+#endif
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE>

@@ -143,6 +143,12 @@ __device__ __forceinline__ void st8(void* base, long long idx, int is_f32, bool 
         *(uint4*)((bf16_t*)base + idx) = u;
     }
 }
+__device__ __forceinline__ void unpack_bf16x8(const uint4& u, float (&o)[8]) {
+    o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16));
+    o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
+    o[4] = bf2f((bf16_t)(u.z & 0xffff)); o[5] = bf2f((bf16_t)(u.z >> 16));
+    o[6] = bf2f((bf16_t)(u.w & 0xffff)); o[7] = bf2f((bf16_t)(u.w >> 16));
+}
 __device__ __forceinline__ bool vec_ok(const void* ptr, int ld, int elem_bytes) {
     return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && ((ld * elem_bytes) & 15) == 0);
 }
