@@ -335,6 +335,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 #endif
     const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && my_valid == 8 && !p.y_f32 &&
                       !(p.res && p.res_f32) && p.act1 <= GVFI_ACT_PRELU && p.act2 <= GVFI_ACT_PRELU;
+    // (the 8-wave tile is never used for the GRU convolutions and has no registers for their operands)
+    const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8;
     __syncthreads();   // every wave is done reading the last staged chunk
 #pragma unroll   // at most 2 passes; unrolled so that a pass's staged accumulators are dead registers afterwards
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -416,6 +418,59 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                     u.w = pack_bf16x2(vv[6], vv[7]);
                     *(uint4*)(yp + (long long)tr * p.ldy) = u;
                 }
+            }
+            if (ps + 1 < NPASS) __syncthreads();
+            continue;
+        }
+        if (fast_gru) {
+            // ---- slim ConvGRU store loops (raft/update.py:58-73): z / r gates and the h update, state operands of
+            // the whole pass prefetched, hardware exp / rcp
+            constexpr int ITERS = (PASS_ROWS * GROUPS_PER_ROW) / NT;
+            constexpr int ROWS_PER_IT = NT / GROUPS_PER_ROW;
+            const int row_a = tid / GROUPS_PER_ROW;
+            const long long pix0 = (long long)g * a.Mg + m_tile0;
+            const bool is_q = p.epi_mode == GVFI_EPI_GRU_Q;
+            const int half = p.Cout >> 1;
+            const bool zhalf = !is_q && my_cout0 < half;
+            const int c0 = (is_q || zhalf) ? my_cout0 : my_cout0 - half;
+            bf16_t* yp = (zhalf || is_q ? (bf16_t*)p.y + pix0 * p.ldy : (bf16_t*)p.y2 + pix0 * p.ldy2) + c0;
+            const int ldo = (zhalf || is_q) ? p.ldy : p.ldy2;
+            const bf16_t* hp = (const bf16_t*)p.aux0 + pix0 * p.lda0 + c0;
+            const bf16_t* zp = (const bf16_t*)p.aux1 + pix0 * p.lda1 + c0;
+            const float* cp = cs + row_a * BN + my_cg * 8;
+            uint4 hpre[ITERS], zpre[ITERS];
+            if (!zhalf) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
+                    if (m_tile0 + tr < a.Mg) {
+                        hpre[it] = *(const uint4*)(hp + (long long)tr * p.lda0);
+                        if (is_q) zpre[it] = *(const uint4*)(zp + (long long)tr * p.lda1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
+                if (m_tile0 + tr >= a.Mg) continue;
+                const float4 c0v = *(const float4*)(cp + it * ROWS_PER_IT * BN);
+                const float4 c1v = *(const float4*)(cp + it * ROWS_PER_IT * BN + 4);
+                float vv[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
+                float hh[8], zz[8];
+                if (!zhalf) unpack_bf16x8(hpre[it], hh);
+                if (is_q) unpack_bf16x8(zpre[it], zz);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = vv[e] + gc.bias[e];
+                    if (is_q) vv[e] = (1.f - zz[e]) * hh[e] + zz[e] * fast_tanh(t);
+                    else vv[e] = zhalf ? fast_sigmoid(t) : fast_sigmoid(t) * hh[e];
+                }
+                uint4 u;
+                u.x = pack_bf16x2(vv[0], vv[1]);
+                u.y = pack_bf16x2(vv[2], vv[3]);
+                u.z = pack_bf16x2(vv[4], vv[5]);
+                u.w = pack_bf16x2(vv[6], vv[7]);
+                *(uint4*)(yp + (long long)tr * ldo) = u;
             }
             if (ps + 1 < NPASS) __syncthreads();
             continue;

@@ -143,6 +143,19 @@ __device__ __forceinline__ void st8(void* base, long long idx, int is_f32, bool 
         *(uint4*)((bf16_t*)base + idx) = u;
     }
 }
+// hardware-rate sigmoid / tanh for the bf16 path (v_exp_f32 + v_rcp_f32, ~1 ulp each: far inside bf16 rounding);
+// the fp32 validation mode keeps expf / tanhf
+#ifndef GVFI_HOSTSIM
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
+}
+#else
+static inline float fast_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+static inline float fast_tanh(float x) { return tanhf(x); }
+#endif
 __device__ __forceinline__ void unpack_bf16x8(const uint4& u, float (&o)[8]) {
     o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16));
     o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
