@@ -292,6 +292,63 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     // per chunk, so (AHEAD-1)*NPIECE is the count to wait for.  The last AHEAD chunks are drained without prefetch.
     stamp(1);
     int kt = (a.dbg & 16) ? a.KT : 0;   // profiling only: skip the K loop
+    if constexpr (NSTAGE == 2 && KK >= 2 && NW >= 8) {
+        // ---- (8-wave tile only: with 2-3 resident 4-wave workgroups another workgroup fills the bubble and the shorter
+        // DMA slack of this schedule costs 5-10 %)  two-buffer ring, software-pipelined across chunks: the barrier that publishes chunk kt+1 sits INSIDE the
+        // MFMA stream of chunk kt -- after it every wave issues the first fragment reads of chunk kt+1 and then still
+        // has the last k-step of chunk kt to feed the matrix pipe, so the LDS round trip that used to follow every
+        // barrier (all 8 waves idle, ~10 % of a K step) is covered.
+        //   hazards: the DMA of chunk kt+1 (into the buffer of chunk kt-1) is issued after the barrier of the previous
+        //   iteration, which every wave passes only with all its reads of that buffer complete (__syncthreads waits
+        //   lgkmcnt(0)); chunk kt+1 is read only after vmcnt(0) + that same barrier.
+        uint4 fa[2][MI], fb[2][NI];
+        auto load_frags = [&](const unsigned char* sa, int kk, int buf) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[buf][i] = *(const uint4*)(sa + a_rd[kk] + i * 32 * RB);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[buf][j] = *(const uint4*)(sa + b_rd[kk] + j * 32 * RB);
+        };
+        if (kt < a.KT) {
+            glds_wait_n<0>();
+            __syncthreads();          // chunk 0 visible
+            stamp(2);
+            load_frags(smem, 0, 0);
+        }
+        for (; kt < a.KT; ++kt) {
+            const bool has_next = kt + 1 < a.KT;
+            const unsigned char* sa = smem + (kt & 1) * STAGE;
+            if (has_next) stage_begin(kt + 1);
+#pragma unroll
+            for (int kk = 0; kk + 1 < KK; ++kk) {
+                load_frags(sa, kk + 1, (kk + 1) & 1);
+                GVFI_SCHED_BARRIER();
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+                    if (has_next) {   // all DMA pieces of chunk kt+1 go out before the barrier below
+                        constexpr int NSLOT = (KK - 1) * MI;
+                        const int slot_id = kk * MI + i;
+#pragma unroll
+                        for (int pc = 0; pc < NPIECE; ++pc)
+                            if (pc % NSLOT == slot_id) stage_piece(pc);
+                    }
+                }
+                GVFI_SCHED_BARRIER();
+            }
+            if (has_next) {
+                glds_wait_n<0>();
+                __syncthreads();      // chunk kt+1 visible; every wave's reads of chunk kt are complete
+                load_frags(smem + ((kt + 1) & 1) * STAGE, 0, KK & 1);
+                GVFI_SCHED_BARRIER();
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[(KK - 1) & 1][i], fb[(KK - 1) & 1][j]);
+            GVFI_SCHED_BARRIER();
+        }
+    } else {
     for (; kt + AHEAD < a.KT; ++kt) {
         glds_wait_n<(AHEAD - 1) * NPIECE>();
         __syncthreads();    // chunk kt visible to every wave; every wave is done reading chunk kt-1's buffer
@@ -303,6 +360,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         glds_wait_n<0>();
         __syncthreads();
         compute(kt, std::false_type{});
+    }
     }
 
     stamp(3);
