@@ -133,17 +133,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         const int koff = (lslot ^ swz(row)) * VE;
         a_off0[i] = (unsigned)(dpix * p.ld0 + koff) * esz;
         a_off1[i] = (unsigned)(dpix * p.ld1 + koff) * esz;
-        // bit t of the mask = filter tap t reads inside the image for this output pixel
-        unsigned mask = 0, bit = 1;
-        for (int th = 0; th < p.KH; ++th) {
-            const bool yin = (unsigned)(iy0 + th) < (unsigned)p.H;
-            for (int tw = 0; tw < p.KW; ++tw) {
-                if (yin && (unsigned)(ix0 + tw) < (unsigned)p.W) mask |= bit;
-                bit <<= 1;
-            }
-        }
+        // bit t of the mask = filter tap t reads inside the image for this output pixel (separable: KH + KW tests)
+        unsigned xbits = 0, mask = 0;
+        for (int tw = 0; tw < p.KW; ++tw)
+            if ((unsigned)(ix0 + tw) < (unsigned)p.W) xbits |= 1u << tw;
+        for (int th = 0; th < p.KH; ++th)
+            if ((unsigned)(iy0 + th) < (unsigned)p.H) mask |= xbits << (th * p.KW);
         a_mask[i] = ok ? mask : 0u;
     }
+    stamp(7);   // (profiling) per-row decode + tap masks done
     unsigned b_off[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
@@ -228,20 +226,24 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     const int my_valid = (p.Cout - my_cout0) >= 8 ? 8 : (p.Cout - my_cout0 > 0 ? p.Cout - my_cout0 : 0);
     GroupConst gc;
     auto load_gc = [&]() {
+        // negative-side slope of the none / ReLU / LeakyReLU / PReLU family: act(v) = max(v,0) + s * min(v,0)
+        // (exact for every member: s = 1, 0, 0.1, slope[c]); the generic path reads it for PReLU only
+        const float f1 = p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f);
+        const float f2 = p.act2 == GVFI_ACT_NONE ? 1.f : (p.act2 == GVFI_ACT_LRELU ? 0.1f : 0.f);
+        auto ld8f = [&](const float* src, float fill, float (&dst)[8]) {
+            if (src != nullptr && my_valid == 8) {   // two 16-byte loads (cout0 is a multiple of 8 floats)
+                const float4 lo = *(const float4*)(src + my_cout0), hi = *(const float4*)(src + my_cout0 + 4);
+                dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w;
+                dst[4] = hi.x; dst[5] = hi.y; dst[6] = hi.z; dst[7] = hi.w;
+            } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool ok = e < my_valid;
-            gc.bias[e] = (ok && p.bias) ? p.bias[my_cout0 + e] : 0.f;
-            // negative-side slope of the none / ReLU / LeakyReLU / PReLU family: act(v) = max(v,0) + s * min(v,0)
-            // (exact for every member: s = 1, 0, 0.1, slope[c]); the generic path reads it for PReLU only
-            gc.s1[e] = p.act1 == GVFI_ACT_PRELU ? (ok ? p.slope1[my_cout0 + e] : 0.f)
-                                                : (p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f));
-            gc.s2[e] = p.act2 == GVFI_ACT_PRELU ? (ok ? p.slope2[my_cout0 + e] : 0.f)
-                                                : (p.act2 == GVFI_ACT_NONE ? 1.f : (p.act2 == GVFI_ACT_LRELU ? 0.1f : 0.f));
-        }
+                for (int e = 0; e < 8; ++e) dst[e] = (src != nullptr && e < my_valid) ? src[my_cout0 + e] : fill;
+            }
+        };
+        ld8f(p.bias, 0.f, gc.bias);
+        ld8f(p.act1 == GVFI_ACT_PRELU ? p.slope1 : nullptr, f1, gc.s1);
+        ld8f(p.act2 == GVFI_ACT_PRELU ? p.slope2 : nullptr, f2, gc.s2);
     };
-    if (GC_EARLY) load_gc();
-
     // ---- prologue: fill the ring with chunks 0 .. AHEAD-1
 #pragma unroll
     for (int q = 0; q < AHEAD; ++q) {
@@ -251,6 +253,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc);
         }
     }
+    if (GC_EARLY) load_gc();   // behind the first chunk's DMA, in its shadow
     // MFMAs of chunk kt; when DMA is true the pieces of chunk kt+AHEAD are issued behind the MFMA groups (every wave
     // of the workgroup is at the same point after the barrier; a burst of issues would idle the matrix pipe)
     auto compute = [&](int kt, auto dma_tag) {

@@ -39,6 +39,7 @@ def main():
         us = (s - t0) / 100.0
         names = ["start", "prologue done", "chunk0 landed", "K loop done", "staged", "stores issued", "stores acked"]
         print(f"{name}: {s.shape[0]} workgroups; kernel span {float(us[:, 6].max()):.1f} us")
+        print(f"  (of the prologue: start -> row decode + tap masks done: {float((us[:, 7] - us[:, 0]).mean()):7.2f})")
         for k, nm in enumerate(names):
             col = us[:, k]
             print(f"  {nm:15s} mean {float(col.mean()):7.2f}  min {float(col.min()):7.2f}  max {float(col.max()):7.2f}"
