@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             const bool has_res = p.res != nullptr, has_a2 = p.act2 != GVFI_ACT_NONE, has_sc = p.out_scale != 1.0f;
             // residual vectors are fetched PF iterations at a time, all in flight together (the 8-wave tile, still
             // holding the other pass's accumulators, only has registers for 4)
-            constexpr int PF = NT > 256 ? (ITERS < 4 ? ITERS : 4) : ITERS;
+            constexpr int PF = NT > 256 ? (ITERS < 2 ? ITERS : 2) : ITERS;
             static_assert(ITERS % PF == 0, "prefetch chunks");
 #pragma unroll
             for (int c = 0; c < ITERS / PF; ++c) {
