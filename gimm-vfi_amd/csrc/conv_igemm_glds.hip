@@ -626,10 +626,17 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     } else {
         // narrow tiles do little MFMA work per chunk (2-8 per wave): the DMA round trip, not the matrix pipe, sets
         // the pace, so they take the deepest ring that keeps >= 2 workgroups per CU
-        bm = 128;
-        if (k == 64) ns = (tile >= 64 || ns == 4) ? 4 : 2;
-        else if (tile == 64) ns = ns == 3 ? 3 : 2;
-        else ns = (ns >= 2 && ns <= 4) ? ns : 2;
+        // tall variant (256 rows, waves 4 x 1) selectable with BM = 256: halves the per-tile fixed cost of the
+        // full-resolution small-channel layers
+        if (bm == 0 && tile == 32 && k == 64 && M >= 65536) bm = 256;   // 32-channel full-resolution layers: -34 %
+        if (bm == 256 && tile <= 64 && !(tile == 64 && k == 64)) {
+            ns = 2;
+        } else {
+            bm = 128;
+            if (k == 64) ns = (tile >= 64 || ns == 4) ? 4 : 2;
+            else if (tile == 64) ns = ns == 3 ? 3 : 2;
+            else ns = (ns >= 2 && ns <= 4) ? ns : 2;
+        }
     }
     plan[0] = 2;
     plan[1] = bm;
@@ -664,6 +671,8 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
             if (ns == 3) return launch_glds<TT, 128, 128, 2, 2, 128, 3>(p, st);                               \
             return launch_glds<TT, 128, 128, 2, 2, 128, 4>(p, st);                                            \
         }                                                                                                     \
+        if (tile == 64 && bm == 256) return launch_glds<TT, 256, 64, 4, 1, 128, 2>(p, st);                    \
+        if (tile == 32 && bm == 256) return launch_glds<TT, 256, 32, 4, 1, 128, 2>(p, st);                    \
         if (tile == 64) {                                                                                     \
             if (ns == 3) return launch_glds<TT, 128, 64, 2, 2, 128, 3>(p, st);                                \
             return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                             \
@@ -675,6 +684,7 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (tile == 128 && bm == 256) return launch_glds<TT, 256, 128, 2, 2, 64, 3>(p, st);                       \
     if (tile == 128) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
     if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                      \
+    if (tile == 32 && bm == 256) return launch_glds<TT, 256, 32, 4, 1, 64, 2>(p, st);                         \
     if (ns == 4) return launch_glds<TT, 128, 32, 4, 1, 64, 4>(p, st);                                         \
     return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }

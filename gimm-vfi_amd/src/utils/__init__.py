@@ -1,0 +1,1 @@
+"""Host-side helpers of the reference-shaped package (setup / padding / flow visualisation)."""

@@ -39,6 +39,10 @@ CONV_SHAPES = [
     (2, 64, 112, 128, 128, 3, 3, dict(algo=1, act1=L.ACT_LRELU)),                             # generic kernel on an aligned shape
     (2, 64, 112, 256, 24, 3, 3, dict(out_f32=True)),                                         # decoder head, 128x32 LDS-DMA tile
     (4, 32, 56, 256, 2, 3, 3, dict(out_f32=True, with_res=True)),                             # RAFT flow head
+    (2, 256, 448, 32, 32, 3, 3, dict(act1=L.ACT_LRELU, with_res=True)),                       # auto -> tall 256x32 tile (cnn encoder)
+    (2, 64, 112, 64, 64, 3, 3, dict(tile=64 | (256 << 10), act1=L.ACT_PRELU)),                # tall 256x64 tile
+    (4, 32, 56, 384, 128, 1, 5, dict(split=128, act1=L.ACT_RELU)),                            # auto -> 64-row tiles (224 workgroups)
+    (1, 40, 56, 128, 128, 3, 3, dict(algo=2 + 16 * 3, tile=128 | (128 << 10))),               # 3-deep ring (counted vmcnt)
 ]
 
 

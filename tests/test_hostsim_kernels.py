@@ -37,6 +37,10 @@ CONV_SHAPES = [
     (1, 8, 10, 128, 130, 1, 5, dict(algo=2 + 16 * 2, tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
     (1, 9, 12, 64, 130, 3, 3, dict(algo=2 + 16 * 4, tile=128 | (128 << 10))),
     (1, 17, 19, 32, 100, 3, 3, dict(algo=2 + 128, tile=128 | (256 << 10), act1=L.ACT_LRELU)),
+    # tall 256-row tiles (waves 4 x 1) of the narrow full-resolution layers
+    (1, 18, 20, 32, 32, 3, 3, dict(tile=32 | (256 << 10), act1=L.ACT_LRELU, with_res=True)),
+    (1, 18, 20, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),
+    (1, 18, 20, 64, 64, 3, 3, dict(tile=64 | (256 << 10), act1=L.ACT_PRELU)),
 ]
 
 
