@@ -595,48 +595,41 @@ extern "C" int gvfi_conv2d_glds_eligible(const gvfi_conv_params* pp) {
     return 0;
 }
 
-// One place decides the tile: plan = {algo, BM, BN, KB(bytes), NSTAGE} for an eligible problem (also reported by
-// gvfi_conv2d_plan).  256x256 (8 waves) for Cout >= 192 on large images, else {128,64} x {128, 64, 32} (4 waves);
-// 128-byte K chunks when the channel counts allow it, else 64-byte chunks.  tile_hint = BN | BM << 10 (0 = auto),
-// algo bits 4..6 = ring depth override.
+// One place decides the kernel variant: plan = {algo, BM, BN, KB(bytes), LDS stages} for an eligible problem (also
+// reported by gvfi_conv2d_plan).  tile_hint = BN | BM << 10 (0 = auto).
+//   BN: 256 (8 waves, 256x256) for Cout >= 192 on >= 65536 pixels, else 128 / 64 / 32 (4 waves);
+//   KB: 128-byte K chunks (ring of 2) when the channel counts allow it, else 64-byte chunks (ring of 4; of 2 for BN = 32);
+//   BM: 128, except 64 when a 128-row grid would leave CUs without a workgroup (RAFT at 1/8 resolution, Cout <= 128)
+//       and 256 (waves 4 x 1) for the BN = 32 full-resolution layers (halves their per-tile fixed cost).
+// Variants that were measured and did not pay (3-/4-deep rings at KB = 128, 64-row tiles on larger grids, a 256x128
+// tile with two workgroups per CU, 256x64 and 512x32 tall tiles) are listed in DESIGN.md and no longer instantiated.
 extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     const gvfi_conv_params& p = *pp;
     const int kb = gvfi_conv2d_glds_eligible(pp);
     if (!kb) return -2;
-    const long long M = (long long)p.N * p.Ho * p.Wo / (p.groups > 0 ? p.groups : 1);
-    int tile = p.tile_hint & 1023, bm = p.tile_hint >> 10, ns = (p.algo >> 4) & 7;
+    const int groups = p.groups > 0 ? p.groups : 1;
+    const long long M = (long long)p.N * p.Ho * p.Wo / groups;
+    int tile = p.tile_hint & 1023, bm = p.tile_hint >> 10;
     if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
     tile = tile >= 256 ? 256 : (tile >= 128 ? 128 : (tile >= 64 ? 64 : 32));
-    int k = 64;
+    int k = 64, ns = 2;
     if (tile == 256) k = p.w_layout == 0 ? 64 : 128;
     else if (kb == 128 && !(p.algo & 128)) k = 128;
     else if (p.w_layout != 0) return -5;
-    if (tile == 256) { bm = 256; ns = k == 64 ? 4 : 2; }
-    else if (tile == 128 && k == 128) {
-        // 128 rows x 2 stages (2 workgroups per CU) is the default; when that grid would not even give every CU one
-        // workgroup (RAFT at 1/8 resolution with Cout <= 128: 224 tiles) 64-row tiles double the workgroups
-        // (measured +10-15 % there, -10-20 % on larger grids; tools/conv_bench.py SMALLM=1)
-        const long long blocks128 = (M + 127) / 128 * ((p.Cout + 127) / 128) * (p.groups > 0 ? p.groups : 1);
-        if (bm == 0) bm = blocks128 <= 256 ? 64 : 128;
-        bm = bm <= 64 ? 64 : 128;
-        if (ns == 0) ns = 2;
-        ns = ns < 2 ? 2 : (ns > 4 ? 4 : ns);
-    } else if (tile == 128 && k == 64 && bm == 256) {
-        ns = 3;      // 256 x 128, 4 waves, 72 KiB: two workgroups per CU (one's epilogue overlaps the other's K loop)
+    if (tile == 256) {
+        bm = 256;
+        ns = k == 64 ? 4 : 2;
+    } else if (tile == 128) {
+        const long long blocks128 = (M + 127) / 128 * ((p.Cout + 127) / 128) * groups;
+        if (bm == 0) bm = (k == 128 && blocks128 <= 256) ? 64 : 128;
+        bm = (bm <= 64 && k == 128) ? 64 : 128;
+        ns = k == 64 ? 4 : 2;
+    } else if (tile == 64) {
+        bm = 128;
+        ns = k == 64 ? 4 : 2;
     } else {
-        // narrow tiles do little MFMA work per chunk (2-8 per wave): the DMA round trip, not the matrix pipe, sets
-        // the pace, so they take the deepest ring that keeps >= 2 workgroups per CU
-        // tall variant (256 rows, waves 4 x 1) selectable with BM = 256: halves the per-tile fixed cost of the
-        // full-resolution small-channel layers
-        if (bm == 0 && tile == 32 && k == 64 && M >= 65536) bm = 256;   // 32-channel full-resolution layers: -34 %
-        if (bm == 256 && tile <= 64 && !(tile == 64 && k == 64)) {
-            ns = 2;
-        } else {
-            bm = 128;
-            if (k == 64) ns = (tile >= 64 || ns == 4) ? 4 : 2;
-            else if (tile == 64) ns = ns == 3 ? 3 : 2;
-            else ns = (ns >= 2 && ns <= 4) ? ns : 2;
-        }
+        if (bm == 0) bm = M >= 65536 ? 256 : 128;
+        bm = bm >= 256 ? 256 : 128;
     }
     plan[0] = 2;
     plan[1] = bm;
@@ -654,39 +647,27 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15)) return -3;
     if (p.groups > 1 && (p.N % p.groups)) return -4;
     hipStream_t st = (hipStream_t)stream;
-    const int bm = plan[1], tile = plan[2], k = plan[3], ns = plan[4];
+    const int bm = plan[1], tile = plan[2], k = plan[3];
 #define GLDS_DISPATCH(TT)                                                                                     \
     if (tile == 256) {                                                                                        \
         if (k == 64) return launch_glds<TT, 256, 256, 2, 4, 64, 4>(p, st);                                    \
         return launch_glds<TT, 256, 256, 2, 4, 128, 2>(p, st);                                                \
     }                                                                                                         \
-    if (k == 128) {                                                                                           \
-        if (tile == 128) {                                                                                    \
-            if (bm == 64) {                                                                                   \
-                if (ns == 2) return launch_glds<TT, 64, 128, 2, 2, 128, 2>(p, st);                            \
-                if (ns == 3) return launch_glds<TT, 64, 128, 2, 2, 128, 3>(p, st);                            \
-                return launch_glds<TT, 64, 128, 2, 2, 128, 4>(p, st);                                         \
-            }                                                                                                 \
-            if (ns == 2) return launch_glds<TT, 128, 128, 2, 2, 128, 2>(p, st);                               \
-            if (ns == 3) return launch_glds<TT, 128, 128, 2, 2, 128, 3>(p, st);                               \
-            return launch_glds<TT, 128, 128, 2, 2, 128, 4>(p, st);                                            \
-        }                                                                                                     \
-        if (tile == 64 && bm == 256) return launch_glds<TT, 256, 64, 4, 1, 128, 2>(p, st);                    \
-        if (tile == 32 && bm == 256) return launch_glds<TT, 256, 32, 4, 1, 128, 2>(p, st);                    \
-        if (tile == 64) {                                                                                     \
-            if (ns == 3) return launch_glds<TT, 128, 64, 2, 2, 128, 3>(p, st);                                \
-            return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                             \
-        }                                                                                                     \
-        if (ns == 3) return launch_glds<TT, 128, 32, 4, 1, 128, 3>(p, st);                                    \
-        if (ns == 4) return launch_glds<TT, 128, 32, 4, 1, 128, 4>(p, st);                                    \
-        return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);                                                 \
+    if (tile == 128) {                                                                                        \
+        if (k == 64) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
+        if (bm == 64) return launch_glds<TT, 64, 128, 2, 2, 128, 2>(p, st);                                   \
+        return launch_glds<TT, 128, 128, 2, 2, 128, 2>(p, st);                                                \
     }                                                                                                         \
-    if (tile == 128 && bm == 256) return launch_glds<TT, 256, 128, 2, 2, 64, 3>(p, st);                       \
-    if (tile == 128) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
-    if (tile == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                      \
-    if (tile == 32 && bm == 256) return launch_glds<TT, 256, 32, 4, 1, 64, 2>(p, st);                         \
-    if (ns == 4) return launch_glds<TT, 128, 32, 4, 1, 64, 4>(p, st);                                         \
-    return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);
+    if (tile == 64) {                                                                                         \
+        if (k == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                     \
+        return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                                 \
+    }                                                                                                         \
+    if (bm == 256) {                                                                                          \
+        if (k == 64) return launch_glds<TT, 256, 32, 4, 1, 64, 2>(p, st);                                     \
+        return launch_glds<TT, 256, 32, 4, 1, 128, 2>(p, st);                                                 \
+    }                                                                                                         \
+    if (k == 64) return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);                                         \
+    return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }
     GLDS_DISPATCH(bf16_t)
 #undef GLDS_DISPATCH

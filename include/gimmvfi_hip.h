@@ -65,7 +65,7 @@ typedef struct {
     const void* aux0; int lda0;         /* GRU: h                                           */
     const void* aux1; int lda1;         /* GRU_Q: z                                         */
     int tile_hint;                      /* 0 = auto, else BN | BM << 10: Cout tile width 32/64/128/256 and (LDS-DMA kernel,
-                                         * BN = 128) pixel tile height 64/128 */
+                                         * BN = 128) pixel tile height 64/128 (BN = 128) or 128/256 (BN = 32) */
     int w_layout;                       /* 0: [Cout][KH][KW][Cin];  1 (LDS-DMA kernel only): K-chunk major,  *
                                          * [K/64][Cout][64] with the 16-byte groups of a row XOR-swizzled by *
                                          * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
@@ -73,8 +73,8 @@ typedef struct {
                                          * channel_chunk * KH*KW + tap (the kernel walks the taps innermost)   */
     int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32);   *
-                                         * bits 4..6: LDS ring depth override (A/B runs), bit 7: *
-                                         * force 64-byte K chunks, bits 8..: profiling switches   */
+                                         * bit 7: force 64-byte K chunks (A/B runs), bits 8..:    *
+                                         * profiling switches (skip phases, s_memtime stamps)     */
 } gvfi_conv_params;
 
 int gvfi_conv2d(const gvfi_conv_params* p, void* stream);

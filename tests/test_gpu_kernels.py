@@ -40,9 +40,9 @@ CONV_SHAPES = [
     (2, 64, 112, 256, 24, 3, 3, dict(out_f32=True)),                                         # decoder head, 128x32 LDS-DMA tile
     (4, 32, 56, 256, 2, 3, 3, dict(out_f32=True, with_res=True)),                             # RAFT flow head
     (2, 256, 448, 32, 32, 3, 3, dict(act1=L.ACT_LRELU, with_res=True)),                       # auto -> tall 256x32 tile (cnn encoder)
-    (2, 64, 112, 64, 64, 3, 3, dict(tile=64 | (256 << 10), act1=L.ACT_PRELU)),                # tall 256x64 tile
+    (2, 64, 112, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),                    # tall 256x32 tile, 128-byte chunks
     (4, 32, 56, 384, 128, 1, 5, dict(split=128, act1=L.ACT_RELU)),                            # auto -> 64-row tiles (224 workgroups)
-    (1, 40, 56, 128, 128, 3, 3, dict(algo=2 + 16 * 3, tile=128 | (128 << 10))),               # 3-deep ring (counted vmcnt)
+    (1, 40, 56, 96, 96, 3, 3, dict(act1=L.ACT_RELU)),                                         # 64-byte chunks, 4-deep ring (counted vmcnt)
 ]
 
 

@@ -32,15 +32,13 @@ CONV_SHAPES = [
     (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),  # 8-wave 256x256 tile
     (1, 9, 11, 128, 24, 3, 3, dict(out_f32=True)),        # Cout <= 32 on the LDS-DMA kernel (128x32 tile)
     (2, 6, 7, 64, 2, 3, 3, dict(out_f32=True, with_res=True)),
-    # selectable LDS-DMA variants: 64-row tiles, 3/4-deep rings (counted vmcnt), 256x128 with 64-byte chunks
-    (1, 9, 40, 64, 70, 3, 3, dict(algo=2 + 16 * 3, tile=128 | (64 << 10), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
-    (1, 8, 10, 128, 130, 1, 5, dict(algo=2 + 16 * 2, tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
-    (1, 9, 12, 64, 130, 3, 3, dict(algo=2 + 16 * 4, tile=128 | (128 << 10))),
-    (1, 17, 19, 32, 100, 3, 3, dict(algo=2 + 128, tile=128 | (256 << 10), act1=L.ACT_LRELU)),
-    # tall 256-row tiles (waves 4 x 1) of the narrow full-resolution layers
+    # selectable LDS-DMA variants: 64-row tiles, 64-byte chunks with the 4-deep ring (counted vmcnt), tall 256-row tiles
+    (1, 9, 40, 64, 70, 3, 3, dict(tile=128 | (64 << 10), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
+    (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
+    (1, 9, 12, 64, 130, 3, 3, dict(algo=2 + 128, tile=128)),
+    (1, 9, 12, 96, 40, 3, 3, dict(act1=L.ACT_LRELU)),
     (1, 18, 20, 32, 32, 3, 3, dict(tile=32 | (256 << 10), act1=L.ACT_LRELU, with_res=True)),
     (1, 18, 20, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),
-    (1, 18, 20, 64, 64, 3, 3, dict(tile=64 | (256 << 10), act1=L.ACT_PRELU)),
 ]
 
 

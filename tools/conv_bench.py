@@ -52,19 +52,8 @@ def main():
         res = {}
         outs = {}
         variants = ((1, 0), (2, 128), (2, 256), (2 + 128, 128), (2 + 128, 256))
-        if os.environ.get("SMALLM"):   # BM / ring depth sweep for the small-M (RAFT) shapes
-            variants = tuple((2 + 16 * ns, 128 | (bm << 10)) for bm in (128, 64) for ns in (2, 3, 4))
-        if os.environ.get("T256x128"):
-            variants = ((2, 256), (2 + 128, 128 | (256 << 10)), (2 + 128, 128 | (128 << 10)), (2, 128 | (128 << 10)))
         if os.environ.get("ABLATE0"):   # prologue / K loop / epilogue split on the auto tile
             variants = tuple((2 + 256 * m, 0) for m in (0, 8, 16, 24, 32))
-        if os.environ.get("TALL"):      # 256-row tiles for the narrow layers
-            nb = 64 if Cout > 32 else 32
-            variants = ((2, (128 << 10) | nb), (2, (256 << 10) | nb), (2 + 128, (128 << 10) | nb), (2 + 128, (256 << 10) | nb))
-        if os.environ.get("RING"):      # ring depth sweep on the narrow tiles
-            variants = tuple((2 + 16 * ns, 0) for ns in (2, 3, 4))
-        if os.environ.get("BN64"):
-            variants = ((2, 128 | (128 << 10)), (2, 64), (2, 32))
         if os.environ.get("ONLY256"):     # single variant for PMC passes
             variants = ((2, 256),)
         if os.environ.get("ABLATE"):
