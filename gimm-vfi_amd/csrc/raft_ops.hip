@@ -151,6 +151,42 @@ extern "C" int gvfi_flow_pack(const float* coords1, void* dst0, int ld0, int pad
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------ tap sum   raft/update.py:6-14 (FlowHead.conv2)
+// A KHxKW convolution with 2-4 output channels over hundreds of input channels is a latency chain on the GEMM
+// engine (K = 2304 per 128-pixel tile for two useful columns).  It is evaluated as a 1x1 convolution producing the
+// KH*KW*C per-tap partial sums P[pixel][tap*C + c] (one pass over the input, all MFMA columns useful) followed by this
+// gather:  out[n,y,x,c] = res + bias[c] + sum_tap P[n, y+dy, x+dx, tap*C + c]   (zero outside the image).
+__global__ void tap_sum_kernel(const float* __restrict__ P, int ldp, int C, int KH, int KW, const float* __restrict__ bias,
+                               const float* __restrict__ res, int ldr, float* __restrict__ out, int ldo, long long total,
+                               int H, int W) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (pixel, channel)
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long pix = idx / C;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    float v = bias ? bias[c] : 0.f;
+    int tap = 0;
+    for (int kh = 0; kh < KH; ++kh) {
+        const int yy = y + kh - KH / 2;
+        for (int kw = 0; kw < KW; ++kw, ++tap) {
+            const int xx = x + kw - KW / 2;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                v += P[(pix + (long long)(kh - KH / 2) * W + (kw - KW / 2)) * ldp + tap * C + c];
+        }
+    }
+    if (res) v += res[pix * ldr + c];
+    out[pix * ldo + c] = v;
+}
+extern "C" int gvfi_tap_sum(const float* P, int ldp, int C, int KH, int KW, const float* bias, const float* res, int ldr,
+                            float* out, int ldo, int N, int H, int W, void* stream) {
+    if (C <= 0 || ldp < KH * KW * C) return -2;
+    const long long total = (long long)N * H * W * C;
+    GVFI_LAUNCH_SIMPLE(tap_sum_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, P, ldp, C, KH, KW, bias, res,
+                       ldr, out, ldo, total, H, W);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ convex upsampling   raft/raft.py:86-97
 // out[n, 8y+i, 8x+j, c] = sum_k softmax_k(mask[n,y,x, k*64+i*8+j]) * 8*flow[n, y+k/3-1, x+k%3-1, c]
 template <typename T>

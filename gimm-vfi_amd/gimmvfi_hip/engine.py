@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import lib as L
-from .ops import ConvLayer, InrMlp, PatchConvLayer, Runtime, V, View
+from .ops import ConvLayer, InrMlp, PatchConvLayer, Runtime, TapSplitConvLayer, V, View
 
 A = L  # activation / epilogue constants
 
@@ -85,8 +85,11 @@ class Engine:
         self._conv(sd, f"{u}.encoder.convc1", cin_pad=self.rt.cp64(324))
         self._patch_conv(sd, f"{u}.encoder.convf1")   # 2 -> 128, 7x7: im2col + 1x1
         for k in ("encoder.convc2", "encoder.convf2", "encoder.conv",
-                  "flow_head.conv1", "flow_head.conv2", "mask.0", "mask.2"):
+                  "flow_head.conv1", "mask.0", "mask.2"):
             self._conv(sd, f"{u}.{k}")
+        # 256 -> 2, 3x3 on the iteration's critical path: 1x1 to the 18 per-tap partial sums + tap gather
+        k = f"{u}.flow_head.conv2"
+        self.layers[k] = TapSplitConvLayer(self.rt, sd[k + ".weight"], sd[k + ".bias"])
         for n in ("1", "2"):
             wz, wr = sd[f"{u}.gru.convz{n}.weight"], sd[f"{u}.gru.convr{n}.weight"]
             bz, br = sd[f"{u}.gru.convz{n}.bias"], sd[f"{u}.gru.convr{n}.bias"]
@@ -249,6 +252,7 @@ class Engine:
         fh = rt.act(n, h8, w8, 256)
         u = fe + ".update_block"
         fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
+        fpart = rt.f32(n, h8, w8, 20)   # 9 taps x 2 partial sums of the flow head (+ pad)
         for it in range(iters):
             rt.corr_lookup(pyr_ab, coords, corrf, n, h8, w8, h8, w8)
             rt.flow_pack(coords, flow8, View(xbuf, 254, 2))
@@ -268,7 +272,7 @@ class Engine:
                 hc, hn = hn, hc
             # after two passes the state is back in hA
             rt.conv(Ls[u + ".flow_head.conv1"], hA, fh, act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".flow_head.conv2"], fh, View(coords), res=View(coords))   # coords1 += delta
+            rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh, View(coords), res=View(coords), scratch=fpart)   # coords1 += delta
             if taps is not None and it in (0, iters - 1):
                 taps[f"r01_corr_it{it}"] = corrf[:B, ..., :324].clone()
                 taps[f"r01_net_it{it}"] = hA[:B].clone()

@@ -96,6 +96,18 @@ class PatchConvLayer:
         self.inner.cin = kh * kw * cin      # real products per output (FLOP accounting)
 
 
+class TapSplitConvLayer:
+    """A KHxKW zero-padded stride-1 convolution with very few output channels, run as a 1x1 convolution to the
+    KH*KW*Cout per-tap partial sums + gvfi_tap_sum (Runtime.tap_split_conv)."""
+
+    def __init__(self, rt, w, b):
+        cout, cin, kh, kw = w.shape
+        self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
+        w2 = w.detach().float().permute(2, 3, 0, 1).reshape(kh * kw * cout, cin, 1, 1)   # row = tap * cout + c
+        self.inner = ConvLayer(rt, w2, None)
+        self.b = None if b is None else b.detach().float().contiguous().to(rt.device)
+
+
 class InrMlp:
     """Packed weights of the fused hypo-network kernel (gvfi_inr_mlp): layers = [(w [out,in], b [out])] x 5 with
     dims 35 -> 128 -> 128 -> 128 -> 128 -> 2.  The packing is the library's own host routine."""
@@ -354,6 +366,23 @@ class Runtime:
         self._chk(self.lib.im2col(src.ptr, src.ld, layer.cin, n, h, w, layer.kh, layer.kw, layer.kh // 2, layer.kw // 2,
                                   scratch.data_ptr(), layer.kpad, self.dtype, self.stream()), "im2col")
         return self.conv(layer.inner, scratch, out, **kw)
+
+    def tap_split_conv(self, layer, src, out, res=None, scratch=None):
+        """out (f32 view) = conv(src) [+ res]; res may alias out.  scratch: f32 [N,H,W,>=KH*KW*cout]."""
+        src = V(src)
+        out = V(out)
+        n, h, w = src.t.shape[:3]
+        k = layer.kh * layer.kw * layer.cout
+        if scratch is None:
+            scratch = self.f32(n, h, w, roundup(k, 4))
+        self.conv(layer.inner, src, View(scratch, 0, k))
+        r = None if res is None else V(res)
+        assert out.is_f32 and (r is None or r.is_f32)
+        self._chk(self.lib.tap_sum(scratch.data_ptr(), scratch.shape[-1], layer.cout, layer.kh, layer.kw,
+                                   None if layer.b is None else layer.b.data_ptr(),
+                                   None if r is None else r.ptr, 0 if r is None else r.ld, out.ptr, out.ld, n, h, w,
+                                   self.stream()), "tap_sum")
+        return out
 
     def inr_mlp(self, mlp, lat, coord, out):
         """out[B,H,W,2] (f32) = hypo-network(lat[..., :32], coord[B,1,H,W,3])."""

@@ -119,6 +119,11 @@ int gvfi_coords_init(float* coords, int N, int h, int w, void* stream);
 /* flow = coords1 - grid -> dst0[.,0:2] (+ zero pad to pad0 channels) and dst1[.,0:2] */
 int gvfi_flow_pack(const float* coords1, void* dst0, int ld0, int pad0, void* dst1, int ld1,
                    int N, int h, int w, int dtype, void* stream);
+/* second half of a "tap split" convolution (raft/update.py:6-14 FlowHead.conv2, 256 -> 2, 3x3): P[n,y,x, tap*C + c]
+ * (float, pitch ldp) holds the per-tap partial sums of a 1x1 convolution with the KH*KW*C re-arranged filters;
+ * out[n,y,x,c] = res + bias[c] + sum over taps of P at the tap's source pixel (zero padding).  res may alias out. */
+int gvfi_tap_sum(const float* P, int ldp, int C, int KH, int KW, const float* bias, const float* res, int ldr,
+                 float* out, int ldo, int N, int H, int W, void* stream);
 int gvfi_convex_upsample(const float* coords1, const void* mask, int ldm, int mask_f32, float* flow_up,
                          int N, int h, int w, int dtype, void* stream);
 

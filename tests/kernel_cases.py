@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 import gimmvfi_r_oracle as orc
 from gimmvfi_hip import lib as L
-from gimmvfi_hip.ops import ConvLayer, InrMlp, PatchConvLayer, View
+from gimmvfi_hip.ops import ConvLayer, InrMlp, PatchConvLayer, TapSplitConvLayer, View
 
 
 def _dev(rt):
@@ -160,6 +160,24 @@ def patch_conv_case(rt, N=2, H=10, W=13, Cin=2, Cout=24, KH=7, KW=7):
     rt.patch_conv(lay, View(xa, 0, Cin), out, act1=L.ACT_RELU)
     ref = F.relu(F.conv2d(x, w, b, padding=(KH // 2, KW // 2)))
     err = float((out.float().cpu().permute(0, 3, 1, 2)[:, :Cout] - ref).abs().max())
+    assert err <= tol(rt, 4.0), err
+
+
+def tap_split_conv_case(rt, N=2, H=9, W=12, Cin=64, Cout=2):
+    """1x1 to per-tap partial sums + gvfi_tap_sum == the 3x3 zero-padded convolution with residual, in place
+    (raft/update.py:6-14, raft/raft.py:157 coords1 = coords1 + delta_flow)."""
+    g = torch.Generator().manual_seed(13)
+    x = _rounded(rt, torch.randn(N, Cin, H, W, generator=g))
+    w = _rounded(rt, torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, H, W, Cout, generator=g)
+    dev = _dev(rt)
+    lay = TapSplitConvLayer(rt, w, b)
+    xa = _to_act(rt, x).to(dev)
+    out = r.clone().to(dev)
+    rt.tap_split_conv(lay, xa, View(out), res=View(out))
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1) + r
+    err = float((out.cpu() - ref).abs().max())
     assert err <= tol(rt, 4.0), err
 
 

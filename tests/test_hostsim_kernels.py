@@ -58,6 +58,10 @@ def test_corr_volume_grouped_gemm(rt):
     kc.corr_volume_case(rt)
 
 
+def test_tap_split_conv(rt):
+    kc.tap_split_conv_case(rt)
+
+
 def test_patch_conv(rt):
     kc.patch_conv_case(rt)
     kc.patch_conv_case(rt, N=1, H=9, W=8, Cin=4, Cout=16)
