@@ -114,6 +114,17 @@ int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const fl
 int gvfi_im2col(const void* x, int ld, int c, int N, int H, int W, int KH, int KW, int pad_h, int pad_w,
                 void* out, int ldo, int dtype, void* stream);
 
+/* ---- volume-free correlation lookup: the reference's native module alt_cuda_corr ------------------------------
+ * (flowformer/alt_cuda_corr/correlation.cpp:19-54 `forward`, correlation_kernel.cu:18-119; caller raft/corr.py:96-124)
+ * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] (dtype GVFI_F32 like the reference op, or GVFI_BF16), coords [B,N,H1,W1,2] float
+ * (x, y) in fmap2 pixels -> corr [B,N,(2r+1)^2,H1,W1] float, channel = dy_index + (2r+1)*dx_index, bilinear in the
+ * dot products, zeros outside fmap2, NOT divided by sqrt(C).  Every output element is written (no zero-fill needed).
+ * radius <= 5, C <= 512. */
+int gvfi_alt_corr_forward(const void* fmap1, const void* fmap2, const float* coords, float* corr, int B, int N,
+                          int H1, int W1, int H2, int W2, int C, int radius, int dtype, void* stream);
+/* 2x2 average pooling of an NHWC map [N,H,W,C] -> [N,H/2,W/2,C] (fmap2 pyramid of raft/corr.py:101-105) */
+int gvfi_avgpool2_nhwc(const void* src, void* dst, int N, int H, int W, int C, int dtype, void* stream);
+
 /* ---- RAFT glue (raft/raft.py:77-97,139-161) ------------------------------------------- */
 int gvfi_coords_init(float* coords, int N, int h, int w, void* stream);
 /* flow = coords1 - grid -> dst0[.,0:2] (+ zero pad to pad0 channels) and dst1[.,0:2] */
