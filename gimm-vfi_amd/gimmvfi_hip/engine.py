@@ -27,8 +27,11 @@ def _fold_bn(w, b, sd, p, eps=1e-5):
 
 
 class Engine:
-    def __init__(self, rt: Runtime, sd):
+    def __init__(self, rt: Runtime, sd, motion_only=False):
+        """motion_only: build only the GIMM blocks (splat metric, cnn_encoder, res_conv, hypo-network) -- the
+        reference's motion-only model `GIMM` (generalizable_INR/gimm.py)."""
         self.rt = rt
+        self.motion_only = motion_only
         sd = {k: v.detach() for k, v in sd.items()}
         self.alpha_v = float(sd["alpha_v"].float().cpu().item())
         self.alpha_fe = float(sd["alpha_fe"].float().cpu().item())
@@ -73,7 +76,36 @@ class Engine:
                   "flow_head.0", "flow_head.2"):
             self._conv(sd, f"{p}.{k}")
 
+    def _build_motion(self, sd):
+        """gimmvfi_r.py:84-124 == gimm.py:36-78: motion encoder, latent refiner, hypo-network."""
+        self._conv(sd, "cnn_encoder.0")
+        self._conv(sd, "cnn_encoder.1")
+        for i in (3, 4, 5):
+            self._conv(sd, f"cnn_encoder.{i}.layers.0")
+            self._conv(sd, f"cnn_encoder.{i}.layers.2")
+        self._conv(sd, "cnn_encoder.7", pad_mode=L.PAD_REFLECT)
+        self._conv(sd, "res_conv.0")
+        self._conv(sd, "res_conv.1")
+        self._conv(sd, "res_conv.3.layers.0")
+        self._conv(sd, "res_conv.3.layers.2")
+        self._conv(sd, "res_conv.5", pad_mode=L.PAD_REFLECT)
+        # INR: weights L2-normalised along fan_in once (constant at inference)  modules/hyponet.py:124-128
+        inr = []
+        for i in range(5):
+            wb = sd[f"hyponet.params_dict.linear_wb{i}"].float()
+            w = torch.nn.functional.normalize(wb[:-1], dim=0)
+            b = wb[-1].clone()
+            if i == 4:
+                b = b + 0.5  # output_bias, hyponet.py:143
+            self._add(f"inr.{i}", w.t().reshape(w.shape[1], w.shape[0], 1, 1).contiguous(), b)
+            inr.append((w.t().contiguous(), b))
+        # bf16 mode: the five layers run as ONE kernel with register-resident activations (csrc/inr_mlp.hip)
+        self.inr_mlp = InrMlp(self.rt, inr) if InrMlp.supported(self.rt, inr) else None
+
     def _build(self, sd):
+        self._build_motion(sd)
+        if self.motion_only:
+            return
         fe = "flow_estimator"
         self._build_encoder(sd, fe + ".fnet", False)
         self._conv(sd, fe + ".fnet.conv2")
@@ -119,29 +151,6 @@ class Engine:
         self._build_update(sd, "amt_update4_high")
         self._conv(sd, "amt_comb_block.0", slope="amt_comb_block.1.weight")
         self._conv(sd, "amt_comb_block.2")
-        self._conv(sd, "cnn_encoder.0")
-        self._conv(sd, "cnn_encoder.1")
-        for i in (3, 4, 5):
-            self._conv(sd, f"cnn_encoder.{i}.layers.0")
-            self._conv(sd, f"cnn_encoder.{i}.layers.2")
-        self._conv(sd, "cnn_encoder.7", pad_mode=L.PAD_REFLECT)
-        self._conv(sd, "res_conv.0")
-        self._conv(sd, "res_conv.1")
-        self._conv(sd, "res_conv.3.layers.0")
-        self._conv(sd, "res_conv.3.layers.2")
-        self._conv(sd, "res_conv.5", pad_mode=L.PAD_REFLECT)
-        # INR: weights L2-normalised along fan_in once (constant at inference)  modules/hyponet.py:124-128
-        inr = []
-        for i in range(5):
-            wb = sd[f"hyponet.params_dict.linear_wb{i}"].float()
-            w = torch.nn.functional.normalize(wb[:-1], dim=0)
-            b = wb[-1].clone()
-            if i == 4:
-                b = b + 0.5  # output_bias, hyponet.py:143
-            self._add(f"inr.{i}", w.t().reshape(w.shape[1], w.shape[0], 1, 1).contiguous(), b)
-            inr.append((w.t().contiguous(), b))
-        # bf16 mode: the five layers run as ONE kernel with register-resident activations (csrc/inr_mlp.hip)
-        self.inr_mlp = InrMlp(self.rt, inr) if InrMlp.supported(self.rt, inr) else None
 
     # ------------------------------------------------------------------ building blocks
     def _enc(self, x, p, norm, B2):
@@ -320,6 +329,106 @@ class Engine:
             rt.conv(Ls[p + ".feat_head.2"], fh0, ft_4, res=ft_4)
             rt.conv(Ls[p + ".flow_head.2"], lh0, View(st4, 0, 4), res=View(st4, 0, 4))
 
+    # ------------------------------------------------------------------ motion INR (shared by GIMM-VFI-R and GIMM)
+    def _motion_encode(self, nfA, f01, f10, B, H, W):
+        """Splat metric (gimmvfi_r.py:444-492 == gimm.py:80-127) and the motion encoder on both normalised flows
+        (gimmvfi_r.py:164-167 == gimm.py:139-140).  nfA: [2B,H,W,2(+pad)] activation, f01/f10: [B,H,W,2] f32.
+        Returns z0, z1 [B,H,W] f32 and latcat [B,H,W,64] = [pl0 | pl1 | (splat0) | (splat1)]."""
+        rt, Ls, lib, st = self.rt, self.layers, self.rt.lib, self.rt.stream
+        n = 2 * B
+        z0, z1 = rt.f32(B, H, W), rt.f32(B, H, W)
+        rt._chk(lib.splat_weights(f01.data_ptr(), f10.data_ptr(), self.g9.data_ptr(), self.alpha_v, self.alpha_fe,
+                                  z0.data_ptr(), z1.data_ptr(), B, H, W, st()), "splat_weights")
+        e0 = rt.act(n, H, W, 16)
+        rt.conv(Ls["cnn_encoder.0"], View(nfA, 0, 2), e0)
+        e = rt.act(n, H, W, 32)
+        rt.conv(Ls["cnn_encoder.1"], e0, e, act1=A.ACT_LRELU)
+        tA = rt.act(n, H, W, 32)
+        for i in (3, 4, 5):
+            rt.conv(Ls[f"cnn_encoder.{i}.layers.0"], e, tA, act1=A.ACT_LRELU)
+            e2 = rt.act(n, H, W, 32)
+            rt.conv(Ls[f"cnn_encoder.{i}.layers.2"], tA, e2, res=e, act2=A.ACT_LRELU if i == 5 else A.ACT_NONE)
+            e = e2
+        latcat = rt.act(B, H, W, 64)   # [pl0 | pl1 | splat0 | splat1]  gimmvfi_r.py:187-192
+        rt.conv(Ls["cnn_encoder.7"], e[:B], View(latcat, 0, 16))
+        rt.conv(Ls["cnn_encoder.7"], e[B:], View(latcat, 16, 16))
+        return z0, z1, latcat
+
+    def _motion_inr(self, latcat, f01, f10, z0, z1, cg, tv, B, H, W, taps=None, tag=""):
+        """One timestep: softmax-splat both latents to t, refine, evaluate the hypo-network on the coordinate grid
+        cg [B,1,Hc,Wc,3] (gimmvfi_r.py:171-205 == gimm.py:147-179).  Returns the normalised flow [B,Hc,Wc,2] f32."""
+        rt, Ls, lib, st = self.rt, self.layers, self.rt.lib, self.rt.stream
+        HW = H * W
+        Hc, Wc = cg.shape[2], cg.shape[3]
+        # softmax splatting of the two latents to time t   gimmvfi_r.py:171-193
+        for d, (fl, zz) in enumerate(((f01, z0), (f10, z1))):
+            acc = rt.f32(B, H, W, 17, zero=True)
+            rt._chk(lib.softsplat_accum(View(latcat, 16 * d, 16).ptr, latcat.shape[-1], 16, fl.data_ptr(),
+                                        zz.data_ptr(), tv.data_ptr(), d, acc.data_ptr(), B, H, W, rt.dtype, st()),
+                    "softsplat_accum")
+            rt._chk(lib.softsplat_normalize(acc.data_ptr(), 16, View(latcat, 32 + 16 * d, 16).ptr,
+                                            latcat.shape[-1], B * HW, rt.dtype, st()), "softsplat_normalize")
+        r0 = rt.act(B, H, W, 32)
+        rt.conv(Ls["res_conv.0"], latcat, r0)
+        r1 = rt.act(B, H, W, 64)
+        rt.conv(Ls["res_conv.1"], r0, r1, act1=A.ACT_LRELU)
+        r2 = rt.act(B, H, W, 64)
+        rt.conv(Ls["res_conv.3.layers.0"], r1, r2, act1=A.ACT_LRELU)
+        r3 = rt.act(B, H, W, 64)
+        rt.conv(Ls["res_conv.3.layers.2"], r2, r3, res=r1, act2=A.ACT_LRELU)
+        lat = rt.act(B, H, W, 32)
+        rt.conv(Ls["res_conv.5"], r3, lat, res=View(latcat, 32, 32))
+        if taps is not None:
+            taps[f"{tag}splat0"] = latcat[..., 32:48].clone()
+            taps[f"{tag}latent"] = lat
+        # INR   modules/hyponet.py:71-146
+        if (Hc, Wc) != (H, W):
+            lat = rt.resize(lat, 32, None, size=(Hc, Wc)).t
+        ninr = rt.f32(B, Hc, Wc, 2)
+        if self.inr_mlp is not None:
+            rt.inr_mlp(self.inr_mlp, View(lat, 0, 32), cg, ninr)
+        else:
+            xin = rt.act(B, Hc, Wc, 35, zero=True)
+            rt._chk(lib.inr_pack(lat.data_ptr(), lat.shape[-1], 32, cg.data_ptr(), xin.data_ptr(), xin.shape[-1],
+                                 xin.shape[-1], B * Hc * Wc, rt.dtype, st()), "inr_pack")
+            hcur = View(xin, 0, 35)
+            for li in range(4):
+                hn = rt.act(B, Hc, Wc, 128)
+                rt.conv(Ls[f"inr.{li}"], hcur, hn, act1=A.ACT_SIN)
+                hcur = hn
+            rt.conv(Ls["inr.4"], hcur, ninr)
+        return ninr
+
+    @torch.no_grad()
+    def forward_motion(self, xs, coord, ori_flow, timesteps):
+        """The reference's motion-only model GIMM.forward (gimm.py:129-214, keep_xs_shape=True): xs = normalised flows
+        (B,2,2,H,W) [channel, frame], ori_flow = raw flows (B,2,2,H,W) [frame 0: 0->1, frame 1: 1->0], coord /
+        timesteps one tensor each or equally long lists.  Returns (a list of) normalised flows (B,2,1,H',W')."""
+        rt = self.rt
+        xs = xs.to(device=rt.device, dtype=torch.float32)
+        ori_flow = ori_flow.to(device=rt.device, dtype=torch.float32)
+        B, _, _, H, W = xs.shape
+        # layout plumbing only: NCHW planes -> the NHWC tensors the kernels read
+        f01 = ori_flow[:, :, 0].permute(0, 2, 3, 1).contiguous()
+        f10 = ori_flow[:, :, 1].permute(0, 2, 3, 1).contiguous()
+        nfA = rt.act(2 * B, H, W, 2, zero=True)
+        nfA[:B, ..., :2] = xs[:, :, 0].permute(0, 2, 3, 1).to(nfA.dtype)
+        nfA[B:, ..., :2] = xs[:, :, 1].permute(0, 2, 3, 1).to(nfA.dtype)
+        z0, z1, latcat = self._motion_encode(nfA, f01, f10, B, H, W)
+        single = not isinstance(timesteps, list)
+        if single:
+            coord, timesteps = [coord], [timesteps]
+        assert isinstance(coord, list) and len(coord) == len(timesteps)
+        outs = []
+        for c, cur_t in zip(coord, timesteps):
+            cg = c.to(device=rt.device, dtype=torch.float32).contiguous()
+            tv = cur_t.to(device=rt.device, dtype=torch.float32).reshape(-1).contiguous()
+            if tv.numel() == 1 and B > 1:
+                tv = tv.expand(B).contiguous()     # gimm.py:184 broadcasts a scalar time over the batch
+            ninr = self._motion_inr(latcat, f01, f10, z0, z1, cg, tv, B, H, W)
+            outs.append(rt.nhwc_to_nchw(ninr, 2).unsqueeze(2))   # (B,2,1,H',W')
+        return outs[0] if single else outs
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, img_xs, coord, t, iters=20, ds_factor=None, taps=None, want_aux=True):
@@ -361,22 +470,7 @@ class Engine:
         raft_flow = torch.stack([rt.nhwc_to_nchw(f01, 2), rt.nhwc_to_nchw(f10, 2)], dim=2)
 
         # ---- predict_flow (gimmvfi_r.py:158-211): splat metric + latent encoder
-        z0, z1 = rt.f32(B, H, W), rt.f32(B, H, W)
-        rt._chk(lib.splat_weights(f01.data_ptr(), f10.data_ptr(), self.g9.data_ptr(), self.alpha_v, self.alpha_fe,
-                                  z0.data_ptr(), z1.data_ptr(), B, H, W, st()), "splat_weights")
-        e0 = rt.act(n, H, W, 16)
-        rt.conv(Ls["cnn_encoder.0"], View(nfA, 0, 2), e0)
-        e = rt.act(n, H, W, 32)
-        rt.conv(Ls["cnn_encoder.1"], e0, e, act1=A.ACT_LRELU)
-        tA = rt.act(n, H, W, 32)
-        for i in (3, 4, 5):
-            rt.conv(Ls[f"cnn_encoder.{i}.layers.0"], e, tA, act1=A.ACT_LRELU)
-            e2 = rt.act(n, H, W, 32)
-            rt.conv(Ls[f"cnn_encoder.{i}.layers.2"], tA, e2, res=e, act2=A.ACT_LRELU if i == 5 else A.ACT_NONE)
-            e = e2
-        latcat = rt.act(B, H, W, 64)   # [pl0 | pl1 | splat0 | splat1]  gimmvfi_r.py:187-192
-        rt.conv(Ls["cnn_encoder.7"], e[:B], View(latcat, 0, 16))
-        rt.conv(Ls["cnn_encoder.7"], e[B:], View(latcat, 16, 16))
+        z0, z1, latcat = self._motion_encode(nfA, f01, f10, B, H, W)
         if taps is not None:
             taps["f01"], taps["f10"] = f01, f10
             taps["w1"], taps["w2"] = z0, z1
@@ -396,43 +490,7 @@ class Engine:
             tv = cur_t.to(device=rt.device, dtype=torch.float32).reshape(-1).contiguous()
             assert cg.shape[0] == B and cg.shape[1] == 1 and cg.shape[-1] == 3 and tv.numel() == B
             Hc, Wc = cg.shape[2], cg.shape[3]
-            # softmax splatting of the two latents to time t   gimmvfi_r.py:171-193
-            for d, (fl, zz) in enumerate(((f01, z0), (f10, z1))):
-                acc = rt.f32(B, H, W, 17, zero=True)
-                rt._chk(lib.softsplat_accum(View(latcat, 16 * d, 16).ptr, latcat.shape[-1], 16, fl.data_ptr(),
-                                            zz.data_ptr(), tv.data_ptr(), d, acc.data_ptr(), B, H, W, rt.dtype, st()),
-                        "softsplat_accum")
-                rt._chk(lib.softsplat_normalize(acc.data_ptr(), 16, View(latcat, 32 + 16 * d, 16).ptr,
-                                                latcat.shape[-1], B * HW, rt.dtype, st()), "softsplat_normalize")
-            r0 = rt.act(B, H, W, 32)
-            rt.conv(Ls["res_conv.0"], latcat, r0)
-            r1 = rt.act(B, H, W, 64)
-            rt.conv(Ls["res_conv.1"], r0, r1, act1=A.ACT_LRELU)
-            r2 = rt.act(B, H, W, 64)
-            rt.conv(Ls["res_conv.3.layers.0"], r1, r2, act1=A.ACT_LRELU)
-            r3 = rt.act(B, H, W, 64)
-            rt.conv(Ls["res_conv.3.layers.2"], r2, r3, res=r1, act2=A.ACT_LRELU)
-            lat = rt.act(B, H, W, 32)
-            rt.conv(Ls["res_conv.5"], r3, lat, res=View(latcat, 32, 32))
-            if taps is not None:
-                taps[f"t{i}_splat0"] = latcat[..., 32:48].clone()
-                taps[f"t{i}_latent"] = lat
-            # INR   modules/hyponet.py:71-146
-            if (Hc, Wc) != (H, W):
-                lat = rt.resize(lat, 32, None, size=(Hc, Wc)).t
-            ninr = rt.f32(B, Hc, Wc, 2)
-            if self.inr_mlp is not None:
-                rt.inr_mlp(self.inr_mlp, View(lat, 0, 32), cg, ninr)
-            else:
-                xin = rt.act(B, Hc, Wc, 35, zero=True)
-                rt._chk(lib.inr_pack(lat.data_ptr(), lat.shape[-1], 32, cg.data_ptr(), xin.data_ptr(), xin.shape[-1],
-                                     xin.shape[-1], B * Hc * Wc, rt.dtype, st()), "inr_pack")
-                hcur = View(xin, 0, 35)
-                for li in range(4):
-                    hn = rt.act(B, Hc, Wc, 128)
-                    rt.conv(Ls[f"inr.{li}"], hcur, hn, act1=A.ACT_SIN)
-                    hcur = hn
-                rt.conv(Ls["inr.4"], hcur, ninr)
+            ninr = self._motion_inr(latcat, f01, f10, z0, z1, cg, tv, B, H, W, taps, f"t{i}_")
             flow_t = rt.f32(B, Hc, Wc, 2)
             ninr_nchw = rt.f32(B, 2, 1, Hc, Wc)
             rt._chk(lib.flow_unnormalize(ninr.data_ptr(), scaler.data_ptr(), flow_t.data_ptr(), ninr_nchw.data_ptr(),

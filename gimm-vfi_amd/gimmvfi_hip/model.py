@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import lib as L
 from .engine import Engine
 from .ops import Runtime
-from .params import param_spec, random_state_dict
+from .params import gimm_param_spec, gimm_state_dict, param_spec, random_state_dict
 
 
 class _Node(nn.Module):
@@ -169,3 +169,82 @@ class GIMMVFI_R(nn.Module):
         mse = torch.reshape((preds - targets) ** 2, (b, -1)).mean(dim=-1)
         psnr = -10 * torch.log10(mse)
         return psnr.mean() if reduction == "mean" else (psnr.sum() if reduction == "sum" else psnr)
+
+
+class GIMM(nn.Module):
+    """Drop-in for the reference's motion-only model (generalizable_INR/gimm.py:26-253, `create_model` type "gimm",
+    used by src/VTF.py / src/VSF.py): flows in, flow at time t out -- the splat metric, motion encoder, softmax
+    splat, latent refiner and hypo-network kernels of the GIMM-VFI-R path without flow estimation and synthesis.
+    Same 36 state_dict keys, same ``forward(xs, coord, keep_xs_shape, ori_flow, timesteps)`` /
+    ``sample_coord_input`` / ``compute_loss`` surface; inference only, no CPU fallback."""
+
+    def __init__(self, config=None, precision=None):
+        super().__init__()
+        self.config = config
+        cfg_prec = None
+        if config is not None:
+            cfg_prec = config.get("precision") if isinstance(config, dict) else getattr(config, "precision", None)
+        self.precision = precision or cfg_prec or os.environ.get("GIMMVFI_PRECISION", "bf16")
+        self.coord_range = (-1.0, 1.0)
+        if config is not None:
+            cr = config.get("coord_range") if isinstance(config, dict) else getattr(config, "coord_range", None)
+            if cr is not None:
+                self.coord_range = (float(cr[0]), float(cr[1]))
+        sd0 = gimm_state_dict(random_state_dict(0))
+        for name in gimm_param_spec():
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(sd0[name].clone(), requires_grad=False))
+        self._engine = None
+        self._engine_key = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._engine = None
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._engine = None
+        return r
+
+    def engine(self, device=None, runtime=None):
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        key = (str(device), self.precision, id(runtime))
+        if self._engine is None or self._engine_key != key:
+            if runtime is None:
+                if device.type != "cuda":
+                    raise RuntimeError(
+                        "GIMM runs only on an MI355X through libgimmvfi_hip.so: move the model and inputs to 'cuda' "
+                        "(there is no CPU fallback)"
+                    )
+                runtime = Runtime(L.get(), self.precision, device)
+            self._engine = Engine(runtime, self.state_dict(), motion_only=True)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, xs, coord=None, keep_xs_shape=True, ori_flow=None, timesteps=None):
+        # gimm.py:129-214
+        assert keep_xs_shape, "keep_xs_shape=False is not used by the reference's drivers"
+        assert coord is not None and ori_flow is not None and timesteps is not None
+        return self.engine(xs.device).forward_motion(xs, coord, ori_flow, timesteps)
+
+    sample_coord_input = GIMMVFI_R.sample_coord_input
+
+    def compute_loss(self, preds, targets, reduction="mean", single=False):
+        # gimm.py:216-238
+        assert reduction in ["mean", "sum", "none"]
+        assert preds.shape[2] == 1 and targets.shape[2] == 1
+        b = preds.shape[0]
+        mse = torch.reshape((preds[:, :, 0] - targets[:, :, 0]) ** 2, (b, -1)).mean(dim=-1)
+        if reduction == "mean":
+            total, psnr = mse.mean(), (-10 * torch.log10(mse)).mean()
+        elif reduction == "sum":
+            total, psnr = mse.sum(), (-10 * torch.log10(mse)).sum()
+        else:
+            total, psnr = mse, -10 * torch.log10(mse)
+        return {"loss_total": total, "mse": total, "psnr": psnr}

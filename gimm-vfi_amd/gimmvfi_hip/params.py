@@ -207,3 +207,16 @@ def random_state_dict(seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, tor
         else:
             raise KeyError(name)
     return sd
+
+
+# ---- the motion-only model GIMM (reference generalizable_INR/gimm.py:26-78): the same blocks under the same names
+GIMM_KEY_PREFIXES = ("cnn_encoder.", "res_conv.", "hyponet.", "g_filter", "alpha_v", "alpha_fe")
+
+
+def gimm_param_spec():
+    return OrderedDict((k, v) for k, v in param_spec().items() if k.startswith(GIMM_KEY_PREFIXES))
+
+
+def gimm_state_dict(sd_full):
+    """The GIMM subset of a GIMM-VFI-R state_dict."""
+    return OrderedDict((k, v) for k, v in sd_full.items() if k.startswith(GIMM_KEY_PREFIXES))

@@ -6,16 +6,18 @@ _PKG = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
-from .generalizable_INR import gimmvfi_r  # noqa: E402
+from .generalizable_INR import gimm, gimmvfi_r  # noqa: E402
 
 
 def create_model(config, ema=False):
     model_type = (config["type"] if isinstance(config, dict) else config.type).lower()
     if model_type == "gimmvfi_r":
         model = gimmvfi_r(config)
-    elif model_type in ("gimmvfi_f", "gimm"):
+    elif model_type == "gimm":
+        model = gimm(config)
+    elif model_type == "gimmvfi_f":
         raise NotImplementedError(
-            f"{model_type}: only the GIMM-VFI-R hot path is implemented on the MI355X kernels so far (SURVEY.md section 8f)"
+            "gimmvfi_f: the FlowFormer encoder is not implemented on the MI355X kernels yet (SURVEY.md section 8f)"
         )
     else:
         raise ValueError(f"{model_type} is invalid..")

@@ -1,6 +1,10 @@
 """Drop-in for reference src/models/generalizable_INR/__init__.py."""
-from gimmvfi_hip.model import GIMMVFI_R
+from gimmvfi_hip.model import GIMM, GIMMVFI_R
 
 
 def gimmvfi_r(config):
     return GIMMVFI_R(config)
+
+
+def gimm(config):
+    return GIMM(config)

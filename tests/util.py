@@ -38,3 +38,27 @@ def maxabs(a, b):
 
 def nchw(t):
     return t.float().permute(0, 3, 1, 2)
+
+
+def gimm_inputs(meta):
+    """Seeded flow pair for the motion-only model (what src/VTF.py:88-139 feeds GIMM): smooth forward flow f01, a
+    roughly consistent backward flow f10, xs = normalize(cat(f01, -f10)), ori_flow = cat(f01, f10)."""
+    import gimmvfi_r_oracle as orc
+
+    B, H, W = meta["B"], meta["H"], meta["W"]
+    g = torch.Generator().manual_seed(meta["seed"])
+    low = torch.randn(B, 2, H // 8, W // 8, generator=g) * 4.0
+    f01 = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)
+    f10 = -f01 + torch.nn.functional.interpolate(torch.randn(B, 2, H // 8, W // 8, generator=g) * 0.5, size=(H, W),
+                                                 mode="bicubic", align_corners=False)
+    raw = torch.stack([f01, -f10], 2)                       # VTF.py:90
+    scaler = raw.abs().max().reshape(1, 1)                  # VTF.py:124-129 (one scaler per call)
+    xs = (raw / scaler + 1.0) / 2.0
+    ori = torch.stack([f01, f10], 2)                        # VTF.py:137
+    if meta["single"]:
+        coord = orc.sample_coord_input(B, (H, W), meta["t"][:1], 1.0)
+        ts = torch.tensor(meta["t"][:1])                    # VTF.py:139: one scalar time for the batch
+    else:
+        coord = [orc.sample_coord_input(B, (H, W), [t], 1.0) for t in meta["t"]]
+        ts = [t * torch.ones(B) for t in meta["t"]]
+    return xs, ori, coord, ts
