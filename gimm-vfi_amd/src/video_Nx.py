@@ -5,7 +5,8 @@
 writes OUT/output.mp4 (side-by-side [original | interpolated], fps 2N) and OUT/flow.mp4 (colour-coded
 flow_t).  Differences: runs on the MI355X HIP kernels (no CuPy / CUDA), and under
 ``python -m torch.distributed.run --nproc-per-node G`` the frame pairs are sharded over G GPUs with one
-RCCL gather of the uint8 result frames to rank 0.  Without OpenCV the frames are written as PNGs
+RCCL gather of the uint8 result frames to rank 0; frame decode / upload and result download / colour-coding run in a
+host pipeline beside the GPU (gimmvfi_hip/io_pipeline.py).  Without OpenCV the frames are written as PNGs
 (OUT/output_frames, OUT/flow_frames) and encoded with ffmpeg when it is on PATH.
 ``--random-init`` (addition) runs with seeded random weights when no checkpoint is available."""
 import argparse
@@ -25,6 +26,7 @@ from utils.setup import single_setup  # noqa: E402
 from utils.utils import InputPadder, set_seed  # noqa: E402
 
 from gimmvfi_hip import shard  # noqa: E402  (models/__init__ put the package root on sys.path)
+from gimmvfi_hip.io_pipeline import FramePrefetcher, ResultDrain  # noqa: E402
 
 try:
     import cv2
@@ -124,31 +126,50 @@ def main(argv=None):
     num_pairs = len(img_list) - 1
     N = args.N
     p0, p1 = shard.pair_range(num_pairs, rank, world)
-    local_frames = []   # per pair: uint8 [N-1, 2, H, W, 3] (interpolated frame, flow image), BGR
     ds_factor = args.ds_factor
+    # host pipeline: frames of this rank's pair range are decoded once, ahead of the GPU, into pinned memory and
+    # uploaded on a side stream; results come back asynchronously and are colour-coded in a consumer thread
+    first = load_image(os.path.join(args.source_path, img_list[0]))
+    padder = InputPadder(first.shape, 32)
+    paths = [os.path.join(args.source_path, f) for f in img_list]
+    frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image)
+    drain = ResultDrain(device)
+
+    def post(pred_u8, flow_f):
+        # pred_u8: [N-1, H, W, 3] uint8 RGB (truncated x255, reference video_Nx.py:140-148); flow_f: [N-1, 2, h, w]
+        fr = []
+        for i in range(pred_u8.shape[0]):
+            fimg = flow_to_image(flow_f[i].permute(1, 2, 0).numpy(), convert_to_bgr=True)
+            if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
+                fimg = np.array(Image.fromarray(fimg).resize((pred_u8.shape[2], pred_u8.shape[1]), Image.BILINEAR))
+            fr.append(np.stack([pred_u8[i].numpy()[:, :, ::-1], fimg], 0))
+        return np.stack(fr, 0)
+
+    coord_cache = {}
     for j in tqdm(range(p0, p1)):
-        I0 = load_image(os.path.join(args.source_path, img_list[j]))
-        I2 = load_image(os.path.join(args.source_path, img_list[j + 1]))
-        padder = InputPadder(I0.shape, 32)
-        I0p, I2p = padder.pad(I0, I2)
-        xs = torch.cat((I0p.unsqueeze(2), I2p.unsqueeze(2)), dim=2).to(device, non_blocking=True)
+        I0p, I2p = frames_in.get(j), frames_in.get(j + 1)
+        xs = torch.stack((I0p, I2p), dim=2)
         batch_size, s_shape = xs.shape[0], xs.shape[-2:]
         with torch.no_grad():
-            coord_inputs = [
-                (model.sample_coord_input(batch_size, s_shape, [1 / N * i], device=xs.device, upsample_ratio=ds_factor), None)
-                for i in range(1, N)
-            ]
-            timesteps = [i * 1 / N * torch.ones(batch_size, device=xs.device, dtype=torch.float) for i in range(1, N)]
+            key = (batch_size, tuple(s_shape))
+            if key not in coord_cache:     # the coordinate grids only depend on the frame size
+                coord_cache[key] = (
+                    [(model.sample_coord_input(batch_size, s_shape, [1 / N * i], device=xs.device,
+                                               upsample_ratio=ds_factor), None) for i in range(1, N)],
+                    [i * 1 / N * torch.ones(batch_size, device=xs.device, dtype=torch.float) for i in range(1, N)])
+            coord_inputs, timesteps = coord_cache[key]
             out = model(xs, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
-        frames = []
-        for i in range(N - 1):
-            pred = padder.unpad(out["imgt_pred"][i])[0]
-            flow = padder.unpad(out["flowt"][i]).squeeze()
-            fimg = flow_to_image(flow.detach().cpu().permute(1, 2, 0).numpy(), convert_to_bgr=True)
-            if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
-                fimg = np.array(Image.fromarray(fimg).resize((pred.shape[-1], pred.shape[-2]), Image.BILINEAR))
-            frames.append(np.stack([to_bgr_u8(pred), fimg], 0))
-        local_frames.append(np.stack(frames, 0))
+            preds = torch.stack([padder.unpad(out["imgt_pred"][i])[0] for i in range(N - 1)], 0)     # [N-1,3,H,W]
+            pred_u8 = model.engine(device).rt.frames_to_u8(preds.contiguous())                       # [N-1,H,W,3] RGB
+            flows = []
+            for i in range(N - 1):
+                u = padder.unpad(out["flowt"][i])
+                flows.append(u.reshape(2, *u.shape[-2:]))
+            flows = torch.stack(flows, 0).contiguous()
+        drain.submit(j, [pred_u8, flows], post)
+    results = drain.finish()
+    frames_in.close()
+    local_frames = [results[j] for j in range(p0, p1)]   # per pair: uint8 [N-1, 2, H, W, 3] (frame, flow image), BGR
     if local_frames:
         lf = torch.from_numpy(np.stack(local_frames, 0)).to(device)
     else:

@@ -1,0 +1,42 @@
+"""End-to-end throughput of the CLI (PNG decode -> pad -> H2D -> model -> D2H -> colour-coding), synthetic frames.
+usage: python tools/cli_bench.py [n_frames] [W] [H] [N]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "gimm-vfi_amd"))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 33
+    W = int(sys.argv[2]) if len(sys.argv) > 2 else 448
+    H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    N = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    with tempfile.TemporaryDirectory() as d:
+        src, out = os.path.join(d, "in"), os.path.join(d, "out")
+        os.makedirs(src)
+        x = synthetic_pairs(1, H, W, seed=0)[0]      # (3,2,H,W): reuse the two frames alternately with a shift
+        for i in range(n):
+            f = np.roll((x[:, i % 2].permute(1, 2, 0).numpy() * 255).astype(np.uint8), 3 * i, axis=1)
+            Image.fromarray(f).save(os.path.join(src, f"{i:04d}.png"))
+        cmd = [sys.executable, os.path.join(ROOT, "gimm-vfi_amd", "src", "video_Nx.py"), "--source-path", src,
+               "--output-path", out, "--N", str(N), "--ds-factor", "1.0", "-m",
+               os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml"), "--random-init", "--eval"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        print(r.stdout[-300:], r.stderr[-300:] if r.returncode else "")
+        print(f"CLI: {n} frames {W}x{H}, {N}x -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
+              f"(incl. process start, model build, graph capture, PNG/video writing)")
+
+
+if __name__ == "__main__":
+    main()
