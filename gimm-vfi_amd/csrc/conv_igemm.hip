@@ -294,6 +294,7 @@ extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {
     const gvfi_conv_params& p = *pp;
     if ((p.algo & 15) == 2 || (p.algo == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds(pp, stream);
     if (p.w_layout != 0) return -5;   // the chunked weight image is only understood by the LDS-DMA kernel
+    if (p.stats != nullptr) return -6;   // fused statistics exist only in the LDS-DMA kernel (gvfi_conv2d_stats_ok)
     const int ve = p.dtype == GVFI_F32 ? 4 : 8;
     if (p.c0 <= 0 || (p.c0 % ve) || (p.c1 % ve) || (p.ld0 % ve) || (p.c1 > 0 && (p.ld1 % ve))) return -2;
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15)) return -3;

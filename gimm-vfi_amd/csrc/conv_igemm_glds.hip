@@ -398,6 +398,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                       !(p.res && p.res_f32) && p.act1 <= GVFI_ACT_PRELU && p.act2 <= GVFI_ACT_PRELU;
     // (the 8-wave tile is never used for the GRU convolutions and has no registers for their operands)
     const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8;
+    float st_sum[8], st_sq[8];   // fused InstanceNorm statistics (p.stats): this thread's 8 channels over its rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_sum[e] = st_sq[e] = 0.f;
     __syncthreads();   // every wave is done reading the last staged chunk
 #pragma unroll   // at most 2 passes; unrolled so that a pass's staged accumulators are dead registers afterwards
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -430,6 +433,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             const bf16_t* rp = (const bf16_t*)p.res + pix0 * p.ldr + my_cout0;
             const float* cp = cs + row_a * BN + my_cg * 8;
             const bool has_res = p.res != nullptr, has_a2 = p.act2 != GVFI_ACT_NONE, has_sc = p.out_scale != 1.0f;
+            const bool do_stats = p.stats != nullptr;
             // residual vectors are fetched PF iterations at a time, all in flight together (the 8-wave tile, still
             // holding the other pass's accumulators, only has registers for 4)
             constexpr int PF = NT > 256 ? (ITERS < 2 ? ITERS : 2) : ITERS;
@@ -478,6 +482,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                     u.z = pack_bf16x2(vv[4], vv[5]);
                     u.w = pack_bf16x2(vv[6], vv[7]);
                     *(uint4*)(yp + (long long)tr * p.ldy) = u;
+                    if (do_stats) {   // statistics of the values as stored (bf16-rounded), like gvfi_instnorm_stats
+                        float sv[8];
+                        unpack_bf16x8(u, sv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            st_sum[e] += sv[e];
+                            st_sq[e] += sv[e] * sv[e];
+                        }
+                    }
                 }
             }
             if (ps + 1 < NPASS) __syncthreads();
@@ -552,6 +565,32 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
+    if (p.stats != nullptr) {   // (uniform: threads of channel groups beyond Cout carry zeros but must reach the barriers)
+        // workgroup reduction through the (now free) staging area: [thread][16] partials -> one atomic pair per channel.
+        // The tile lies inside one image (Ho*Wo % BM == 0, checked on the host).
+        __syncthreads();
+        float* red = cs;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[tid * 16 + e] = st_sum[e];
+            red[tid * 16 + 8 + e] = st_sq[e];
+        }
+        __syncthreads();
+        if (tid < BN) {   // channel n0 + tid: partials of the NT / GROUPS_PER_ROW threads that own its group
+            const int cgi = tid >> 3, e = tid & 7;
+            float s0 = 0.f, s1 = 0.f;
+            for (int t = cgi; t < NT; t += GROUPS_PER_ROW) {
+                s0 += red[t * 16 + e];
+                s1 += red[t * 16 + 8 + e];
+            }
+            const int c = n0 + tid;
+            if (c < p.Cout) {
+                const long long img = ((long long)g * a.Mg + m_tile0) / HoWo;
+                atomicAdd(p.stats + (img * p.Cout + c) * 2 + 0, s0);
+                atomicAdd(p.stats + (img * p.Cout + c) * 2 + 1, s1);
+            }
+        }
+    }
     stamp(5);
 #ifndef GVFI_HOSTSIM
     if (a.dbg & 128) {   // profiling only: time until this wave's stores are acknowledged
@@ -581,6 +620,20 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     dim3 grid(a.per_xcd * 8, 1, groups);
     GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
     return (int)hipGetLastError();
+}
+
+// fused statistics: only the LDS-DMA kernel's slim bf16 store loop accumulates them, and only when a tile cannot
+// straddle two images
+extern "C" int gvfi_conv2d_stats_ok(const gvfi_conv_params* pp) {
+    const gvfi_conv_params& p = *pp;
+    int plan[5];
+    if (p.dtype != GVFI_BF16 || (p.algo & 15) == 1 || !((p.algo & 15) == 2 || gvfi_conv2d_glds_eligible(pp))) return 0;
+    if (gvfi_conv2d_glds_plan(pp, plan) != 0) return 0;
+    if (p.epi_mode != GVFI_EPI_STD || p.y_f32 || (p.res && p.res_f32) || p.act1 > GVFI_ACT_PRELU || p.act2 > GVFI_ACT_PRELU)
+        return 0;
+    if ((p.groups > 1) || ((long long)p.Ho * p.Wo) % plan[1] != 0 || (p.Cout % 8) != 0) return 0;
+    if ((((uintptr_t)p.y) & 15) || ((p.ldy * 2) & 15) || (p.res && ((((uintptr_t)p.res) & 15) || ((p.ldr * 2) & 15)))) return 0;
+    return 1;
 }
 
 // 0 = not eligible, else the K-chunk row size in bytes (128 or 64) the LDS-DMA kernel would use
@@ -646,6 +699,7 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (rc) return rc;
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15)) return -3;
     if (p.groups > 1 && (p.N % p.groups)) return -4;
+    if (p.stats != nullptr && !gvfi_conv2d_stats_ok(pp)) return -6;   // statistics requested but not computable here
     hipStream_t st = (hipStream_t)stream;
     const int bm = plan[1], tile = plan[2], k = plan[3];
 #define GLDS_DISPATCH(TT)                                                                                     \

@@ -164,8 +164,9 @@ class Engine:
             lay = Ls[name]
             if inst:
                 raw = rt.act(n, h, w, cout)
-                rt.conv(lay, src, raw)
-                return rt.instnorm(raw, cout, relu=final_relu, res=res).t
+                stats = rt.f32(n, cout, 2, zero=True)
+                rt.conv(lay, src, raw, stats=stats)     # statistics fused into the convolution where possible
+                return rt.instnorm(raw, cout, relu=final_relu, res=res, stats=stats if rt.last_stats_fused else None).t
             out = rt.act(n, h, w, cout)
             rt.conv(lay, src, out, act1=A.ACT_RELU if final_relu else A.ACT_NONE, res=res,
                     act2=A.ACT_RELU if res is not None else A.ACT_NONE)

@@ -45,6 +45,7 @@ class ConvParams(C.Structure):
         ("y2", C.c_void_p), ("ldy2", C.c_int),
         ("aux0", C.c_void_p), ("lda0", C.c_int),
         ("aux1", C.c_void_p), ("lda1", C.c_int),
+        ("stats", C.c_void_p),
         ("tile_hint", C.c_int),
         ("w_layout", C.c_int),
         ("algo", C.c_int),

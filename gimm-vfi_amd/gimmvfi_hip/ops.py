@@ -193,6 +193,7 @@ class Runtime:
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
         self._side = None        # second stream for fork()
+        self.last_stats_fused = False
 
     # ------------------------------------------------------------------ memory
     def stream(self):
@@ -226,7 +227,10 @@ class Runtime:
     # ------------------------------------------------------------------ convolution
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0):
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None):
+        """stats: optional zero-initialised f32 [N, cout, 2]; when the library can fuse the InstanceNorm statistics
+        into this convolution (gvfi_conv2d_stats_ok) they are accumulated there and True is returned in
+        ``self.last_stats_fused``, else the caller computes them with instnorm_stats."""
         x0 = V(x0)
         out = V(out)
         p = L.ConvParams()
@@ -290,6 +294,14 @@ class Runtime:
             p.aux1, p.lda1 = aux1.ptr, aux1.ld
         p.tile_hint = tile
         p.algo = algo
+        p.stats = None
+        self.last_stats_fused = False
+        if stats is not None:
+            p.stats = stats.data_ptr()
+            if self.lib.conv2d_stats_ok(C.byref(p)) == 1:
+                self.last_stats_fused = True
+            else:
+                p.stats = None
         if self.ev_log is None:
             self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
         else:
@@ -328,12 +340,14 @@ class Runtime:
                                        self.stream()), "prep_images")
         return act, img4
 
-    def instnorm(self, x, c, relu, res=None, out=None):
+    def instnorm(self, x, c, relu, res=None, out=None, stats=None):
+        """stats: [n, c, 2] already accumulated by the producing convolution (Runtime.conv(stats=...)), else None."""
         x = V(x)
         n, h, w = x.t.shape[:3]
-        stats = self.f32(n, c, 2, zero=True)
-        self._chk(self.lib.instnorm_stats(x.ptr, x.ld, c, n, h * w, stats.data_ptr(), self.dtype, self.stream()),
-                  "instnorm_stats")
+        if stats is None:
+            stats = self.f32(n, c, 2, zero=True)
+            self._chk(self.lib.instnorm_stats(x.ptr, x.ld, c, n, h * w, stats.data_ptr(), self.dtype, self.stream()),
+                      "instnorm_stats")
         out = V(self.act(n, h, w, c) if out is None else out)
         r = None if res is None else V(res)
         self._chk(self.lib.instnorm_apply(x.ptr, x.ld, c, n, h * w, stats.data_ptr(), 1 if relu else 0,

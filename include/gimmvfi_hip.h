@@ -64,6 +64,10 @@ typedef struct {
     void* y2; int ldy2;                 /* GRU_ZR: r*h destination                          */
     const void* aux0; int lda0;         /* GRU: h                                           */
     const void* aux1; int lda1;         /* GRU_Q: z                                         */
+    float* stats;                       /* optional [N][Cout][2]: per (image, channel) sum and sum of squares of the stored
+                                         * outputs, atomically accumulated by the LDS-DMA kernel's bf16 store loop
+                                         * (InstanceNorm statistics of raft/extractor.py:26-58 fused into the producing
+                                         * convolution); needs Ho*Wo % BM == 0, see gvfi_conv2d_stats_ok */
     int tile_hint;                      /* 0 = auto, else BN | BM << 10: Cout tile width 32/64/128/256 and (LDS-DMA kernel,
                                          * BN = 128) pixel tile height 64/128 (BN = 128) or 128/256 (BN = 32) */
     int w_layout;                       /* 0: [Cout][KH][KW][Cin];  1 (LDS-DMA kernel only): K-chunk major,  *
@@ -82,6 +86,8 @@ int gvfi_conv2d(const gvfi_conv_params* p, void* stream);
  * LDS stages} */
 int gvfi_conv2d_plan(const gvfi_conv_params* p, int* plan);
 int gvfi_conv2d_glds_plan(const gvfi_conv_params* p, int* plan);
+/* 1 when gvfi_conv2d would accumulate p->stats for this problem (else the caller runs gvfi_instnorm_stats) */
+int gvfi_conv2d_stats_ok(const gvfi_conv_params* p);
 /* the two kernels behind gvfi_conv2d (exposed for A/B measurements) */
 int gvfi_conv2d_glds_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);

@@ -163,6 +163,34 @@ def patch_conv_case(rt, N=2, H=10, W=13, Cin=2, Cout=24, KH=7, KW=7):
     assert err <= tol(rt, 4.0), err
 
 
+def conv_stats_case(rt, N=2, H=16, W=16, Cin=64, Cout=64, tile=0):
+    """InstanceNorm statistics fused into the convolution's store loop == sums over the stored tensor."""
+    assert rt.precision == "bf16"
+    g = torch.Generator().manual_seed(14)
+    x = _rounded(rt, torch.randn(N, Cin, H, W, generator=g))
+    w = _rounded(rt, torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    dev = _dev(rt)
+    lay = ConvLayer(rt, w, b)
+    xa = _to_act(rt, x).to(dev)
+    out = rt.act(N, H, W, Cout)
+    stats = rt.f32(N, Cout, 2, zero=True)
+    rt.conv(lay, xa, out, stats=stats, tile=tile)
+    assert rt.last_stats_fused
+    o = out.float().cpu()
+    ref = torch.stack([o.sum((1, 2)), (o * o).sum((1, 2))], -1)          # [N, Cout, 2] of the stored (rounded) values
+    err = float((stats.cpu() - ref).abs().max())
+    assert err <= 1e-3 * float(ref.abs().max()), err
+    # and the normalisation that consumes them equals F.instance_norm of the stored tensor
+    y = rt.instnorm(out, Cout, relu=False, stats=stats).t.float().cpu()
+    n = F.instance_norm(o.permute(0, 3, 1, 2), eps=1e-5).permute(0, 2, 3, 1)
+    assert float((y - n).abs().max()) <= tol(rt, 4.0)
+    # a shape whose tiles straddle images is refused (caller falls back to gvfi_instnorm_stats)
+    out2 = rt.act(N, H - 1, W - 5, Cout)
+    rt.conv(lay, _to_act(rt, x[:, :, :H - 1, :W - 5]).to(dev), out2, stats=rt.f32(N, Cout, 2, zero=True))
+    assert not rt.last_stats_fused
+
+
 def tap_split_conv_case(rt, N=2, H=9, W=12, Cin=64, Cout=2):
     """1x1 to per-tap partial sums + gvfi_tap_sum == the 3x3 zero-padded convolution with residual, in place
     (raft/update.py:6-14, raft/raft.py:157 coords1 = coords1 + delta_flow)."""

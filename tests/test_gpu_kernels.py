@@ -65,6 +65,13 @@ def test_corr_volume_grouped_gemm(rt):
     kc.corr_volume_case(rt, B=2, h=32, w=56, C=256, seed=3)
 
 
+def test_conv_fused_instnorm_stats(rt):
+    if rt.precision != "bf16":
+        pytest.skip("fused statistics live in the bf16 store loop; fp32 runs gvfi_instnorm_stats")
+    kc.conv_stats_case(rt)
+    kc.conv_stats_case(rt, N=1, H=8, W=16, Cin=64, Cout=96)
+
+
 def test_tap_split_conv(rt):
     kc.tap_split_conv_case(rt)
 
