@@ -385,8 +385,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                          vec_ok(p.y2, p.ldy2, (int)sizeof(T)) && vec_ok(p.aux0, p.lda0, (int)sizeof(T)) &&
                          vec_ok(p.aux1, p.lda1, (int)sizeof(T)) &&
                          (p.bias == nullptr || true);
-    if (!GC_EARLY) load_gc();
+    // (8-wave tile) uniform: plain activation epilogue that can be applied in the accumulator layout, see below
+    const bool direct16 = NW >= 8 && sizeof(T) == 2 && BM * BN * 2 <= NSTAGE * STAGE && p.epi_mode == GVFI_EPI_STD &&
+                          vec_all && !p.y_f32 && p.res == nullptr && p.act1 <= GVFI_ACT_PRELU &&
+                          p.act2 == GVFI_ACT_NONE && n0 + BN <= p.Cout;
+    if (!GC_EARLY && !direct16) load_gc();
 #ifndef GVFI_HOSTSIM
+    if (GC_EARLY || !direct16)
     // Make the compiler wait for the bias / slope loads HERE.  Their first real use is inside the store loop; the
     // s_waitcnt vmcnt(0) it would put there also waits, in every iteration, for the previous iteration's global
     // store to be acknowledged (stores share the counter): ~1500 cycles x 8-16 iterations per tile, 15 % of the
@@ -398,10 +403,54 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                       !(p.res && p.res_f32) && p.act1 <= GVFI_ACT_PRELU && p.act2 <= GVFI_ACT_PRELU;
     // (the 8-wave tile is never used for the GRU convolutions and has no registers for their operands)
     const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8;
-    float st_sum[8], st_sq[8];   // fused InstanceNorm statistics (p.stats): this thread's 8 channels over its rows
+    // fused InstanceNorm statistics (p.stats): this thread's 8 channels over its rows.  4-wave tiles only (the layers
+    // that are normalised have <= 128 channels; the 8-wave tile has no registers to spare)
+    constexpr bool STATS = NW <= 4;
+    float st_sum[STATS ? 8 : 1], st_sq[STATS ? 8 : 1];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) st_sum[e] = st_sq[e] = 0.f;
+    for (int e = 0; e < (STATS ? 8 : 1); ++e) st_sum[e] = st_sq[e] = 0.f;
     __syncthreads();   // every wave is done reading the last staged chunk
+    bool done16 = false;
+    if constexpr (NW >= 8 && sizeof(T) == 2 && BM * BN * 2 <= NSTAGE * STAGE) {
+        // ---- 8-wave tile, plain activation epilogue (4 of the 5 convolutions of a ResBlock): bias + activation are
+        // applied in the accumulator layout (a lane owns ONE output channel per 32-column block, so they are per-lane
+        // scalars), the bf16 result is staged -- the whole 256x256 tile fits the ring once, instead of two fp32
+        // passes -- and the store loop only moves 16-byte vectors.  Same arithmetic and rounding as the loop below.
+        if (direct16) {
+            bf16_t* cs16 = (bf16_t*)smem;
+            const float f1 = p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f);
+            const bool has_sc = p.out_scale != 1.0f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = wn * WN + j * 32 + frow;
+                const float bj = p.bias ? p.bias[n0 + col] : 0.f;
+                const float sj = p.act1 == GVFI_ACT_PRELU ? p.slope1[n0 + col] : f1;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                        const float t = acc[i][j][r] + bj;
+                        float v = fmaxf(t, 0.f) + sj * fminf(t, 0.f);
+                        if (has_sc) v *= p.out_scale;
+                        cs16[row * BN + col] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int ITERS16 = (BM * GROUPS_PER_ROW) / NT, ROWS_PER_IT = NT / GROUPS_PER_ROW;
+            const int row_a = tid / GROUPS_PER_ROW;
+            bf16_t* yp = (bf16_t*)p.y + ((long long)g * a.Mg + m_tile0) * p.ldy + my_cout0;
+#pragma unroll 4
+            for (int it = 0; it < ITERS16; ++it) {
+                const int row = row_a + it * ROWS_PER_IT;
+                if (m_tile0 + row >= a.Mg) continue;
+                *(uint4*)(yp + (long long)row * p.ldy) = *(const uint4*)(cs16 + row * BN + my_cg * 8);
+            }
+            done16 = true;
+        }
+    }
+    if (!done16)
 #pragma unroll   // at most 2 passes; unrolled so that a pass's staged accumulators are dead registers afterwards
     for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
@@ -433,7 +482,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             const bf16_t* rp = (const bf16_t*)p.res + pix0 * p.ldr + my_cout0;
             const float* cp = cs + row_a * BN + my_cg * 8;
             const bool has_res = p.res != nullptr, has_a2 = p.act2 != GVFI_ACT_NONE, has_sc = p.out_scale != 1.0f;
-            const bool do_stats = p.stats != nullptr;
+            const bool do_stats = STATS && p.stats != nullptr;
             // residual vectors are fetched PF iterations at a time, all in flight together (the 8-wave tile, still
             // holding the other pass's accumulators, only has registers for 4)
             constexpr int PF = NT > 256 ? (ITERS < 2 ? ITERS : 2) : ITERS;
@@ -482,13 +531,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                     u.z = pack_bf16x2(vv[4], vv[5]);
                     u.w = pack_bf16x2(vv[6], vv[7]);
                     *(uint4*)(yp + (long long)tr * p.ldy) = u;
-                    if (do_stats) {   // statistics of the values as stored (bf16-rounded), like gvfi_instnorm_stats
-                        float sv[8];
-                        unpack_bf16x8(u, sv);
+                    if constexpr (STATS) {
+                        if (do_stats) {   // statistics of the values as stored (bf16-rounded), like gvfi_instnorm_stats
+                            float sv[8];
+                            unpack_bf16x8(u, sv);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            st_sum[e] += sv[e];
-                            st_sq[e] += sv[e] * sv[e];
+                            for (int e = 0; e < 8; ++e) {
+                                st_sum[e] += sv[e];
+                                st_sq[e] += sv[e] * sv[e];
+                            }
                         }
                     }
                 }
@@ -565,6 +616,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
+    if constexpr (STATS)
     if (p.stats != nullptr) {   // (uniform: threads of channel groups beyond Cout carry zeros but must reach the barriers)
         // workgroup reduction through the (now free) staging area: [thread][16] partials -> one atomic pair per channel.
         // The tile lies inside one image (Ho*Wo % BM == 0, checked on the host).
@@ -628,7 +680,7 @@ extern "C" int gvfi_conv2d_stats_ok(const gvfi_conv_params* pp) {
     const gvfi_conv_params& p = *pp;
     int plan[5];
     if (p.dtype != GVFI_BF16 || (p.algo & 15) == 1 || !((p.algo & 15) == 2 || gvfi_conv2d_glds_eligible(pp))) return 0;
-    if (gvfi_conv2d_glds_plan(pp, plan) != 0) return 0;
+    if (gvfi_conv2d_glds_plan(pp, plan) != 0 || plan[2] >= 256) return 0;   // (not in the 8-wave tile)
     if (p.epi_mode != GVFI_EPI_STD || p.y_f32 || (p.res && p.res_f32) || p.act1 > GVFI_ACT_PRELU || p.act2 > GVFI_ACT_PRELU)
         return 0;
     if ((p.groups > 1) || ((long long)p.Ho * p.Wo) % plan[1] != 0 || (p.Cout % 8) != 0) return 0;

@@ -252,7 +252,7 @@ class Engine:
             taps["r01_corr_l0"] = pyr_a[0]
             taps["r01_corr_l3"] = pyr_a[3]
         coords = rt.coords_init(n, h8, w8)
-        corrf = rt.act(n, h8, w8, 324, zero=True, pitch=rt.cp64(324))
+        corrf = rt.act(n, h8, w8, 324, zero=True, pitch=rt.cp64(324), zero_pad_only=True)
         flow8 = rt.act(n, h8, w8, 2, zero=True)
         c1 = rt.act(n, h8, w8, 256)
         corflo = rt.act(n, h8, w8, 256)
@@ -554,7 +554,7 @@ class Engine:
         rt.resize(ft0, 2, 0.25, mul=0.25, out=View(fl4in, 0, 2))
         rt.resize(ft1, 2, 0.25, mul=0.25, out=View(fl4in, 2, 2))
         # ---- NewInitDecoder  fi_components.py:255-276
-        f_in = rt.act(B, h4, w4, 272, zero=True, pitch=rt.cp64(272))
+        f_in = rt.act(B, h4, w4, 272, zero=True, pitch=rt.cp64(272), zero_pad_only=True)
         rt.warp(up8[:B], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
         rt.warp(up8[B:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
         rt.copy(View(fl4in, 0, 4), View(f_in, 256, 4), 4)
@@ -591,7 +591,7 @@ class Engine:
         c0, c1 = rt.f32(B, h8, w8, 2), rt.f32(B, h8, w8, 2)
         rt._chk(lib.lookup_coords(fl0.data_ptr(), fl1.data_ptr(), tv.data_ptr(), c0.data_ptr(), c1.data_ptr(), B, h8,
                                   w8, st()), "lookup_coords")
-        corr = rt.act(B, h8, w8, 648, zero=True, pitch=rt.cp64(648))
+        corr = rt.act(B, h8, w8, 648, zero=True, pitch=rt.cp64(648), zero_pad_only=True)
         rt.corr_lookup(pyr, c0, View(corr, 0, 324), B, h8, w8, h8, w8)
         rt.corr_lookup(pyrT, c1, View(corr, 324, 324), B, h8, w8, h8, w8)
         flow_lr = rt.f32(B, h8, w8, 4)
@@ -599,7 +599,7 @@ class Engine:
         rt.copy(fl1, View(flow_lr, 2, 2), 2)
         net_lr = rt.resize(ft_4, 128, 0.5).t
         self._amt_update("amt_update4_low", net_lr, flow_lr, corr, B, h8, w8, st4, ft_4, low=True)
-        corr_up = rt.act(B, h4, w4, 648, zero=True, pitch=rt.cp64(648))
+        corr_up = rt.act(B, h4, w4, 648, zero=True, pitch=rt.cp64(648), zero_pad_only=True)
         rt.resize(View(corr, 0, 648), 648, 2.0, out=View(corr_up, 0, 648))
         flow4 = rt.f32(B, h4, w4, 4)
         rt.copy(View(st4, 0, 4), flow4, 4)
@@ -611,7 +611,7 @@ class Engine:
         fl0u = rt.resize(View(st4, 0, 2), 2, 4.0, mul=4.0).t
         fl1u = rt.resize(View(st4, 2, 2), 2, 4.0, mul=4.0).t
         mku = rt.resize(mask_4, 1, 4.0).t
-        fin = rt.act(B, H, W, 273, zero=True, pitch=rt.cp64(273))
+        fin = rt.act(B, H, W, 273, zero=True, pitch=rt.cp64(273), zero_pad_only=True)
         rt.resize(ft_4, 128, 4.0, out=View(fin, 0, 128))
         rt.warp(up4[:B], 64, fl0u, View(fin, 128, 64))
         rt.warp(up4[B:], 64, fl1u, View(fin, 192, 64))

@@ -33,7 +33,9 @@ CONV_SHAPES = [
     (2, 64, 112, 273, 24, 3, 3, dict(out_f32=True)),                                         # 273-channel concat
     (1, 40, 40, 648, 256, 1, 1, dict(act1=L.ACT_LRELU)),
     (1, 33, 47, 18, 3, 7, 7, dict(out_f32=True, with_res=True)),                              # comb block, ragged size
-    (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),  # 8-wave tile, ragged
+    (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
+    (1, 17, 19, 64, 256, 3, 3, dict(tile=256, act1=L.ACT_PRELU)),   # 8-wave tile, bf16-staged activation epilogue
+    (1, 9, 19, 64, 256, 1, 1, dict(tile=256, act1=L.ACT_LRELU, out_scale=0.5)),  # 8-wave tile, ragged
     (4, 128, 224, 256, 256, 3, 3, dict(act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),   # auto -> 256x256 tile
     (4, 128, 224, 256, 256, 3, 3, dict(split=192, tile=128)),                                # same, 128-wide tile
     (2, 64, 112, 128, 128, 3, 3, dict(algo=1, act1=L.ACT_LRELU)),                             # generic kernel on an aligned shape

@@ -29,7 +29,9 @@ CONV_SHAPES = [
     (2, 7, 7, 64, 130, 3, 3, dict(stride=2, out_f32=True)),
     (1, 9, 9, 64, 40, 3, 3, dict(reflect=True, with_res=True, act2=L.ACT_LRELU)),
     (1, 6, 10, 64, 70, 3, 3, dict(act1=L.ACT_RELU, with_res=True, algo=1)),   # same shape, generic kernel
-    (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),  # 8-wave 256x256 tile
+    (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
+    (1, 17, 19, 64, 256, 3, 3, dict(tile=256, act1=L.ACT_PRELU)),   # 8-wave tile, bf16-staged activation epilogue
+    (1, 9, 19, 64, 256, 1, 1, dict(tile=256, act1=L.ACT_LRELU, out_scale=0.5)),  # 8-wave 256x256 tile
     (1, 9, 11, 128, 24, 3, 3, dict(out_f32=True)),        # Cout <= 32 on the LDS-DMA kernel (128x32 tile)
     (2, 6, 7, 64, 2, 3, 3, dict(out_f32=True, with_res=True)),
     # selectable LDS-DMA variants: 64-row tiles, 64-byte chunks with the 4-deep ring (counted vmcnt), tall 256-row tiles
