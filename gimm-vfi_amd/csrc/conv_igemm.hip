@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
                     v *= p.out_scale;
                     st_any<T>(p.y, pix * p.ldy + cout, p.y_f32, v);
                 } else if (p.epi_mode == GVFI_EPI_GRU_ZR) {
+                    if (p.res) v += ld_any<T>(p.res, pix * p.ldr + cout, p.res_f32);   // hoisted context term
                     const float s = gvfi_sigmoid(v);
                     if (cout < half) {
                         st_any<T>(p.y, pix * p.ldy + cout, 0, s);
@@ -239,6 +240,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
                         st_any<T>(p.y2, pix * p.ldy2 + c, 0, s * h);
                     }
                 } else {  // GVFI_EPI_GRU_Q
+                    if (p.res) v += ld_any<T>(p.res, pix * p.ldr + cout, p.res_f32);
                     const float q = tanhf(v);
                     const float h = ld_any<T>(p.aux0, pix * p.lda0 + cout, 0);
                     const float z = ld_any<T>(p.aux1, pix * p.lda1 + cout, 0);

@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && my_valid == 8 && !p.y_f32 &&
                       !(p.res && p.res_f32) && p.act1 <= GVFI_ACT_PRELU && p.act2 <= GVFI_ACT_PRELU;
     // (the 8-wave tile is never used for the GRU convolutions and has no registers for their operands)
-    const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8;
+    const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8 &&
+                          (p.res == nullptr || p.res_f32);
     // fused InstanceNorm statistics (p.stats): this thread's 8 channels over its rows.  4-wave tiles only (the layers
     // that are normalised have <= 128 channels; the 8-wave tile has no registers to spare)
     constexpr bool STATS = NW <= 4;
@@ -563,6 +564,22 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             const bf16_t* hp = (const bf16_t*)p.aux0 + pix0 * p.lda0 + c0;
             const bf16_t* zp = (const bf16_t*)p.aux1 + pix0 * p.lda1 + c0;
             const float* cp = cs + row_a * BN + my_cg * 8;
+            // pre-activation context term (f32 [pixel][Cout]): the part of the gate convolution that reads RAFT's
+            // constant context features is evaluated once per forward, not once per iteration
+            const float* rp = (const float*)p.res + pix0 * p.ldr + my_cout0;
+            const bool has_ctx = p.res != nullptr;
+            uint4 cpre[ITERS][2];
+            if (has_ctx) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
+                    if (m_tile0 + tr < a.Mg) {
+                        const uint4* q4 = (const uint4*)(rp + (long long)tr * p.ldr);
+                        cpre[it][0] = q4[0];
+                        cpre[it][1] = q4[1];
+                    }
+                }
+            }
             uint4 hpre[ITERS], zpre[ITERS];
             if (!zhalf) {
 #pragma unroll
@@ -584,6 +601,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                 float hh[8], zz[8];
                 if (!zhalf) unpack_bf16x8(hpre[it], hh);
                 if (is_q) unpack_bf16x8(zpre[it], zz);
+                if (has_ctx) {
+                    vv[0] += __builtin_bit_cast(float, cpre[it][0].x); vv[1] += __builtin_bit_cast(float, cpre[it][0].y);
+                    vv[2] += __builtin_bit_cast(float, cpre[it][0].z); vv[3] += __builtin_bit_cast(float, cpre[it][0].w);
+                    vv[4] += __builtin_bit_cast(float, cpre[it][1].x); vv[5] += __builtin_bit_cast(float, cpre[it][1].y);
+                    vv[6] += __builtin_bit_cast(float, cpre[it][1].z); vv[7] += __builtin_bit_cast(float, cpre[it][1].w);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = vv[e] + gc.bias[e];

@@ -238,6 +238,11 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         }
     } else if (p.epi_mode == GVFI_EPI_GRU_ZR) {
         const int half = p.Cout >> 1;   // groups never straddle the z / r halves (half % 8 == 0 checked on the host)
+        if (p.res) {   // pre-activation term hoisted out of the recurrence (the context part of the gate convolution)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < n_valid) v[e] += ld_any<T>(p.res, pix * p.ldr + cout0 + e, p.res_f32);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gvfi_sigmoid(v[e]);
         if (cout0 < half) {
@@ -263,6 +268,11 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
             }
         }
     } else {  // GVFI_EPI_GRU_Q
+        if (p.res) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < n_valid) v[e] += ld_any<T>(p.res, pix * p.ldr + cout0 + e, p.res_f32);
+        }
         float h[8], z[8];
         if (vec) {
             ld8(p.aux0, pix * p.lda0 + cout0, 0, BF, h);

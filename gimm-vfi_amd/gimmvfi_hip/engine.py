@@ -125,8 +125,17 @@ class Engine:
         for n in ("1", "2"):
             wz, wr = sd[f"{u}.gru.convz{n}.weight"], sd[f"{u}.gru.convr{n}.weight"]
             bz, br = sd[f"{u}.gru.convz{n}.bias"], sd[f"{u}.gru.convr{n}.bias"]
-            self._add(f"gru.zr{n}", torch.cat([wz, wr], 0), torch.cat([bz, br], 0))
-            self._conv(sd, f"{u}.gru.convq{n}", name=f"gru.q{n}")
+            # hx = [h(128) | inp(128) | motion(126) | flow(2)]  (raft/update.py:143-144, 58-73).  The context features
+            # `inp` do not change over the 20 iterations, so their share of every gate convolution is evaluated once
+            # per forward ("ctx" layers, bias included) and enters the recurrence as a pre-activation term; the
+            # per-iteration convolution only reads [h | motion | flow] (256 of the 384 channels).
+            wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
+            wq, bq = sd[f"{u}.gru.convq{n}.weight"], sd[f"{u}.gru.convq{n}.bias"]
+            keep = list(range(0, 128)) + list(range(256, 384))
+            self._add(f"gru.zr{n}", wzr[:, keep], None)
+            self._add(f"gru.q{n}", wq[:, keep], None)
+            self._add(f"gru.zr{n}.ctx", wzr[:, 128:256], bzr)
+            self._add(f"gru.q{n}.ctx", wq[:, 128:256], bq)
         for k in ("amt_last_cproj", "amt_second_last_cproj", "amt_fproj"):
             self._conv(sd, k)
         p = "amt_init_decoder"
@@ -261,6 +270,12 @@ class Engine:
         rh = rt.act(n, h8, w8, 128)
         fh = rt.act(n, h8, w8, 256)
         u = fe + ".update_block"
+        # context share of the four gate convolutions (f32, evaluated once): see _build
+        ctx = {}
+        for key in ("gru.zr1", "gru.q1", "gru.zr2", "gru.q2"):
+            lay = Ls[key + ".ctx"]
+            ctx[key] = rt.f32(n, h8, w8, lay.cout)
+            rt.conv(lay, View(xbuf, 0, 128), ctx[key])
         fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
         fpart = rt.f32(n, h8, w8, 20)   # 9 taps x 2 partial sums of the flow head (+ pad)
         for it in range(iters):
@@ -277,8 +292,9 @@ class Engine:
             rt.conv(Ls[u + ".encoder.conv"], corflo, View(xbuf, 128, 126), act1=A.ACT_RELU)
             hc, hn = hA, hB
             for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73
-                rt.conv(Ls["gru.zr" + nn_], hc, zbuf, x1=xbuf, epi=A.EPI_GRU_ZR, y2=rh, aux0=hc)
-                rt.conv(Ls["gru.q" + nn_], rh, hn, x1=xbuf, epi=A.EPI_GRU_Q, aux0=hc, aux1=zbuf)
+                xm = View(xbuf, 128, 128)   # [motion(126) | flow(2)]
+                rt.conv(Ls["gru.zr" + nn_], hc, zbuf, x1=xm, epi=A.EPI_GRU_ZR, y2=rh, aux0=hc, res=ctx["gru.zr" + nn_])
+                rt.conv(Ls["gru.q" + nn_], rh, hn, x1=xm, epi=A.EPI_GRU_Q, aux0=hc, aux1=zbuf, res=ctx["gru.q" + nn_])
                 hc, hn = hn, hc
             # after two passes the state is back in hA
             rt.conv(Ls[u + ".flow_head.conv1"], hA, fh, act1=A.ACT_RELU)

@@ -34,9 +34,12 @@ enum {
 enum { GVFI_PAD_ZEROS = 0, GVFI_PAD_REFLECT = 1 };
 enum {
     GVFI_EPI_STD = 0,    /* y = act2(act1(acc + bias) + res) * out_scale                       */
-    GVFI_EPI_GRU_ZR = 1, /* cout <  Cout/2: y  = sigmoid(acc+bias)            (z gate)          *
-                          * cout >= Cout/2: y2 = sigmoid(acc+bias) * aux0     (r * h)           */
-    GVFI_EPI_GRU_Q = 2   /* y = (1 - aux1) * aux0 + aux1 * tanh(acc+bias)     (h update)        */
+    GVFI_EPI_GRU_ZR = 1, /* cout <  Cout/2: y  = sigmoid(acc+bias+res)        (z gate)          *
+                          * cout >= Cout/2: y2 = sigmoid(acc+bias+res) * aux0 (r * h)           */
+    GVFI_EPI_GRU_Q = 2   /* y = (1 - aux1) * aux0 + aux1 * tanh(acc+bias+res) (h update)        *
+                          * res (optional, [pixel][Cout]): pre-activation term evaluated outside *
+                          * the recurrence -- the gate convolution's share of RAFT's constant    *
+                          * context features (raft/update.py:58-73, raft/raft.py:134-136)        */
 };
 
 /* Implicit-GEMM convolution on the matrix cores (MFMA), NHWC, fused epilogue.

@@ -121,12 +121,16 @@ class SimRuntime(Runtime):
             v = _act(v, act2, slope2) * out_scale
             out.t[..., out.coff:out.coff + cout] = v.to(out.t.dtype)
         elif epi == L.EPI_GRU_ZR:
+            if res is not None:
+                v = v + self._sl(V(res), cout)
             s = torch.sigmoid(v)
             half = cout // 2
             out.t[..., out.coff:out.coff + half] = s[..., :half].to(out.t.dtype)
             y2 = V(y2)
             y2.t[..., y2.coff:y2.coff + half] = (s[..., half:] * self._sl(V(aux0), half)).to(y2.t.dtype)
         else:
+            if res is not None:
+                v = v + self._sl(V(res), cout)
             q = torch.tanh(v)
             h = self._sl(V(aux0), cout)
             z = self._sl(V(aux1), cout)

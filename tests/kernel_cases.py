@@ -92,7 +92,7 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     return err
 
 
-def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5):
+def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5, ctx_split=False):
     """SepConvGRU half step with the fused epilogues (raft/update.py:58-66)."""
     g = torch.Generator().manual_seed(seed)
     h = _rounded(rt, torch.tanh(torch.randn(N, C, H, W, generator=g)))
@@ -104,8 +104,22 @@ def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5):
     lq = ConvLayer(rt, wq, bq)
     ha, xa = _to_act(rt, h).to(dev), _to_act(rt, x).to(dev)
     zb, rh, hn = rt.act(N, H, W, C), rt.act(N, H, W, C), rt.act(N, H, W, C)
-    rt.conv(lzr, ha, zb, x1=xa, epi=L.EPI_GRU_ZR, y2=rh, aux0=ha)
-    rt.conv(lq, rh, hn, x1=xa, epi=L.EPI_GRU_Q, aux0=ha, aux1=zb)
+    if not ctx_split:
+        rt.conv(lzr, ha, zb, x1=xa, epi=L.EPI_GRU_ZR, y2=rh, aux0=ha)
+        rt.conv(lq, rh, hn, x1=xa, epi=L.EPI_GRU_Q, aux0=ha, aux1=zb)
+    else:
+        # the first C channels of x play RAFT's constant context: their share of both convolutions is a separate
+        # (bias-carrying) convolution evaluated once, handed to the gate epilogues as a pre-activation term
+        keep = list(range(0, C)) + list(range(2 * C, 3 * C))
+        wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
+        lzr_m, lq_m = ConvLayer(rt, wzr[:, keep], None), ConvLayer(rt, wq[:, keep], None)
+        lzr_c, lq_c = ConvLayer(rt, wzr[:, C:2 * C], bzr), ConvLayer(rt, wq[:, C:2 * C], bq)
+        czr, cq = rt.f32(N, H, W, 2 * C), rt.f32(N, H, W, C)
+        rt.conv(lzr_c, View(xa, 0, C), czr)
+        rt.conv(lq_c, View(xa, 0, C), cq)
+        xm = View(xa, C, C)
+        rt.conv(lzr_m, ha, zb, x1=xm, epi=L.EPI_GRU_ZR, y2=rh, aux0=ha, res=czr)
+        rt.conv(lq_m, rh, hn, x1=xm, epi=L.EPI_GRU_Q, aux0=ha, aux1=zb, res=cq)
     pad = (kh // 2, kw // 2)
     hx = torch.cat([h, x], 1)
     z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=pad))

@@ -54,6 +54,8 @@ def test_gru_epilogues(rt):
     kc.gru_case(rt, kh=1, kw=5)
     kc.gru_case(rt, kh=5, kw=1, seed=1)
     kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=1, kw=5, seed=2)   # 64-multiples -> LDS-DMA kernel and its GRU store loops
+    kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=5, kw=1, seed=3, ctx_split=True)   # hoisted context term (LDS-DMA kernel)
+    kc.gru_case(rt, kh=1, kw=5, seed=4, ctx_split=True)                          # same on the generic kernel
 
 
 def test_corr_volume_grouped_gemm(rt):
