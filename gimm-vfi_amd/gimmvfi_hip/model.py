@@ -63,6 +63,7 @@ class GIMMVFI_R(nn.Module):
         # so eager mode is host-bound as soon as the kernels are fast.  GIMMVFI_GRAPH=0 disables it.
         self.use_graph = os.environ.get("GIMMVFI_GRAPH", "1") != "0"
         self._graphs = {}
+        self.max_graphs = 4      # captured graphs keep their intermediates alive (GBs at 2K): bounded cache
 
     # ---- engine cache invalidation: weights are folded/packed for the kernels lazily
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -101,7 +102,17 @@ class GIMMVFI_R(nn.Module):
         eng = self.engine(img_xs.device)
         if not (self.use_graph and img_xs.is_cuda and eng.rt.ev_log is None):
             return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
-        return self._forward_graph(eng, img_xs, coord, t, iters, ds_factor)
+        try:
+            return self._forward_graph(eng, img_xs, coord, t, iters, ds_factor)
+        except RuntimeError as e:
+            # capture can fail for reasons outside this package (another capture in progress, allocator limits);
+            # the eager launch list is the same kernels -- never a different arithmetic path
+            if "capture" not in str(e).lower() and "graph" not in str(e).lower():
+                raise
+            self.use_graph = False
+            self._graphs = {}
+            torch.cuda.synchronize(img_xs.device)
+            return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
 
     def _forward_graph(self, eng, img_xs, coord, t, iters, ds_factor):
         """Capture once per input signature, then replay; inputs are copied into the graph's static buffers and
@@ -110,6 +121,8 @@ class GIMMVFI_R(nn.Module):
             assert isinstance(c, tuple) and c[1] is None, "sub-sampled coordinates are a training feature"
         key = (tuple(img_xs.shape), str(img_xs.device), tuple(tuple(c[0].shape) for c in coord), len(t), ds_factor)
         ent = self._graphs.get(key)
+        if ent is None and len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))     # oldest signature: its private memory pool is released
         if ent is None:
             dev = img_xs.device
             sx = img_xs.detach().to(torch.float32).contiguous().clone()

@@ -1,0 +1,75 @@
+"""Flow-benchmark driver of the motion-only model (reference src/VTF.py) on a synthetic Vimeo-triplet-flow tree."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import ROOT
+
+SRC = os.path.join(ROOT, "gimm-vfi_amd", "src")
+
+
+def _tree(tmp_path, n=2, H=64, W=96):
+    sys.path.insert(0, SRC)
+    from utils.frame_utils import writeFlow
+
+    root = tmp_path / "vimeo_triplet"
+    names = []
+    g = torch.Generator().manual_seed(5)
+    for k in range(n):
+        name = f"0000{k}/0001"
+        d = root / "flow_sequences" / name
+        os.makedirs(d)
+        low = torch.randn(1, 2, H // 8, W // 8, generator=g) * 3.0
+        f13 = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)[0].permute(1, 2, 0)
+        for fn, fl in (("im1_im3", f13), ("im3_im1", -f13), ("im2_im3", 0.5 * f13), ("im2_im1", -0.5 * f13)):
+            writeFlow(str(d / (fn + ".flo")), fl.numpy())
+        names.append(name)
+    (root / "tri_testlist.txt").write_text("\n".join(names) + "\n")
+    return str(root)
+
+
+def test_flo_roundtrip_and_bad_magic(tmp_path):
+    sys.path.insert(0, SRC)
+    from utils.frame_utils import readFlow, writeFlow
+
+    uv = np.random.RandomState(0).randn(7, 11, 2).astype(np.float32)
+    p = str(tmp_path / "a.flo")
+    writeFlow(p, uv)
+    assert np.array_equal(readFlow(p), uv)
+    assert os.path.getsize(p) == 12 + 7 * 11 * 8
+    with open(p, "r+b") as f:
+        f.write(b"\x00\x00\x00\x00")
+    assert readFlow(p) is None
+
+
+@pytest.mark.gpu
+def test_vtf_driver_matches_oracle_scores(tmp_path):
+    import gimm_oracle as go
+    from gimmvfi_hip.params import gimm_state_dict, random_state_dict
+
+    root = _tree(tmp_path)
+    sys.path.insert(0, SRC)
+    import VTF
+
+    cfg = os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimm", "gimm.yaml")
+    psnr, epe, n = VTF.main(["-m", cfg, "--eval", "--random-init", "--data-root", root, "--precision", "fp32"])
+    assert n == 2 and np.isfinite(psnr) and np.isfinite(epe)
+    # the same protocol on the CPU oracle (reference VTF.py:64-159 restated with the pinned GIMM oracle)
+    sd = gimm_state_dict(random_state_dict(0))
+    ps, es = [], []
+    for name in open(os.path.join(root, "tri_testlist.txt")).read().split():
+        d = os.path.join(root, "flow_sequences", name)
+        rd = lambda f: VTF.process_flow(os.path.join(d, f))
+        gt = (rd("im2_im3.flo") - rd("im2_im1.flo")).unsqueeze(2)
+        xs = torch.cat((rd("im1_im3.flo").unsqueeze(2), -rd("im3_im1.flo").unsqueeze(2)), 2)
+        s = xs.abs().max().reshape(1, 1)
+        ori = torch.cat((xs[:, :, :1], -xs[:, :, 1:2]), 2)
+        with torch.no_grad():
+            out = go.forward(sd, (xs / s + 1) / 2, VTF.mid_coords(xs.shape[3], xs.shape[4], "cpu"), ori, torch.tensor([0.5]))
+        tgt = (gt / s + 1) / 2
+        ps.append(float(-10 * torch.log10(((out[:, :, 0] - tgt[:, :, 0]) ** 2).reshape(1, -1).mean(-1)).sum()))
+        es.append(float((((out * 2 - 1) * s)[0, :, 0] - gt[0, :, 0]).pow(2).sum(0).sqrt().mean()))
+    assert abs(psnr - np.mean(ps)) < 0.05 and abs(epe - np.mean(es)) < 1e-3 * max(1.0, np.mean(es))
