@@ -38,41 +38,56 @@ def process_flow(path):
     return torch.from_numpy(readFlow(path).copy()).permute(2, 0, 1).unsqueeze(0).to(torch.float32)
 
 
-def mid_coords(h, w, device):
-    """(1,1,h,w,3) coordinate grid of the middle time step: the t = 0.5 slice of a 3-step grid over [0,1]
-    (VTF.py:92-121), spatial axes at pixel centres in [-1,1]."""
+def grid_coords(h, w, device, t):
+    """(1,1,h,w,3) coordinate grid at normalised time t (a slice of the reference's `xytshape2coordinate` grid over
+    [0,1], VTF.py:92-121 / VSF.py:98-127), spatial axes at pixel centres in [-1,1]."""
     ys = -1.0 + 2.0 * (0.5 + torch.arange(h, device=device)) / h
     xs = -1.0 + 2.0 * (0.5 + torch.arange(w, device=device)) / w
-    g = torch.stack(torch.meshgrid(torch.tensor([0.5], device=device), ys, xs, indexing="ij"), dim=-1)
+    g = torch.stack(torch.meshgrid(torch.tensor([float(t)], device=device), ys, xs, indexing="ij"), dim=-1)
     return g.unsqueeze(0)
 
 
-def evaluate(model, data_root, device, limit=None):
-    with open(os.path.join(data_root, "tri_testlist.txt")) as f:
+def mid_coords(h, w, device):
+    return grid_coords(h, w, device, 0.5)
+
+
+# protocol: (list file, first frame, last frame, [(middle frame, coordinate time, timestep)])
+TRIPLET = ("tri_testlist.txt", 1, 3, [(2, 0.5, 0.5)])                                   # VTF.py:61-139
+# the septuplet driver pairs the grid slice (t_id-1)/6 with the time step t_id/6 (VSF.py:128-148): kept as is
+SEPTUPLET = ("sep_testlist.txt", 1, 7, [(k, (k - 1) / 6, k / 6) for k in range(2, 7)])   # VSF.py:61-148
+
+
+def evaluate(model, data_root, device, limit=None, protocol=TRIPLET):
+    listfile, a, b, mids = protocol
+    with open(os.path.join(data_root, listfile)) as f:
         names = [ln for ln in f.read().splitlines() if ln.strip()]
     if limit:
         names = names[:limit]
     psnrs, epes = [], []
     for name in names:
         d = os.path.join(data_root, "flow_sequences", name)
-        gt = (process_flow(os.path.join(d, "im2_im3.flo")) - process_flow(os.path.join(d, "im2_im1.flo"))).unsqueeze(2)
-        f01 = process_flow(os.path.join(d, "im1_im3.flo")).unsqueeze(2)
-        f10 = process_flow(os.path.join(d, "im3_im1.flo")).unsqueeze(2)
+        f01 = process_flow(os.path.join(d, f"im{a}_im{b}.flo")).unsqueeze(2)
+        f10 = process_flow(os.path.join(d, f"im{b}_im{a}.flo")).unsqueeze(2)
         xs = torch.cat((f01, -f10), dim=2).to(device)                       # VTF.py:90
         scaler = xs.abs().max().reshape(1, 1)                                # VTF.py:124-129
         ori = torch.cat((xs[:, :, :1], -xs[:, :, 1:2]), dim=2)              # VTF.py:137
-        with torch.no_grad():
-            out = model((xs / scaler + 1.0) / 2.0, mid_coords(xs.shape[3], xs.shape[4], device), ori_flow=ori,
-                        timesteps=torch.tensor([0.5], device=device))
-            target = (gt.to(device) / scaler + 1.0) / 2.0
-            psnrs.append(float(model.compute_loss(out, target, reduction="sum")["psnr"]))
-            flow = (out * 2.0 - 1.0) * scaler                                # un-normalise, VTF.py:151-157
-            epes.append(float(((flow[0, :, 0] - gt[0, :, 0].to(device)) ** 2).sum(0).sqrt().mean()))
-    return float(np.mean(psnrs)), float(np.mean(epes)), len(names)
+        xn = (xs / scaler + 1.0) / 2.0
+        for k, tc, ts in mids:
+            gt = (process_flow(os.path.join(d, f"im{k}_im{b}.flo")) - process_flow(os.path.join(d, f"im{k}_im{a}.flo"))).unsqueeze(2)
+            with torch.no_grad():
+                out = model(xn, grid_coords(xs.shape[3], xs.shape[4], device, tc), ori_flow=ori,
+                            timesteps=torch.tensor([ts], device=device, dtype=torch.float32))
+                target = (gt.to(device) / scaler + 1.0) / 2.0
+                psnrs.append(float(model.compute_loss(out, target, reduction="sum")["psnr"]))
+                flow = (out * 2.0 - 1.0) * scaler                            # un-normalise, VTF.py:151-157
+                epes.append(float(((flow[0, :, 0] - gt[0, :, 0].to(device)) ** 2).sum(0).sqrt().mean()))
+    return float(np.mean(psnrs)), float(np.mean(epes)), len(psnrs)
 
 
-def main(argv=None):
+def main(argv=None, protocol=TRIPLET, default_root="data/vimeo90k/vimeo_triplet"):
     args, extra = default_parser().parse_known_args(argv)
+    if args.data_root == "data/vimeo90k/vimeo_triplet":
+        args.data_root = default_root
     set_seed(args.seed)
     config = single_setup(args, extra)
     device = torch.device("cuda")
@@ -88,7 +103,7 @@ def main(argv=None):
     else:
         raise ValueError("--load-path must be specified in evaluation mode")
     model = model.to(device).eval()
-    psnr, epe, n = evaluate(model, args.data_root, device)
+    psnr, epe, n = evaluate(model, args.data_root, device, protocol=protocol)
     print("Avg PSNR: {} EPE: {}".format(psnr, epe))
     return psnr, epe, n
 

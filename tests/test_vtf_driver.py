@@ -57,6 +57,7 @@ def test_vtf_driver_matches_oracle_scores(tmp_path):
     cfg = os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimm", "gimm.yaml")
     psnr, epe, n = VTF.main(["-m", cfg, "--eval", "--random-init", "--data-root", root, "--precision", "fp32"])
     assert n == 2 and np.isfinite(psnr) and np.isfinite(epe)
+    assert VTF.SEPTUPLET[3][0] == (2, 1 / 6, 2 / 6) and len(VTF.SEPTUPLET[3]) == 5     # VSF.py:67,128-148
     # the same protocol on the CPU oracle (reference VTF.py:64-159 restated with the pinned GIMM oracle)
     sd = gimm_state_dict(random_state_dict(0))
     ps, es = [], []
@@ -73,3 +74,27 @@ def test_vtf_driver_matches_oracle_scores(tmp_path):
         ps.append(float(-10 * torch.log10(((out[:, :, 0] - tgt[:, :, 0]) ** 2).reshape(1, -1).mean(-1)).sum()))
         es.append(float((((out * 2 - 1) * s)[0, :, 0] - gt[0, :, 0]).pow(2).sum(0).sqrt().mean()))
     assert abs(psnr - np.mean(ps)) < 0.05 and abs(epe - np.mean(es)) < 1e-3 * max(1.0, np.mean(es))
+
+
+@pytest.mark.gpu
+def test_vsf_driver_runs_the_septuplet_protocol(tmp_path):
+    sys.path.insert(0, SRC)
+    from utils.frame_utils import writeFlow
+    import VSF
+
+    H, W = 64, 96
+    root = tmp_path / "vimeo_septuplet"
+    d = root / "flow_sequences" / "00001" / "0001"
+    os.makedirs(d)
+    g = torch.Generator().manual_seed(6)
+    f17 = torch.nn.functional.interpolate(torch.randn(1, 2, H // 8, W // 8, generator=g) * 3.0, size=(H, W),
+                                          mode="bicubic", align_corners=False)[0].permute(1, 2, 0)
+    writeFlow(str(d / "im1_im7.flo"), f17.numpy())
+    writeFlow(str(d / "im7_im1.flo"), (-f17).numpy())
+    for k in range(2, 7):
+        writeFlow(str(d / f"im{k}_im7.flo"), ((7 - k) / 6 * f17).numpy())
+        writeFlow(str(d / f"im{k}_im1.flo"), (-(k - 1) / 6 * f17).numpy())
+    (root / "sep_testlist.txt").write_text("00001/0001\n")
+    cfg = os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimm", "gimm.yaml")
+    psnr, epe, n = VSF.main(["-m", cfg, "--eval", "--random-init", "--data-root", str(root)])
+    assert n == 5 and np.isfinite(psnr) and np.isfinite(epe)
