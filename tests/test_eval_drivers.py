@@ -98,3 +98,31 @@ def test_vsf_driver_runs_the_septuplet_protocol(tmp_path):
     cfg = os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimm", "gimm.yaml")
     psnr, epe, n = VSF.main(["-m", cfg, "--eval", "--random-init", "--data-root", str(root)])
     assert n == 5 and np.isfinite(psnr) and np.isfinite(epe)
+
+
+@pytest.mark.gpu
+def test_snu_film_arb_driver_on_a_synthetic_split(tmp_path):
+    """reference src/SNU_FILM_arb.py protocol (medium split = 4x): PSNR of the three in-between frames, files written."""
+    from PIL import Image
+
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    sys.path.insert(0, SRC)
+    import SNU_FILM_arb as snu
+
+    root = tmp_path / "SNU-FILM"
+    seq = root / "test" / "clip_a"
+    os.makedirs(seq)
+    x = synthetic_pairs(1, 128, 160, seed=9)[0]                      # (3,2,H,W)
+    a, b = x[:, 0], x[:, 1]
+    for k in range(5):                                               # frames 00010..00014: linear blend as "truth"
+        img = ((1 - k / 4) * a + k / 4 * b).permute(1, 2, 0).numpy()
+        Image.fromarray((img * 255).astype(np.uint8)).save(str(seq / f"{10 + k:05d}.png"))
+    (root / "test-medium.txt").write_text("test/clip_a/00010.png test/clip_a/00012.png test/clip_a/00014.png\n")
+    assert snu.between("x/00010.png", 3) == "x/00013.png"
+    cfg = os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml")
+    out = tmp_path / "pred"
+    res = snu.main(["-m", cfg, "--eval", "--random-init", "--data-root", str(root), "--splits", "medium", "-p", str(out)])
+    psnr, n = res["medium"]
+    assert n == 3 and np.isfinite(psnr)
+    assert sorted(os.listdir(out)) == ["clip_a_00011.png", "clip_a_00012.png", "clip_a_00013.png"]
