@@ -126,3 +126,95 @@ def test_snu_film_arb_driver_on_a_synthetic_split(tmp_path):
     psnr, n = res["medium"]
     assert n == 3 and np.isfinite(psnr)
     assert sorted(os.listdir(out)) == ["clip_a_00011.png", "clip_a_00012.png", "clip_a_00013.png"]
+
+
+def test_x4k_listing_and_area_resize(tmp_path):
+    """reference src/X4K.py:42-63 window protocol; INTER_AREA shrink == area-weighted mean (checked by brute force)."""
+    sys.path.insert(0, SRC)
+    import X4K as x4k
+
+    scene = tmp_path / "Type1" / "TEST01"
+    os.makedirs(scene)
+    for k in range(65):
+        (scene / f"{k:04d}.png").write_bytes(b"")
+    s = x4k.getXVFI(str(tmp_path))
+    assert len(s) == 2 * 7                                           # two 32-frame windows x 7 targets; frame 64 only closes
+    assert [os.path.basename(p) for p in s[0][:3]] == ["0000.png", "0032.png", "0004.png"] and abs(s[0][3] - 0.125) < 1e-12
+    assert [os.path.basename(p) for p in s[13][:3]] == ["0032.png", "0064.png", "0060.png"] and abs(s[13][3] - 0.875) < 1e-12
+    s4 = x4k.getXVFI(str(tmp_path), multiple=2, t_step_size=4)
+    assert len(s4) == 16 and os.path.basename(s4[0][2]) == "0002.png" and s4[0][3] == 0.5
+
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(1, 3, 12, 20, generator=g)
+    assert torch.allclose(x4k.area_resize(img, (10, 6)), torch.nn.functional.avg_pool2d(img, 2))
+    out = x4k.area_resize(img, (8, 5))                               # non-integer factors 2.5 x 2.4
+    ref = torch.zeros(1, 3, 5, 8, dtype=torch.float64)
+    fine = img.double().repeat_interleave(5, -2).repeat_interleave(8, -1)   # 60 x 160 lattice: both grids align on it
+    for i in range(5):
+        for j in range(8):
+            ref[..., i, j] = fine[..., 12 * i:12 * i + 12, 20 * j:20 * j + 20].mean((-2, -1))
+    assert float((out.double() - ref).abs().max()) < 1e-6
+    assert x4k.area_resize(img, (20, 12)) is img
+
+
+@pytest.mark.gpu
+def test_x4k_driver_on_a_synthetic_tree(tmp_path):
+    """reference src/X4K.py protocol on a 512x512 stand-in: 2k mode = area-resampled + DS 0.5, 4k mode = native + DS 0.25."""
+    from PIL import Image
+
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    sys.path.insert(0, SRC)
+    import X4K as x4k
+
+    scene = tmp_path / "x4k" / "Type1" / "TEST01"
+    os.makedirs(scene)
+    x = synthetic_pairs(1, 512, 512, seed=4)[0]
+    a, b = x[:, 0], x[:, 1]
+    for k in range(5):
+        img = ((1 - k / 4) * a + k / 4 * b).permute(1, 2, 0).numpy()
+        Image.fromarray((img * 255).astype(np.uint8)).save(str(scene / f"{k:04d}.png"))
+    cfg = os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml")
+    out = tmp_path / "pred"
+    res = x4k.main(["-m", cfg, "--eval", "--random-init", "--data-root", str(tmp_path / "x4k"), "--multiple", "2",
+                    "--t-step-size", "4", "--size-2k", "256x256", "-p", str(out)])
+    for mode in ("XTEST-2k", "XTEST-4k"):
+        psnr, n = res[mode]
+        assert n == 1 and np.isfinite(psnr)
+    assert os.listdir(out) == ["TEST01_0002.png"]
+    assert Image.open(str(out / "TEST01_0002.png")).size == (512, 512)   # the 4k pass wrote last, at native size
+
+
+def test_x4k_evaluate_mode_protocol_with_a_stand_in_model(tmp_path):
+    """Host logic of the X4K driver without a GPU: pad -> model(ds_factor, coord grid at ds) -> unpad -> 8-bit -> PSNR."""
+    from PIL import Image
+
+    sys.path.insert(0, SRC)
+    import X4K as x4k
+
+    scene = tmp_path / "x4k" / "Type1" / "TEST01"
+    os.makedirs(scene)
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.rand(3, 72, 100, generator=g), torch.rand(3, 72, 100, generator=g)
+    for k in range(5):
+        img = ((1 - k / 4) * a + k / 4 * b).permute(1, 2, 0).numpy()
+        Image.fromarray((img * 255).round().astype(np.uint8)).save(str(scene / f"{k:04d}.png"))
+    calls = []
+
+    class Blend:
+        def sample_coord_input(self, b, s_shape, t_ids, device=None, upsample_ratio=1.0):
+            return torch.full((b, 1, int(s_shape[0] * upsample_ratio), int(s_shape[1] * upsample_ratio), 3), t_ids[0])
+
+        def __call__(self, xs, coords, t=None, ds_factor=None):
+            calls.append((tuple(xs.shape), tuple(coords[0][0].shape), float(t[0][0]), ds_factor))
+            return {"imgt_pred": [(1 - t[0][0]) * xs[:, :, 0] + t[0][0] * xs[:, :, 1]]}
+
+    samples = x4k.getXVFI(str(tmp_path / "x4k"), multiple=2, t_step_size=4)
+    out = tmp_path / "pred"
+    os.makedirs(out)
+    psnr4, n4 = x4k.evaluate_mode(Blend(), samples, "XTEST-4k", "cpu", (50, 36), str(out))
+    psnr2, n2 = x4k.evaluate_mode(Blend(), samples, "XTEST-2k", "cpu", (50, 36), None)
+    assert n4 == n2 == 1 and psnr4 > 45 and psnr2 > 45                  # a blend of 8-bit frames, re-quantised
+    assert calls[0] == ((1, 3, 2, 96, 128), (1, 1, 24, 32, 3), 0.5, 0.25)   # padded to /32, coord grid at DS 0.25
+    assert calls[1] == ((1, 3, 2, 64, 64), (1, 1, 32, 32, 3), 0.5, 0.5)     # 36x50 resampled, padded, DS 0.5
+    assert Image.open(str(out / "TEST01_0002.png")).size == (100, 72)
