@@ -220,3 +220,180 @@ def gimm_param_spec():
 def gimm_state_dict(sd_full):
     """The GIMM subset of a GIMM-VFI-R state_dict."""
     return OrderedDict((k, v) for k, v in sd_full.items() if k.startswith(GIMM_KEY_PREFIXES))
+
+
+# ---- GIMM-VFI-F (reference generalizable_INR/gimmvfi_f.py:30-112): FlowFormer flow estimator instead of RAFT, no
+# amt_*proj 1x1 projections; everything else under the same names.  639 entries / 30,611,132 elements.
+def _lin(d, name, cout, cin, bias=True):
+    d[name + ".weight"] = (cout, cin)
+    if bias:
+        d[name + ".bias"] = (cout,)
+
+
+def _norm(d, name, c):
+    d[name + ".weight"] = (c,)
+    d[name + ".bias"] = (c,)
+
+
+def _twins(d, p):
+    """timm twins_svt_large cut to two stages (reference flowformer/core/FlowFormer/encoders.py:7-19; classes
+    LatentCostFormer/twins.py:814-983,1028-1150).  svt.norm (1024) survives the surgery and is in the checkpoint."""
+    dims, srs = (128, 256), (8, 4)
+    cin = 3
+    for i, (c, patch) in enumerate(zip(dims, (4, 2))):
+        _conv(d, f"{p}.svt.patch_embeds.{i}.proj", c, cin, patch)
+        _norm(d, f"{p}.svt.patch_embeds.{i}.norm", c)
+        cin = c
+    for i, (c, sr) in enumerate(zip(dims, srs)):
+        for j in (0, 1):
+            b = f"{p}.svt.blocks.{i}.{j}"
+            _norm(d, b + ".norm1", c)
+            if j == 0:
+                _lin(d, b + ".attn.qkv", 3 * c, c)
+                _lin(d, b + ".attn.proj", c, c)
+            else:
+                _lin(d, b + ".attn.q", c, c)
+                _lin(d, b + ".attn.kv", 2 * c, c)
+                _lin(d, b + ".attn.proj", c, c)
+                _conv(d, b + ".attn.sr", c, c, sr)
+                _norm(d, b + ".attn.norm", c)
+            _norm(d, b + ".norm2", c)
+            _lin(d, b + ".mlp.fc1", 4 * c, c)
+            _lin(d, b + ".mlp.fc2", c, 4 * c)
+    for i, c in enumerate(dims):
+        _conv(d, f"{p}.svt.pos_block.{i}.proj.0", c, 1, 3)  # depthwise
+    _norm(d, p + ".svt.norm", 1024)
+
+
+def _attn_layer(d, p, qdim, tdim, qk, v, proj_in):
+    # encoder.py:282-346 / 214-279, decoder.py:35-120: norm1, norm2, q, k, v, proj, ffn.{0,3}
+    _norm(d, p + ".norm1", qdim)
+    _norm(d, p + ".norm2", qdim)
+    _lin(d, p + ".q", qk, qdim)
+    _lin(d, p + ".k", qk, tdim)
+    _lin(d, p + ".v", v, tdim)
+    _lin(d, p + ".proj", qdim, proj_in)
+    _lin(d, p + ".ffn.0", qdim, qdim)
+    _lin(d, p + ".ffn.3", qdim, qdim)
+
+
+def _vertical_block(d, p, local):
+    # Block(with_rpe, vert_c_dim=64) -> LocallyGroupedAttnRPEContext / GlobalSubSampleAttnRPEContext (twins.py:331-546)
+    _norm(d, p + ".norm1", 128)
+    _lin(d, p + ".attn.context_proj", 64, 256)
+    _lin(d, p + ".attn.q", 128, 192)
+    _lin(d, p + ".attn.k", 128, 192 if local else 128)
+    _lin(d, p + ".attn.v", 128, 128)
+    _lin(d, p + ".attn.proj", 128, 128)
+    if not local:
+        _conv(d, p + ".attn.sr_key", 128, 192, 4)
+        _conv(d, p + ".attn.sr_value", 128, 128, 4)
+        _norm(d, p + ".attn.norm", 128)
+    _norm(d, p + ".norm2", 128)
+    _lin(d, p + ".mlp.fc1", 512, 128)
+    _lin(d, p + ".mlp.fc2", 128, 512)
+
+
+def _flowformer(d, fe):
+    me = fe + ".memory_encoder"
+    _twins(d, me + ".feat_encoder")
+    d[me + ".channel_convertor.weight"] = (256, 256, 1, 1)
+    ce = me + ".cost_perceiver_encoder"
+    d[ce + ".latent_tokens"] = (1, 8, 128)
+    _conv(d, ce + ".patch_embed.proj.0", 16, 1, 6)
+    _conv(d, ce + ".patch_embed.proj.2", 32, 16, 6)
+    _conv(d, ce + ".patch_embed.proj.4", 64, 32, 6)
+    _conv(d, ce + ".patch_embed.ffn_with_coord.0", 128, 128, 1)
+    _conv(d, ce + ".patch_embed.ffn_with_coord.2", 128, 128, 1)
+    _norm(d, ce + ".patch_embed.norm", 128)
+    _attn_layer(d, ce + ".input_layer", 128, 128, 128, 128, 128)
+    for i in range(3):
+        _attn_layer(d, f"{ce}.encoder_layers.{i}", 128, 128, 128, 128, 128)
+    for i in range(3):
+        _vertical_block(d, f"{ce}.vertical_encoder_layers.{i}.local_block", True)
+        _vertical_block(d, f"{ce}.vertical_encoder_layers.{i}.global_block", False)
+    md = fe + ".memory_decoder"
+    _conv(d, md + ".flow_token_encoder.0", 64, 81, 1)
+    _conv(d, md + ".flow_token_encoder.2", 64, 64, 1)
+    _conv(d, md + ".proj", 256, 256, 1)
+    _attn_layer(d, md + ".decoder_layer.cross_attend", 64, 128, 64, 64, 128)
+    u = md + ".update_block"
+    _conv(d, u + ".encoder.convc1", 256, 145, 1)
+    _conv(d, u + ".encoder.convc2", 192, 256, 3)
+    _conv(d, u + ".encoder.convf1", 128, 2, 7)
+    _conv(d, u + ".encoder.convf2", 64, 128, 3)
+    _conv(d, u + ".encoder.conv", 126, 256, 3)
+    for n, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
+        for g in "zrq":
+            _conv(d, f"{u}.gru.conv{g}{n}", 128, 512, kh, kw)
+    _conv(d, u + ".flow_head.conv1", 256, 128, 3)
+    _conv(d, u + ".flow_head.conv2", 2, 256, 3)
+    _conv(d, u + ".mask.0", 256, 128, 3)
+    _conv(d, u + ".mask.2", 576, 256, 1)
+    d[u + ".aggregator.gamma"] = (1,)
+    d[u + ".aggregator.to_v.weight"] = (128, 128, 1, 1)
+    d[md + ".att.to_qk.weight"] = (256, 128, 1, 1)
+    d[md + ".att.pos_emb.rel_ind"] = (160, 160)
+    d[md + ".att.pos_emb.rel_height.weight"] = (319, 128)
+    d[md + ".att.pos_emb.rel_width.weight"] = (319, 128)
+    _twins(d, fe + ".context_encoder")
+
+
+def param_spec_f() -> "OrderedDict[str, tuple]":
+    d = OrderedDict()
+    done = False
+    for k, v in param_spec().items():
+        if k.startswith("flow_estimator.") or k.startswith(("amt_last_cproj", "amt_second_last_cproj", "amt_fproj")):
+            if not done:
+                _flowformer(d, "flow_estimator")
+                done = True
+            continue
+        d[k] = v
+    return d
+
+
+def random_state_dict_f(seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded random GIMM-VFI-F weights: the shared blocks exactly as random_state_dict(seed) gives them, the
+    FlowFormer from an independent generator (Linear/conv ~ U(+-gain/sqrt(fan_in)), LayerNorm gamma/beta and the
+    GMA gamma non-trivial so that every fused/folded path is exercised)."""
+    base = random_state_dict(seed, gain)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1000 + seed)
+
+    def U(shape, lo, hi):
+        return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+    spec = param_spec_f()
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        if name in base:
+            sd[name] = base[name]
+        elif name.endswith("rel_ind"):
+            # gma.py:10-14 (buffer of RelPosEmb; unused by the forward)
+            dlt = torch.arange(160).view(1, -1) - torch.arange(160).view(-1, 1)
+            sd[name] = dlt + 159
+        elif name.endswith("latent_tokens"):
+            sd[name] = U(shape, -1.0, 1.0)
+        elif name.endswith("gamma"):
+            sd[name] = torch.tensor([0.35], dtype=torch.float32)
+        elif len(shape) >= 2:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            b = gain / math.sqrt(fan_in)
+            sd[name] = U(shape, -b, b)
+        elif name.endswith(".bias"):
+            ws = spec.get(name[: -len("bias")] + "weight")
+            if ws is not None and len(ws) >= 2:
+                fan_in = 1
+                for s in ws[1:]:
+                    fan_in *= s
+                b = gain / math.sqrt(fan_in)
+                sd[name] = U(shape, -b, b)
+            else:  # LayerNorm beta
+                sd[name] = U(shape, -0.1, 0.1)
+        elif name.endswith(".weight"):  # LayerNorm gamma
+            sd[name] = U(shape, 0.8, 1.2)
+        else:
+            raise KeyError(name)
+    return sd

@@ -545,6 +545,12 @@ def forward(sd, img_xs, coord, t, ds_factor=None, iters=20, taps=None):
     corr_fn = BidirCorr(_conv(sd, "amt_fproj", fnet0), _conv(sd, "amt_fproj", fnet1))
     feats0 = [_conv(sd, "amt_second_last_cproj", feats0[0]), _conv(sd, "amt_last_cproj", feats0[1])]
     feats1 = [_conv(sd, "amt_second_last_cproj", feats1[0]), _conv(sd, "amt_last_cproj", feats1[1])]
+    return forward_after_flow(sd, img_xs, full, f01, f10, feats0, feats1, corr_fn, coord, t, taps)
+
+
+def forward_after_flow(sd, img_xs, full, f01, f10, feats0, feats1, corr_fn, coord, t, taps=None):
+    """Everything of GIMMVFI_{R,F}.forward behind the flow estimator (gimmvfi_r.py:143-156, 352-407;
+    identical in gimmvfi_f.py:124-139, 329-384): flow normalisation, predict_flow, frame_synthesize."""
     nflows, scal = normalize_flow(torch.stack([f01, -f10], 2))
     flows = torch.stack([f01, f10], 2)
     # predict_flow (gimmvfi_r.py:158-211)

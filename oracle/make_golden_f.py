@@ -1,0 +1,51 @@
+"""Generates tests/golden/f_*.npz by running the REAL reference GIMM-VFI-F (imported from /root/reference via
+oracle/ref_harness.py, timm boundary answered by the reference's vendored Twins class) on seeded synthetic inputs
+with the seeded weights of gimmvfi_hip.params.random_state_dict_f(0).  Run in the dev container only:
+
+    python oracle/make_golden_f.py
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "gimm-vfi_amd"))
+warnings.filterwarnings("ignore")
+
+import ref_harness as rh  # noqa: E402
+from gimmvfi_hip.params import random_state_dict_f  # noqa: E402
+from gimmvfi_hip.synth import synthetic_pairs  # noqa: E402
+
+CASES = {
+    # name: (B, H, W, seed, ds_factor, t list)
+    "f_128x192_t050": (1, 128, 192, 3, None, [0.5]),
+    "f_b2_128x128_t025_075": (2, 128, 128, 4, None, [0.25, 0.75]),
+}
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    sd = random_state_dict_f(0)
+    model = rh.build_reference_model_f(sd)
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    json.dump(keys, open(os.path.join(out_dir, "state_dict_keys_f.json"), "w"), indent=0)
+    for name, (B, H, W, seed, ds, tl) in CASES.items():
+        x = synthetic_pairs(B, H, W, seed)
+        o = rh.reference_forward(model, x, tl, ds)
+        arrs = {"raft_flow": o["raft_flow"].numpy(), "nflow": o["nflow"].numpy()}
+        for i in range(len(tl)):
+            arrs[f"imgt_pred_{i}"] = o["imgt_pred"][i].numpy()
+            arrs[f"flowt_{i}"] = o["flowt"][i].numpy()
+            arrs[f"flowt0_4_{i}"] = o["flowt0_pred"][i][1].numpy()
+        arrs["meta"] = np.array(json.dumps({"B": B, "H": H, "W": W, "seed": seed, "ds": ds, "t": tl}))
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **arrs)
+        print(name, {k: v.shape for k, v in arrs.items() if k != "meta"})
+
+
+if __name__ == "__main__":
+    main()

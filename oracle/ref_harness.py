@@ -229,3 +229,169 @@ if __name__ == "__main__":
     t0 = time.time()
     out = reference_forward(m, x, [0.5])
     print("fwd s", time.time() - t0, out["imgt_pred"][0].shape, float(out["imgt_pred"][0].mean()))
+
+
+# ----------------------------------------------------------------------------------------------
+# GIMM-VFI-F (FlowFormer flow estimator).  Extra absent dependencies:
+#   timm==0.4.12 (requirements.txt:74), yacs==0.1.6, loguru==0.7.2, and `turtle` (tkinter) which
+#   LatentCostFormer/convnext.py:1 imports by accident.
+# timm is the one that carries arithmetic: `timm.create_model("twins_svt_large")`
+# (flowformer/core/FlowFormer/encoders.py:10).  The reference vendors an adapted copy of timm's
+# twins.py (LatentCostFormer/twins.py:814-1290, model kwargs in the comment at :1344-1348); the shim
+# below answers create_model with THAT vendored class, and `timm.models.layers.Mlp` with timm 0.4.12's
+# published definition (fc1 -> act -> drop -> fc2 -> drop).  Everything else of FlowFormer is the
+# reference's own code, run unmodified.  Parity at the timm boundary is therefore pinned against the
+# reference's vendored Twins, not against the timm wheel (absent here): "parity unpinned" for timm
+# itself, stated in DESIGN.md.
+# ----------------------------------------------------------------------------------------------
+def _install_shims_f():
+    _install_shims()
+    import torch.nn as nn
+
+    if "loguru" not in sys.modules:
+        lg = types.ModuleType("loguru")
+
+        class _Logger:
+            def __getattr__(self, k):
+                return lambda *a, **kw: None
+
+        lg.logger = _Logger()
+        sys.modules["loguru"] = lg
+    if "turtle" not in sys.modules:
+        tt = types.ModuleType("turtle")
+        tt.forward = lambda *a, **kw: None
+        sys.modules["turtle"] = tt
+    if "yacs" not in sys.modules:
+        yacs = types.ModuleType("yacs")
+        ycfg = types.ModuleType("yacs.config")
+
+        class CfgNode(AttrDict):
+            def clone(self):
+                return CfgNode({k: (v.clone() if isinstance(v, CfgNode) else v) for k, v in self.items()})
+
+        ycfg.CfgNode = CfgNode
+        yacs.config = ycfg
+        sys.modules["yacs"] = yacs
+        sys.modules["yacs.config"] = ycfg
+    if "timm" not in sys.modules:
+        timm = types.ModuleType("timm")
+        data = types.ModuleType("timm.data")
+        data.IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+        data.IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+        models = types.ModuleType("timm.models")
+        layers = types.ModuleType("timm.models.layers")
+        registry = types.ModuleType("timm.models.registry")
+        vit = types.ModuleType("timm.models.vision_transformer")
+        helpers = types.ModuleType("timm.models.helpers")
+
+        class Mlp(nn.Module):  # timm 0.4.12 timm/models/layers/mlp.py
+            def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+                super().__init__()
+                out_features = out_features or in_features
+                hidden_features = hidden_features or in_features
+                self.fc1 = nn.Linear(in_features, hidden_features)
+                self.act = act_layer()
+                self.fc2 = nn.Linear(hidden_features, out_features)
+                self.drop = nn.Dropout(drop)
+
+            def forward(self, x):
+                return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+        class DropPath(nn.Module):
+            def __init__(self, drop_prob=None):
+                super().__init__()
+                self.drop_prob = drop_prob
+
+            def forward(self, x):
+                assert not self.training
+                return x
+
+        layers.Mlp = Mlp
+        layers.DropPath = DropPath
+        layers.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+        layers.trunc_normal_ = torch.nn.init.trunc_normal_
+        layers.activations = types.ModuleType("timm.models.layers.activations")
+        registry.register_model = lambda fn: fn
+        vit.Attention = type("Attention", (nn.Module,), {})
+        helpers.build_model_with_cfg = None
+        helpers.overlay_external_default_cfg = None
+
+        def create_model(name, pretrained=False, **kw):
+            assert name == "twins_svt_large", name
+            tw = importlib.import_module(
+                _PKG + ".generalizable_INR.flowformer.core.FlowFormer.LatentCostFormer.twins"
+            )
+            class TimmBlock(tw.Block):
+                # timm 0.4.12 twins.py Block.forward(x, size): the vendored Block (twins.py:1094-1097) added a
+                # `context` argument that it forwards to every attention class; timm's own does not.
+                def forward(self, x, size):
+                    x = x + self.drop_path(self.attn(self.norm1(x), size))
+                    x = x + self.drop_path(self.mlp(self.norm2(x)))
+                    return x
+
+            # kwargs of twins_svt_large: reference twins.py:1344-1348 (comment) == timm 0.4.12 twins.py
+            return tw.Twins(
+                block_cls=TimmBlock,
+                patch_size=4,
+                embed_dims=[128, 256, 512, 1024],
+                num_heads=[4, 8, 16, 32],
+                mlp_ratios=[4, 4, 4, 4],
+                depths=[2, 2, 18, 2],
+                wss=[7, 7, 7, 7],
+                sr_ratios=[8, 4, 2, 1],
+            )
+
+        timm.create_model = create_model
+        timm.data = data
+        timm.models = models
+        models.layers = layers
+        models.registry = registry
+        models.vision_transformer = vit
+        models.helpers = helpers
+        for n, m in (
+            ("timm", timm),
+            ("timm.data", data),
+            ("timm.models", models),
+            ("timm.models.layers", layers),
+            ("timm.models.registry", registry),
+            ("timm.models.vision_transformer", vit),
+            ("timm.models.helpers", helpers),
+        ):
+            sys.modules[n] = m
+
+
+def default_arch_config_f() -> AttrDict:
+    """configs/gimmvfi/gimmvfi_f_arb.yaml:7-27 merged with configs.py:38-57 defaults."""
+    c = default_arch_config()
+    c.type = "gimmvfi_f"
+    return c
+
+
+def load_reference_modules_f():
+    """Returns the reference's gimmvfi_f module."""
+    if "mod_f" in _CACHE:
+        return _CACHE["mod_f"]
+    load_reference_modules()
+    _install_shims_f()
+    ffpkg = importlib.import_module(_PKG + ".generalizable_INR.flowformer")
+
+    def initialize_Flowformer():
+        # reference flowformer/__init__.py:6-18 without the torch.load of pretrained_ckpt/flowformer_sintel.pth
+        cfg = ffpkg.get_cfg()
+        return ffpkg.build_flowformer(cfg)
+
+    ffpkg.initialize_Flowformer = initialize_Flowformer
+    mod = importlib.import_module(_PKG + ".generalizable_INR.gimmvfi_f")
+    mod.initialize_Flowformer = initialize_Flowformer
+    _CACHE["mod_f"] = mod
+    return mod
+
+
+def build_reference_model_f(state_dict=None):
+    mod = load_reference_modules_f()
+    torch.manual_seed(0)
+    model = mod.GIMMVFI_F(default_arch_config_f())
+    if state_dict is not None:
+        model.load_state_dict(state_dict, strict=True)
+    model.eval()
+    return model

@@ -28,3 +28,10 @@ def simlib():
     from sim_runtime import hostsim_lib
 
     return hostsim_lib()
+
+
+@pytest.fixture(scope="session")
+def sd_f():
+    from gimmvfi_hip.params import random_state_dict_f
+
+    return random_state_dict_f(0)

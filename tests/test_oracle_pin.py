@@ -55,3 +55,57 @@ def test_reference_accepts_our_state_dict_strict(sd):
     ref = rh.build_reference_model()
     ref.load_state_dict(sd, strict=True)
     assert list(ref.state_dict().keys()) == list(sd.keys())
+
+
+# ---- GIMM-VFI-F (FlowFormer flow estimator): oracle/gimmvfi_f_oracle.py
+F_CASES = ["f_128x192_t050", "f_b2_128x128_t025_075"]
+
+
+@pytest.mark.parametrize("name", F_CASES)
+def test_f_oracle_matches_golden(name, sd_f):
+    import gimmvfi_f_oracle as forc
+
+    meta, gold = load_golden(name)
+    x, coords, ts = golden_inputs(meta)
+    with torch.no_grad():
+        o = forc.forward(sd_f, x, coords, ts, meta["ds"])
+    tol = 1e-5  # bit-exact on the same torch build; slack for other BLAS/oneDNN builds (32 recurrent iterations)
+    assert maxabs(o["raft_flow"], gold["raft_flow"]) <= tol * 100
+    assert maxabs(o["nflow"], gold["nflow"]) <= tol * 10
+    for i in range(len(meta["t"])):
+        assert maxabs(o["imgt_pred"][i], gold[f"imgt_pred_{i}"]) <= tol * 10
+        assert maxabs(o["flowt"][i], gold[f"flowt_{i}"]) <= tol * 100
+        assert tuple(o["flowt"][i].shape) == tuple(gold[f"flowt_{i}"].shape)
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="reference checkout only exists in the dev container")
+def test_f_oracle_matches_reference_live(sd_f):
+    import gimmvfi_f_oracle as forc
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    ref = rh.build_reference_model_f(sd_f)
+    assert list(ref.state_dict().keys()) == list(sd_f.keys())  # strict=True load + same order as the reference
+    x = synthetic_pairs(1, 128, 160, 11)
+    tl = [0.3, 0.8]
+    ro = rh.reference_forward(ref, x, tl, None)
+    coords = [(forc.sample_coord_input(1, x.shape[-2:], [t], 1.0), None) for t in tl]
+    with torch.no_grad():
+        oo = forc.forward(sd_f, x, coords, [t * torch.ones(1) for t in tl], None)
+    for k in ("raft_flow", "nflow"):
+        assert maxabs(ro[k], oo[k]) == 0.0
+    for i in range(2):
+        for k in ("imgt_pred", "flowt", "ninrflow"):
+            assert maxabs(ro[k][i], oo[k][i]) == 0.0
+        for j in range(2):
+            assert maxabs(ro["flowt0_pred"][i][j], oo["flowt0_pred"][i][j]) == 0.0
+
+
+def test_f_param_spec_matches_recorded_reference_keys(sd_f):
+    import json
+    import os
+
+    from util import GOLDEN
+
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys_f.json")))
+    assert list(keys.keys()) == list(sd_f.keys())
+    assert all(list(sd_f[k].shape) == v for k, v in keys.items())
