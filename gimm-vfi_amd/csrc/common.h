@@ -81,6 +81,7 @@ __device__ __forceinline__ float apply_act(float v, int act, const float* slope,
         case GVFI_ACT_SIGMOID: return gvfi_sigmoid(v);
         case GVFI_ACT_TANH: return tanhf(v);
         case GVFI_ACT_SIN: return sinf(v);
+        case GVFI_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
         default: return v;
     }
 }

@@ -1,0 +1,399 @@
+// FlowFormer glue kernels of the GIMM-VFI-F flow estimator (reference src/models/generalizable_INR/flowformer/core/
+// FlowFormer/LatentCostFormer/*): everything that is not a dense contraction.  The linear layers, patch / sub-sampling
+// convolutions, the cost volume, QK^T and attention*V of the global motion aggregation run on gvfi_conv2d (MFMA).
+//
+// Token tensors are row matrices [rows][ld] in the activation type (a row = one token, channel-contiguous like an
+// NHWC pixel); all reductions (LayerNorm statistics, soft-max, dot products) are evaluated in float.
+//
+// First correct version: one thread per output row / (query, head); the heavy parts of the path are the
+// contractions, these kernels stream a few hundred bytes per token.
+#include "common.h"
+
+#define GVFI_BLOCK 256
+static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK - 1) / GVFI_BLOCK)); }
+
+// ------------------------------------------------------------------ nn.LayerNorm over the channel axis
+// twins.py:1169 (eps 1e-6 in the Twins blocks), torch default 1e-5 elsewhere (twins.py:1146, encoder.py:65,...)
+template <typename T>
+__global__ void layernorm_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, T* __restrict__ y, int ldy, long long rows,
+                                 int C) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const T* xr = x + r * ldx;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += Elem<T>::ld(xr + c);
+    const float mean = s / (float)C;
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = Elem<T>::ld(xr + c) - mean;
+        v += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(v / (float)C + eps);
+    T* yr = y + r * ldy;
+    for (int c = 0; c < C; ++c) Elem<T>::st(yr + c, (Elem<T>::ld(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+}
+extern "C" int gvfi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                              long long rows, int C, int dtype, void* stream) {
+    if (C <= 0 || ldx < C || ldy < C) return -2;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((layernorm_kernel<T>), grid1d(rows), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                              (const T*)x, ldx, gamma, beta, eps, (T*)y, ldy, rows, C));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ PEG: y = x + depthwise3x3(x) + bias   twins.py:1100-1119
+template <typename T>
+__global__ void dwconv3x3_res_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w /*[9][C]*/,
+                                     const float* __restrict__ bias, T* __restrict__ y, int ldy, long long total, int H,
+                                     int W, int C) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (pixel, channel)
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long pix = idx / C;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H);
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = py + ky - 1;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = px + kx - 1;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            acc += w[(ky * 3 + kx) * C + c] * Elem<T>::ld(x + (pix + (long long)(ky - 1) * W + (kx - 1)) * ldx + c);
+        }
+    }
+    Elem<T>::st(y + pix * ldy + c, acc + bias[c] + Elem<T>::ld(x + pix * ldx + c));
+}
+extern "C" int gvfi_dwconv3x3_res(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int H,
+                                  int W, int C, int dtype, void* stream) {
+    const long long total = (long long)N * H * W * C;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((dwconv3x3_res_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, (const T*)x, ldx, w, bias, (T*)y, ldy, total, H, W, C));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ LinearPositionEmbeddingSine   attention.py:170-182
+// enc(x, y)[k] for dim channels: [sin(3.14 x f/200) | cos(3.14 x f/200) | sin(3.14 y f/200) | cos(..)], f = 0..dim/4-1
+__device__ __forceinline__ float pos_enc_channel(float px, float py, int c, int dim) {
+    const int q = dim >> 2;
+    const int part = c / q;
+    const float f = (float)(c - part * q);
+    const float a = 3.14f * (part < 2 ? px : py) * f * (1.0f / 200.0f);
+    return (part & 1) ? cosf(a) : sinf(a);
+}
+// out[row, 0:dim] (+)= enc(scale * coords[row % period] + offset)
+template <typename T>
+__global__ void pos_embed_kernel(const float* __restrict__ coords, long long period, float scale, float offset, int dim,
+                                 T* __restrict__ out, int ldo, long long total, int accumulate) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (row, channel)
+    if (idx >= total) return;
+    const int c = (int)(idx % dim);
+    const long long r = idx / dim;
+    const long long cr = r % period;
+    const float e = pos_enc_channel(coords[cr * 2] * scale + offset, coords[cr * 2 + 1] * scale + offset, c, dim);
+    T* o = out + r * ldo + c;
+    Elem<T>::st(o, accumulate ? Elem<T>::ld(o) + e : e);
+}
+extern "C" int gvfi_pos_embed(const float* coords, long long period, float scale, float offset, int dim, void* out, int ldo,
+                              long long rows, int accumulate, int dtype, void* stream) {
+    if (dim <= 0 || (dim & 3) || period <= 0) return -2;
+    const long long total = rows * dim;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((pos_embed_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                              coords, period, scale, offset, dim, (T*)out, ldo, total, accumulate));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ first cost-map convolution   encoder.py:39-41
+// Conv2d(1, 16, 6, stride 2, padding 2) + ReLU over the cost maps [maps][H][W] (float, the all-pairs volume itself),
+// zero-extended to a multiple of the patch size on the right / bottom (encoder.py:70-75): out [maps][Ho][Wo][16].
+template <typename T>
+__global__ void cost_embed1_kernel(const float* __restrict__ vol, const float* __restrict__ w /*[36][16]*/,
+                                   const float* __restrict__ bias, T* __restrict__ out, int ldo, long long total, int H,
+                                   int W, int Ho, int Wo) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over output pixels
+    if (idx >= total) return;
+    const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho);
+    const long long m = idx / ((long long)Wo * Ho);
+    const float* src = vol + m * (long long)H * W;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = bias[c];
+    for (int ky = 0; ky < 6; ++ky) {
+        const int yy = oy * 2 - 2 + ky;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 6; ++kx) {
+            const int xx = ox * 2 - 2 + kx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float v = src[(long long)yy * W + xx];
+            const float* wk = w + (ky * 6 + kx) * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] += v * wk[c];
+        }
+    }
+    T* o = out + idx * ldo;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Elem<T>::st(o + c, acc[c] > 0.f ? acc[c] : 0.f);
+}
+extern "C" int gvfi_cost_embed1(const float* vol, const float* w, const float* bias, void* out, int ldo, long long maps,
+                                int H, int W, int Ho, int Wo, int dtype, void* stream) {
+    if (ldo < 16) return -2;
+    const long long total = maps * Ho * Wo;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((cost_embed1_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                              vol, w, bias, (T*)out, ldo, total, H, W, Ho, Wo));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ 81-tap cost lookup   decoder.py:237-255
+// out[q, i*win + j] = bilinear(cost_map[q]; x + (i - r), y + (j - r)), zeros outside, same float expression as
+// bilinear_sampler + grid_sample(align_corners=True) (utils/utils.py:83-97); the window axes are transposed exactly
+// as in RAFT's lookup (delta = stack(meshgrid(dy, dx)) is added to (x, y)).
+template <typename T>
+__global__ void cost_lookup_kernel(const float* __restrict__ maps, const float* __restrict__ coords, T* __restrict__ out,
+                                   int ldo, long long total, int h, int w, int radius) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (query, tap)
+    if (idx >= total) return;
+    const int win = 2 * radius + 1;
+    const int tap = (int)(idx % (win * win));
+    const long long q = idx / (win * win);
+    const int i = tap / win, j = tap % win;
+    const float* base = maps + q * (long long)h * w;
+    const float cx = coords[q * 2 + 0] + (float)(i - radius);
+    const float cy = coords[q * 2 + 1] + (float)(j - radius);
+    const float xn = 2.f * cx / (float)(w - 1) - 1.f;
+    const float yn = 2.f * cy / (float)(h - 1) - 1.f;
+    const float ix = ((xn + 1.f) * 0.5f) * (float)(w - 1);
+    const float iy = ((yn + 1.f) * 0.5f) * (float)(h - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float ax = ix - x0f, ay = iy - y0f;
+    const bool xin0 = x0 >= 0 && x0 < w, xin1 = x0 + 1 >= 0 && x0 + 1 < w;
+    const bool yin0 = y0 >= 0 && y0 < h, yin1 = y0 + 1 >= 0 && y0 + 1 < h;
+    float v = 0.f;
+    if (xin0 && yin0) v += (1.f - ax) * (1.f - ay) * base[(long long)y0 * w + x0];
+    if (xin1 && yin0) v += ax * (1.f - ay) * base[(long long)y0 * w + x0 + 1];
+    if (xin0 && yin1) v += (1.f - ax) * ay * base[(long long)(y0 + 1) * w + x0];
+    if (xin1 && yin1) v += ax * ay * base[(long long)(y0 + 1) * w + x0 + 1];
+    Elem<T>::st(out + q * ldo + tap, v);
+}
+extern "C" int gvfi_cost_lookup(const float* maps, const float* coords, void* out, int ldo, long long Q, int h, int w,
+                                int radius, int dtype, void* stream) {
+    const int win = 2 * radius + 1;
+    if (h < 2 || w < 2 || ldo < win * win) return -2;
+    const long long total = Q * win * win;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((cost_lookup_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                              maps, coords, (T*)out, ldo, total, h, w, radius));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ attention over small key sets
+// One thread = one (query row, head): soft-max(q.k_j * scale) over the keys in one pass (running maximum), V accumulated
+// in registers.  HD = head dimension (8, 16, 32).
+template <typename T, int HD> struct AttnAcc {
+    float q[HD], o[HD], m, l;
+    __device__ __forceinline__ void init(const T* qp) {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { q[d] = Elem<T>::ld(qp + d); o[d] = 0.f; }
+        m = -INFINITY;
+        l = 0.f;
+    }
+    template <typename KT> __device__ __forceinline__ void key(const KT* kp, const KT* vp, float scale) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s += q[d] * Elem<KT>::ld(kp + d);
+        s *= scale;
+        const float mn = fmaxf(m, s);
+        const float a = expf(m - mn), p = expf(s - mn);   // expf(-inf) = 0 on the first key
+        l = l * a + p;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = o[d] * a + p * Elem<KT>::ld(vp + d);
+        m = mn;
+    }
+    __device__ __forceinline__ void store(T* op) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) Elem<T>::st(op + d, o[d] * inv);
+    }
+};
+
+// Locally-grouped attention (twins.py:814-867, 331-427): tokens on an H x W grid per image, a query attends to the ws x ws
+// window that contains it; window positions beyond the grid (the reference zero-pads the token grid AFTER the norm,
+// so those tokens carry the projection of zero [+ positional code]) use kpad / vpad [ws*ws][C] (float).
+template <typename T, int HD>
+__global__ void attn_window_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                   const T* __restrict__ v, int ldv, const float* __restrict__ kpad,
+                                   const float* __restrict__ vpad, T* __restrict__ out, int ldo, long long total, int H,
+                                   int W, int ws, int heads, float scale) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (token row, head)
+    if (idx >= total) return;
+    const int hd = (int)(idx % heads);
+    const long long row = idx / heads;
+    const int px = (int)(row % W), py = (int)((row / W) % H);
+    const long long img0 = row - (long long)py * W - px;
+    const int wy = py / ws * ws, wx = px / ws * ws;
+    const int C = heads * HD;
+    AttnAcc<T, HD> acc;
+    acc.init(q + row * ldq + hd * HD);
+    for (int dy = 0; dy < ws; ++dy)
+        for (int dx = 0; dx < ws; ++dx) {
+            const int yy = wy + dy, xx = wx + dx;
+            if (yy < H && xx < W) {
+                const long long kr = img0 + (long long)yy * W + xx;
+                acc.key(k + kr * ldk + hd * HD, v + kr * ldv + hd * HD, scale);
+            } else {
+                const int pos = dy * ws + dx;
+                acc.key(kpad + pos * C + hd * HD, vpad + pos * C + hd * HD, scale);
+            }
+        }
+    acc.store(out + row * ldo + hd * HD);
+}
+extern "C" int gvfi_attn_window(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
+                                const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
+                                int head_dim, float scale, int dtype, void* stream) {
+    const long long total = (long long)n_img * H * W * heads;
+#define GVFI_AW(HD_)                                                                                                 \
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_window_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),          \
+                                              (hipStream_t)stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
+                                              kpad, vpad, (T*)out, ldo, total, H, W, ws, heads, scale))
+    if (head_dim == 8) GVFI_AW(8);
+    else if (head_dim == 16) GVFI_AW(16);
+    else if (head_dim == 32) GVFI_AW(32);
+    else return -2;
+#undef GVFI_AW
+    return (int)hipGetLastError();
+}
+
+// Attention of NQ queries per group against M keys per group (twins.py:870-925, 430-546; attention.py:10-66;
+// encoder.py:214-346; decoder.py:35-120).  Groups g = (g1, g0), g0 < G0; rows are addressed as
+//   query  : g1*qb1 + g0*qb0 + i*qs      key/value : g1*kb1 + g0*kb0 + j*ks      output : g1*ob1 + g0*ob0 + i*os
+// which covers batched global attention (G0 = 1), one shared query set (qb1 = qb0 = 0), the self-attention over the K
+// latent tokens of a cost map and the decoder's one-query cross-attention in the image-major latent layout
+// [(b, k)][p] (key stride P).
+template <typename T, int HD>
+__global__ void attn_global_kernel(const T* __restrict__ q, int ldq, long long qb1, long long qb0, long long qs,
+                                   const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv, long long kb1,
+                                   long long kb0, long long ks, T* __restrict__ out, int ldo, long long ob1, long long ob0,
+                                   long long os, long long total, int G0, int NQ, int M, int heads, float scale) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (g1, g0, i, head)
+    if (idx >= total) return;
+    const int hd = (int)(idx % heads);
+    long long r = idx / heads;
+    const int i = (int)(r % NQ);
+    r /= NQ;
+    const long long g0 = r % G0, g1 = r / G0;
+    AttnAcc<T, HD> acc;
+    acc.init(q + (g1 * qb1 + g0 * qb0 + i * qs) * ldq + hd * HD);
+    const long long kbase = g1 * kb1 + g0 * kb0;
+    for (int j = 0; j < M; ++j) {
+        const long long kr = kbase + j * ks;
+        acc.key(k + kr * ldk + hd * HD, v + kr * ldv + hd * HD, scale);
+    }
+    acc.store(out + (g1 * ob1 + g0 * ob0 + i * os) * ldo + hd * HD);
+}
+extern "C" int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
+                                const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
+                                long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
+                                int head_dim, float scale, int dtype, void* stream) {
+    if (G0 <= 0 || NQ <= 0 || M <= 0) return -2;
+    const long long total = G1 * G0 * NQ * heads;
+#define GVFI_AG(HD_)                                                                                                   \
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_global_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),            \
+                                              (hipStream_t)stream, (const T*)q, ldq, qb1, qb0, qs, (const T*)k, ldk,     \
+                                              (const T*)v, ldv, kb1, kb0, ks, (T*)out, ldo, ob1, ob0, os, total, G0, NQ, \
+                                              M, heads, scale))
+    if (head_dim == 8) GVFI_AG(8);
+    else if (head_dim == 16) GVFI_AG(16);
+    else if (head_dim == 32) GVFI_AG(32);
+    else return -2;
+#undef GVFI_AG
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ [x | context] (+ positional code)   twins.py:366-395, 465-493
+// Row r = (im, p) of n_img images with P = H*W tokens each: out[r, 0:Cx] = x[r], out[r, Cx:Cx+Cc] = ctx[cimg(im)][p].
+// The reference tiles the context batch (`context.repeat(B // nb, 1, 1, 1)`, twins.py:366) over the (batch, latent
+// token) axis, so image (b, k) of a direction with nb pairs reads context (b*K + k) % nb -- reproduced here:
+// cimg = d*nb + (im % (nb*K)) % nb with d = im / (nb*K).
+// enc_mode 1: += enc(x % ws, y % ws) (window position), 2: += enc(x, y); over all Cx + Cc channels.
+template <typename T>
+__global__ void xqk_kernel(const T* __restrict__ x, int ldx, int Cx, const T* __restrict__ ctx, int ldc, int Cc,
+                           T* __restrict__ out, int ldo, long long total, int P, int W, int K, int nb, int enc_mode,
+                           int ws) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (row, channel)
+    if (idx >= total) return;
+    const int Ct = Cx + Cc;
+    const int c = (int)(idx % Ct);
+    const long long r = idx / Ct;
+    const int p = (int)(r % P);
+    const long long im = r / P;
+    float val;
+    if (c < Cx) {
+        val = Elem<T>::ld(x + r * ldx + c);
+    } else {
+        const long long per = (long long)nb * K;
+        const long long cimg = (im / per) * nb + (im % per) % nb;
+        val = Elem<T>::ld(ctx + (cimg * P + p) * ldc + (c - Cx));
+    }
+    if (enc_mode) {
+        int px = p % W, py = p / W;
+        if (enc_mode == 1) { px %= ws; py %= ws; }
+        val += pos_enc_channel((float)px, (float)py, c, Ct);
+    }
+    Elem<T>::st(out + r * ldo + c, val);
+}
+extern "C" int gvfi_ff_xqk(const void* x, int ldx, int Cx, const void* ctx, int ldc, int Cc, void* out, int ldo, int n_img,
+                           int H, int W, int K, int nb, int enc_mode, int ws, int dtype, void* stream) {
+    if (((Cx + Cc) & 3) || nb <= 0 || K <= 0 || (enc_mode == 1 && ws <= 0)) return -2;
+    const long long total = (long long)n_img * H * W * (Cx + Cc);
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((xqk_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                              (const T*)x, ldx, Cx, (const T*)ctx, ldc, Cc, (T*)out, ldo, total, H * W, W,
+                                              K, nb, enc_mode, ws));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ out[row] = table[(row / P) % K]   encoder.py:420 (latent tokens)
+template <typename T>
+__global__ void tile_rows_kernel(const float* __restrict__ table, T* __restrict__ out, int ldo, long long total, int P,
+                                 int K, int C) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    Elem<T>::st(out + r * ldo + c, table[((r / P) % K) * C + c]);
+}
+extern "C" int gvfi_tile_rows(const float* table, void* out, int ldo, long long rows, int P, int K, int C, int dtype,
+                              void* stream) {
+    const long long total = rows * C;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((tile_rows_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                              table, (T*)out, ldo, total, P, K, C));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ row soft-max of the GMA similarity   gma.py:70-74
+// x float [rows][n] -> y [rows][ldy] in the activation type (pad columns n..ldy zeroed: y is the A operand of the
+// attention*V contraction).  One 64-lane wave per row.
+template <typename T>
+__global__ void softmax_rows_kernel(const float* __restrict__ x, int n, T* __restrict__ y, int ldy, long long rows) {
+    const long long r = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    const bool live = r < rows;
+    const float* xr = x + (live ? r : 0) * (long long)n;
+    float m = -INFINITY;
+    if (live)
+        for (int c = lane; c < n; c += 64) m = fmaxf(m, xr[c]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float s = 0.f;
+    if (live)
+        for (int c = lane; c < n; c += 64) s += expf(xr[c] - m);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (!live) return;
+    const float inv = 1.0f / s;
+    T* yr = y + r * ldy;
+    for (int c = lane; c < ldy; c += 64) Elem<T>::st(yr + c, c < n ? expf(xr[c] - m) * inv : 0.f);
+}
+extern "C" int gvfi_softmax_rows(const float* x, int n, void* y, int ldy, long long rows, int dtype, void* stream) {
+    if (n <= 0 || ldy < n) return -2;
+    const int wpb = GVFI_BLOCK / 64;
+    dim3 grid((unsigned)((rows + wpb - 1) / wpb));
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((softmax_rows_kernel<T>), grid, dim3(GVFI_BLOCK), (hipStream_t)stream, x, n,
+                                            (T*)y, ldy, rows));
+    return (int)hipGetLastError();
+}

@@ -106,6 +106,11 @@ class Engine:
         self._build_motion(sd)
         if self.motion_only:
             return
+        self._build_flow(sd)
+        self._build_synth(sd)
+
+    def _build_flow(self, sd):
+        """RAFT flow estimator + the 1x1 projections of its features (gimmvfi_r.py:44-53)."""
         fe = "flow_estimator"
         self._build_encoder(sd, fe + ".fnet", False)
         self._conv(sd, fe + ".fnet.conv2")
@@ -138,6 +143,9 @@ class Engine:
             self._add(f"gru.q{n}.ctx", wq[:, 128:256], bq)
         for k in ("amt_last_cproj", "amt_second_last_cproj", "amt_fproj"):
             self._conv(sd, k)
+
+    def _build_synth(self, sd):
+        """Frame-synthesis decoders, identical in GIMM-VFI-R and -F (gimmvfi_r.py:55-64,113-124)."""
         p = "amt_init_decoder"
         for i in (1, 2, 3, 4, 5):
             self._conv(sd, f"{p}.upsample.{i}.0", slope=f"{p}.upsample.{i}.1.weight")
@@ -466,18 +474,8 @@ class Engine:
         HW = H * W
 
         # ---- cal_bidirection_flow (gimmvfi_r.py:126-156)
-        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps)
-        f01, f10 = flow_up[:B], flow_up[B:]
+        f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps)
         h4, w4 = H // 4, W // 4
-        g = rt.act(n, h8, w8, 256)
-        rt.conv(Ls["amt_fproj"], fmap, g)
-        pyr2 = self._corr_pyramids(g, torch.cat([g[B:], g[:B]], 0), n, h8, w8)
-        pyr = [p[:B * h8 * w8] for p in pyr2]       # corr
-        pyrT = [p[B * h8 * w8:] for p in pyr2]      # corr_T (raft/corr.py:32)
-        feat4 = rt.act(n, h4, w4, 128)
-        rt.conv(Ls["amt_second_last_cproj"], cfeats[1], feat4)
-        feat8 = rt.act(n, h8, w8, 256)
-        rt.conv(Ls["amt_last_cproj"], cfeats[2], feat8)
         scaler = rt.f32(B, zero=True)
         rt._chk(lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), B, HW, st()), "flow_absmax")
         nfA = rt.act(n, H, W, 2, zero=True)
@@ -525,6 +523,32 @@ class Engine:
         out["raft_flow"] = raft_flow
         out["nflow"] = nflow
         return out
+
+    def _flow(self, imgA, B, iters, taps):
+        """Bidirectional flow + what frame synthesis needs from the flow estimator (gimmvfi_r.py:126-141): flows
+        [B,H,W,2] f32 of both directions, the two correlation pyramids of BidirCorrBlock, context features at 1/4
+        (128 ch) and 1/8 (256 ch) for both frames."""
+        rt, Ls = self.rt, self.layers
+        n = 2 * B
+        H, W = imgA.shape[1:3]
+        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps)
+        f01, f10 = flow_up[:B], flow_up[B:]
+        h4, w4 = H // 4, W // 4
+        g = rt.act(n, h8, w8, 256)
+        rt.conv(Ls["amt_fproj"], fmap, g)
+        pyr, pyrT = self._bidir_pyramids(g, B, h8, w8)
+        feat4 = rt.act(n, h4, w4, 128)
+        rt.conv(Ls["amt_second_last_cproj"], cfeats[1], feat4)
+        feat8 = rt.act(n, h8, w8, 256)
+        rt.conv(Ls["amt_last_cproj"], cfeats[2], feat8)
+        return f01, f10, pyr, pyrT, feat4, feat8, (h8, w8)
+
+    def _bidir_pyramids(self, g, B, h8, w8):
+        """BidirCorrBlock (raft/corr.py:23-45): volume + transposed volume, each with its pooled pyramid."""
+        pyr2 = self._corr_pyramids(g, torch.cat([g[B:], g[:B]], 0), 2 * B, h8, w8)
+        pyr = [p[:B * h8 * w8] for p in pyr2]       # corr
+        pyrT = [p[B * h8 * w8:] for p in pyr2]      # corr_T (raft/corr.py:32)
+        return pyr, pyrT
 
     def _init_upsample(self, feat8):
         # modules/fi_components.py:234-244

@@ -1,0 +1,499 @@
+"""GIMM-VFI-F inference pipeline on the HIP kernels: the FlowFormer flow estimator in front of the shared
+motion-INR / frame-synthesis engine (engine.Engine).
+
+Mirrors reference generalizable_INR/gimmvfi_f.py:114-139, 304-384 and flowformer/core/FlowFormer/LatentCostFormer/
+{transformer,encoder,decoder,gru,gma,attention,twins}.py + ../encoders.py.  Stage names in ``taps`` are those of
+oracle/gimmvfi_f_oracle.py.
+
+Layout: both directions run as one batch of n = 2B images [frame0 of b = 0..B-1, frame1 ...]; direction d of pair b is
+image d*B + b.  Token tensors are row matrices [rows, C] (an NHWC tensor flattened); every linear layer is a 1x1
+gvfi_conv2d over a [1, 1, rows, C] view.  The 8 latent cost tokens of every cost map live in ONE image-major layout
+[(image, token k), pixel p, 128] for the whole encoder, so the "vertical" Twins blocks see plain NHWC images and the
+per-map attention over the tokens is a strided gather (gvfi_attn_global) -- the reference permutes the tensor twice
+per layer (encoder.py:447-459).
+
+Work the reference performs but never uses is not executed: the feature encoder runs once per image instead of once
+per direction (encoder.py:507-509 re-encodes both images for each direction), the mask head + convex upsampling run
+for the last of the 32 decoder iterations only (decoder.py:312-314 evaluates all and returns the last).
+"""
+import math
+
+import torch
+
+from . import lib as L
+from .engine import Engine
+from .ops import ConvLayer, PatchConvLayer, TapSplitConvLayer, View
+
+A = L
+K_LAT = 8          # cost_latent_token_num   configs/submission.py:30
+TWINS = ((128, 4, 4, 8), (256, 2, 8, 4))   # (embed dim, patch, heads, sr_ratio)   twins.py:1344-1348
+
+
+def _enc_host(xs, ys, dim):
+    """LinearPositionEmbeddingSine (attention.py:170-182) on the host -- weight preparation only (the constant
+    key vectors of padded window positions)."""
+    fb = torch.linspace(0, dim // 4 - 1, dim // 4)
+    x = xs.float()[:, None]
+    y = ys.float()[:, None]
+    return torch.cat([torch.sin(3.14 * x * fb * (1 / 200)), torch.cos(3.14 * x * fb * (1 / 200)),
+                      torch.sin(3.14 * y * fb * (1 / 200)), torch.cos(3.14 * y * fb * (1 / 200))], dim=-1)
+
+
+class EngineF(Engine):
+    # ------------------------------------------------------------------ weight preparation
+    def _lin(self, sd, key, name=None, **kw):
+        w = sd[key + ".weight"]
+        b = sd.get(key + ".bias")
+        self._add(name or key, w.reshape(w.shape[0], w.shape[1], 1, 1), b, **kw)
+
+    def _lin_cat(self, sd, keys, name):
+        w = torch.cat([sd[k + ".weight"] for k in keys], 0)
+        b = torch.cat([sd[k + ".bias"] for k in keys], 0)
+        self._add(name, w.reshape(w.shape[0], w.shape[1], 1, 1), b)
+
+    def _ln(self, sd, key):
+        self.ln[key] = (sd[key + ".weight"].float().contiguous().to(self.rt.device),
+                        sd[key + ".bias"].float().contiguous().to(self.rt.device))
+
+    def _f32(self, t):
+        return t.detach().float().contiguous().to(self.rt.device)
+
+    def _build_twins(self, sd, p):
+        cin = 3
+        for i, (c, patch, heads, sr) in enumerate(TWINS):
+            k = f"{p}.svt.patch_embeds.{i}.proj"
+            self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=patch, pad=(0, 0))
+            self._ln(sd, f"{p}.svt.patch_embeds.{i}.norm")
+            for j in (0, 1):
+                b = f"{p}.svt.blocks.{i}.{j}"
+                self._ln(sd, b + ".norm1")
+                self._ln(sd, b + ".norm2")
+                if j == 0:
+                    self._lin(sd, b + ".attn.qkv")
+                    bias = sd[b + ".attn.qkv.bias"].float()
+                    # padded window positions carry qkv(0) = bias (twins.py:846-857)
+                    self.consts[b + ".kpad"] = self._f32(bias[c:2 * c].repeat(49, 1))
+                    self.consts[b + ".vpad"] = self._f32(bias[2 * c:].repeat(49, 1))
+                else:
+                    self._lin(sd, b + ".attn.q")
+                    self._lin(sd, b + ".attn.kv")
+                    k = b + ".attn.sr"
+                    self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=sr, pad=(0, 0))
+                    self._ln(sd, b + ".attn.norm")
+                self._lin(sd, b + ".attn.proj")
+                self._lin(sd, b + ".mlp.fc1")
+                self._lin(sd, b + ".mlp.fc2")
+            k = f"{p}.svt.pos_block.{i}.proj.0"
+            self.consts[k + ".w"] = self._f32(sd[k + ".weight"].reshape(c, 9).t())   # [9][C]
+            self.consts[k + ".b"] = self._f32(sd[k + ".bias"])
+            cin = c
+
+    def _build_attn_layer(self, sd, p, merge_qkv):
+        self._ln(sd, p + ".norm1")
+        self._ln(sd, p + ".norm2")
+        if merge_qkv:
+            self._lin_cat(sd, (p + ".q", p + ".k", p + ".v"), p + ".qkv")
+        else:
+            self._lin(sd, p + ".q")
+            self._lin_cat(sd, (p + ".k", p + ".v"), p + ".kv")
+        self._lin(sd, p + ".proj")
+        self._lin(sd, p + ".ffn.0")
+        self._lin(sd, p + ".ffn.3")
+
+    def _build_vertical(self, sd, p, local):
+        self._ln(sd, p + ".norm1")
+        self._ln(sd, p + ".norm2")
+        a = p + ".attn"
+        self._lin(sd, a + ".context_proj")
+        self._lin(sd, a + ".v")
+        self._lin(sd, a + ".proj")
+        self._lin(sd, p + ".mlp.fc1")
+        self._lin(sd, p + ".mlp.fc2")
+        if local:
+            self._lin_cat(sd, (a + ".q", a + ".k"), a + ".qk")
+            # window positions beyond the grid: x_qk = 0 + positional code -> k = Wk enc(pos) + bk, v = bv
+            # (twins.py:375-407); constants of the weights
+            dy, dx = torch.meshgrid(torch.arange(7), torch.arange(7), indexing="ij")
+            enc = _enc_host(dx.reshape(-1), dy.reshape(-1), 192)
+            wk, bk = sd[a + ".k.weight"].float().cpu(), sd[a + ".k.bias"].float().cpu()
+            self.consts[a + ".kpad"] = self._f32(enc @ wk.t() + bk)
+            self.consts[a + ".vpad"] = self._f32(sd[a + ".v.bias"].float().repeat(49, 1))
+        else:
+            self._lin(sd, a + ".q")
+            self._lin(sd, a + ".k")
+            for k in (a + ".sr_key", a + ".sr_value"):
+                self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=4, pad=(0, 0))
+            self._ln(sd, a + ".norm")
+
+    def _build_flow(self, sd):
+        """FlowFormer (flowformer/__init__.py:6-18, transformer.py:29-42)."""
+        self.ln, self.consts = {}, {}
+        fe = "flow_estimator"
+        self._build_twins(sd, fe + ".context_encoder")
+        me = fe + ".memory_encoder"
+        self._build_twins(sd, me + ".feat_encoder")
+        k = me + ".channel_convertor"
+        self._add(k, sd[k + ".weight"], None)
+        ce = me + ".cost_perceiver_encoder"
+        k = ce + ".patch_embed.proj.0"
+        self.consts[k + ".w"] = self._f32(sd[k + ".weight"].reshape(16, 36).t())    # [36][16]
+        self.consts[k + ".b"] = self._f32(sd[k + ".bias"])
+        for k in (ce + ".patch_embed.proj.2", ce + ".patch_embed.proj.4"):
+            self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=2, pad=(2, 2))
+        self._conv(sd, ce + ".patch_embed.ffn_with_coord.0")
+        self._conv(sd, ce + ".patch_embed.ffn_with_coord.2")
+        self._ln(sd, ce + ".patch_embed.norm")
+        self.consts["latent"] = self._f32(sd[ce + ".latent_tokens"].reshape(K_LAT, 128))
+        self._build_attn_layer(sd, ce + ".input_layer", False)
+        for i in range(3):
+            self._build_attn_layer(sd, f"{ce}.encoder_layers.{i}", True)
+            self._build_vertical(sd, f"{ce}.vertical_encoder_layers.{i}.local_block", True)
+            self._build_vertical(sd, f"{ce}.vertical_encoder_layers.{i}.global_block", False)
+        md = fe + ".memory_decoder"
+        self._conv(sd, md + ".flow_token_encoder.0")
+        self._conv(sd, md + ".flow_token_encoder.2")
+        w, b = sd[md + ".proj.weight"], sd[md + ".proj.bias"]
+        self._add("ff.proj_net", w[:128], b[:128])     # tanh half   decoder.py:279-281
+        self._add("ff.proj_inp", w[128:], b[128:])     # relu half
+        self._build_attn_layer(sd, md + ".decoder_layer.cross_attend", False)
+        u = md + ".update_block"
+        self._conv(sd, u + ".encoder.convc1", cin_pad=self.rt.cp64(145))
+        self.layers[u + ".encoder.convf1"] = PatchConvLayer(self.rt, sd[u + ".encoder.convf1.weight"],
+                                                            sd[u + ".encoder.convf1.bias"])
+        for k in ("encoder.convc2", "encoder.convf2", "encoder.conv", "flow_head.conv1", "mask.0", "mask.2"):
+            self._conv(sd, f"{u}.{k}")
+        k = u + ".flow_head.conv2"
+        self.layers[k] = TapSplitConvLayer(self.rt, sd[k + ".weight"], sd[k + ".bias"])
+        for n in ("1", "2"):
+            # hx = [h(128) | inp(128) | motion(128) | aggregated motion(128)]   gru.py:150-154; the context share (inp)
+            # of the gate convolutions is evaluated once per forward, as in the RAFT engine
+            wz, wr = sd[f"{u}.gru.convz{n}.weight"], sd[f"{u}.gru.convr{n}.weight"]
+            bz, br = sd[f"{u}.gru.convz{n}.bias"], sd[f"{u}.gru.convr{n}.bias"]
+            wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
+            wq, bq = sd[f"{u}.gru.convq{n}.weight"], sd[f"{u}.gru.convq{n}.bias"]
+            keep = list(range(0, 128)) + list(range(256, 512))
+            self._add(f"gru.zr{n}", wzr[:, keep], None)
+            self._add(f"gru.q{n}", wq[:, keep], None)
+            self._add(f"gru.zr{n}.ctx", wzr[:, 128:256], bzr)
+            self._add(f"gru.q{n}.ctx", wq[:, 128:256], bq)
+        # GMA (gma.py:32-115): q pre-scaled by dim_head^-0.5, gamma folded into to_v
+        wqk = sd[md + ".att.to_qk.weight"]
+        self._add("gma.q", wqk[:128], None)
+        self._add("gma.k", wqk[128:], None)
+        gamma = float(sd[u + ".aggregator.gamma"].float().item())
+        self._wv = (sd[u + ".aggregator.to_v.weight"].float().reshape(128, 128) * gamma).to(self.rt.tdtype).to(self.rt.device)
+        self._wv_rep = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _tok(self, rows, c):
+        return torch.empty((rows, c), dtype=self.rt.tdtype, device=self.rt.device)
+
+    @staticmethod
+    def _img(t):
+        """[rows, C] token matrix as the [1, 1, rows, C] NHWC tensor gvfi_conv2d reads."""
+        return t if t.dim() == 4 else t.view(1, 1, t.shape[0], t.shape[1])
+
+    def _linear(self, name, x, cout=None, out=None, act=A.ACT_NONE, res=None, x1=None):
+        """out = act(x [| x1] W^T + b) (+ res); x, out: token matrices or Views of them."""
+        rt = self.rt
+        lay = self.layers[name]
+        xv = x if isinstance(x, View) else View(x)
+        rows = xv.npix
+        if out is None:
+            out = self._tok(rows, lay.cout)
+        ov = out if isinstance(out, View) else View(out)
+        mk = lambda v: View(v.t.view(1, 1, rows, v.t.shape[-1]), v.coff, v.c)
+        rv = None
+        if res is not None:
+            rv = mk(res if isinstance(res, View) else View(res))
+        x1v = None
+        if x1 is not None:
+            x1v = mk(x1 if isinstance(x1, View) else View(x1))
+        rt.conv(lay, mk(xv), mk(ov), x1=x1v, act1=act, res=rv)
+        return out
+
+    def _mlp_res(self, p, x, norm, eps, fc1, fc2):
+        """x + fc2(gelu(fc1(LN(x))))."""
+        y = self.rt.layernorm(x, self.ln[norm], eps)
+        h = self._linear(fc1, y, act=A.ACT_GELU)
+        return self._linear(fc2, h, res=x)
+
+    # ------------------------------------------------------------------ Twins-SVT (two stages)   encoders.py:21-48
+    def _twins(self, img, p):
+        rt, Ls, C_ = self.rt, self.layers, self.consts
+        n = img.shape[0]
+        x = View(img, 0, 3)
+        feats = []
+        for i, (c, patch, heads, sr) in enumerate(TWINS):
+            src = x if isinstance(x, View) else View(x)
+            H, W = src.t.shape[1:3]
+            assert H % patch == 0 and W % patch == 0
+            h, w = H // patch, W // patch
+            assert h % sr == 0 and w % sr == 0, "token grid must be a multiple of the sub-sampling ratio"
+            hd = c // heads
+            rows = n * h * w
+            emb = rt.act(n, h, w, c)
+            rt.conv(Ls[f"{p}.svt.patch_embeds.{i}.proj"], src, emb)
+            t = rt.layernorm(emb.view(rows, c), self.ln[f"{p}.svt.patch_embeds.{i}.norm"], 1e-5)
+            # ---- block 0: locally-grouped attention (ws 7)   twins.py:814-867
+            b = f"{p}.svt.blocks.{i}.0"
+            y = rt.layernorm(t, self.ln[b + ".norm1"], 1e-6)
+            qkv = self._linear(b + ".attn.qkv", y)
+            a = self._tok(rows, c)
+            rt.attn_window(View(qkv, 0, c), View(qkv, c, c), View(qkv, 2 * c, c), C_[b + ".kpad"], C_[b + ".vpad"], a,
+                           n, h, w, 7, heads, hd)
+            t = self._linear(b + ".attn.proj", a, res=t)
+            t = self._mlp_res(b, t, b + ".norm2", 1e-6, b + ".mlp.fc1", b + ".mlp.fc2")
+            # ---- PEG   twins.py:1100-1119
+            k = f"{p}.svt.pos_block.{i}.proj.0"
+            t = rt.dwconv3x3_res(t.view(n, h, w, c), C_[k + ".w"], C_[k + ".b"]).view(rows, c)
+            # ---- block 1: global sub-sampled attention   twins.py:870-925
+            b = f"{p}.svt.blocks.{i}.1"
+            y = rt.layernorm(t, self.ln[b + ".norm1"], 1e-6)
+            q = self._linear(b + ".attn.q", y)
+            hs, ws_ = h // sr, w // sr
+            m = hs * ws_
+            s = rt.act(n, hs, ws_, c)
+            rt.conv(Ls[b + ".attn.sr"], y.view(n, h, w, c), s)
+            s = rt.layernorm(s.view(n * m, c), self.ln[b + ".attn.norm"], 1e-5)
+            kv = self._linear(b + ".attn.kv", s)
+            a = self._tok(rows, c)
+            N = h * w
+            rt.attn_global(q, (N, 0, 1), View(kv, 0, c), View(kv, c, c), (m, 0, 1), a, (N, 0, 1), n, 1, N, m, heads, hd)
+            t = self._linear(b + ".attn.proj", a, res=t)
+            t = self._mlp_res(b, t, b + ".norm2", 1e-6, b + ".mlp.fc1", b + ".mlp.fc2")
+            x = t.view(n, h, w, c)
+            feats.append(x)
+        return feats
+
+    # ------------------------------------------------------------------ cost-volume encoder   encoder.py:349-466
+    def _vertical(self, p, x, ctx, n, B, h8, w8, local):
+        """Block(with_rpe, vert_c_dim 64) over the [n*K] latent images (twins.py:1028-1097, 331-546)."""
+        rt, Ls, C_ = self.rt, self.layers, self.consts
+        P8 = h8 * w8
+        n_img = n * K_LAT
+        rows = n_img * P8
+        a_ = p + ".attn"
+        y = rt.layernorm(x, self.ln[p + ".norm1"], 1e-5)
+        ctxp = self._linear(a_ + ".context_proj", ctx)            # [n*P8, 64]
+        att = self._tok(rows, 128)
+        if local:
+            xqk = self._tok(rows, 192)
+            rt.ff_xqk(y, ctxp, xqk, n_img, h8, w8, K_LAT, B, 1)
+            qk = self._linear(a_ + ".qk", xqk)
+            v = self._linear(a_ + ".v", y)
+            rt.attn_window(View(qk, 0, 128), View(qk, 128, 128), v, C_[a_ + ".kpad"], C_[a_ + ".vpad"], att, n_img, h8, w8,
+                           7, 8, 16)
+        else:
+            assert h8 % 4 == 0 and w8 % 4 == 0, "1/8 grid must be a multiple of sr_ratio 4 (frames padded to /32)"
+            xq = self._tok(rows, 192)
+            rt.ff_xqk(y, ctxp, xq, n_img, h8, w8, K_LAT, B, 2)
+            q = self._linear(a_ + ".q", xq)
+            xk = self._tok(rows, 192)
+            rt.ff_xqk(y, ctxp, xk, n_img, h8, w8, K_LAT, B, 0)
+            hs, ws_ = h8 // 4, w8 // 4
+            m = hs * ws_
+            sk = rt.act(n_img, hs, ws_, 128)
+            rt.conv(Ls[a_ + ".sr_key"], xk.view(n_img, h8, w8, 192), sk)
+            sv = rt.act(n_img, hs, ws_, 128)
+            rt.conv(Ls[a_ + ".sr_value"], y.view(n_img, h8, w8, 128), sv)
+            sk = rt.layernorm(sk.view(n_img * m, 128), self.ln[a_ + ".norm"], 1e-5)
+            sv = rt.layernorm(sv.view(n_img * m, 128), self.ln[a_ + ".norm"], 1e-5)
+            rt.pos_embed(self._grid(hs, ws_), m, 4.0, 0.0, 128, sk, n_img * m, True)
+            k = self._linear(a_ + ".k", sk)
+            v = self._linear(a_ + ".v", sv)
+            rt.attn_global(q, (P8, 0, 1), k, v, (m, 0, 1), att, (P8, 0, 1), n_img, 1, P8, m, 8, 16)
+        x = self._linear(a_ + ".proj", att, res=x)
+        return self._mlp_res(p, x, p + ".norm2", 1e-5, p + ".mlp.fc1", p + ".mlp.fc2")
+
+    def _grid(self, h, w):
+        key = ("grid", h, w)
+        if key not in self._grids:
+            self._grids[key] = self.rt.coords_init(1, h, w)
+        return self._grids[key]
+
+    def _cost_encoder(self, vol, ctx, n, B, h8, w8, taps):
+        rt, Ls, C_ = self.rt, self.layers, self.consts
+        P8 = h8 * w8
+        maps = n * P8
+        ce = "flow_estimator.memory_encoder.cost_perceiver_encoder"
+        pe = ce + ".patch_embed"
+        # ---- PatchEmbed of the cost maps   encoder.py:30-96
+        hp, wp = (h8 + 7) // 8 * 8, (w8 + 7) // 8 * 8
+        e1 = rt.cost_embed1(vol, C_[pe + ".proj.0.w"], C_[pe + ".proj.0.b"], maps, h8, w8, hp // 2, wp // 2)
+        e2 = rt.act(maps, hp // 4, wp // 4, 32)
+        rt.conv(Ls[pe + ".proj.2"], e1, e2, act1=A.ACT_RELU)
+        h3, w3 = hp // 8, wp // 8
+        T = h3 * w3
+        tok = rt.act(maps, h3, w3, 128)
+        rt.conv(Ls[pe + ".proj.4"], e2, View(tok, 0, 64))
+        rt.pos_embed(self._grid(h3, w3), T, 8.0, 4.0, 64, View(tok, 64, 64), maps * T, False)
+        f1 = self._linear(pe + ".ffn_with_coord.0", tok.view(maps * T, 128), act=A.ACT_RELU)
+        f2 = self._linear(pe + ".ffn_with_coord.2", f1)
+        xt = rt.layernorm(f2, self.ln[pe + ".norm"], 1e-5)
+        if taps is not None:
+            taps["f01_cost_tokens"] = xt.view(maps, T, 128)[:B * P8]
+        # ---- input_layer: the 8 learned latent tokens attend to the 28 tokens of every cost map   encoder.py:282-346
+        ip = ce + ".input_layer"
+        lat = C_["latent"].to(rt.tdtype)
+        qlat = self._linear(ip + ".q", rt.layernorm(lat, self.ln[ip + ".norm1"], 1e-5))
+        kv = self._linear(ip + ".kv", xt)
+        rows = n * K_LAT * P8
+        att = self._tok(rows, 128)
+        lay = (K_LAT * P8, 1, P8)          # row of (image b, pixel p, token i) in the image-major latent layout
+        rt.attn_global(qlat, (0, 0, 1), View(kv, 0, 128), View(kv, 128, 128), (P8 * T, T, 1), att, lay, n, P8, K_LAT, T,
+                       8, 16)
+        short = self._tok(rows, 128)
+        rt.tile_rows(C_["latent"], short, rows, P8, K_LAT, 128)
+        x = self._linear(ip + ".proj", att, res=short)
+        y = rt.layernorm(x, self.ln[ip + ".norm2"], 1e-5)
+        x = self._linear(ip + ".ffn.3", self._linear(ip + ".ffn.0", y, act=A.ACT_GELU), res=x)
+        short_cut = x
+        if taps is not None:
+            taps["f01_latent_in"] = x
+        for idx in range(3):
+            # ---- SelfAttentionLayer over the 8 tokens of a map   encoder.py:214-279
+            ep = f"{ce}.encoder_layers.{idx}"
+            y = rt.layernorm(x, self.ln[ep + ".norm1"], 1e-5)
+            qkv = self._linear(ep + ".qkv", y)
+            att = self._tok(rows, 128)
+            rt.attn_global(View(qkv, 0, 128), lay, View(qkv, 128, 128), View(qkv, 256, 128), lay, att, lay, n, P8, K_LAT,
+                           K_LAT, 8, 16)
+            x = self._linear(ep + ".proj", att, res=x)
+            y = rt.layernorm(x, self.ln[ep + ".norm2"], 1e-5)
+            x = self._linear(ep + ".ffn.3", self._linear(ep + ".ffn.0", y, act=A.ACT_GELU), res=x)
+            vp = f"{ce}.vertical_encoder_layers.{idx}"
+            x = self._vertical(vp + ".local_block", x, ctx, n, B, h8, w8, True)
+            x = self._vertical(vp + ".global_block", x, ctx, n, B, h8, w8, False)
+            if taps is not None and idx == 0:
+                taps["f01_latent_l0"] = x
+        mem = self._tok(rows, 128)
+        rt.copy(x, mem, 128, add=short_cut)      # cost_encoder_res   encoder.py:462-463
+        return mem
+
+    # ------------------------------------------------------------------ FlowFormer (both directions batched)
+    def _flowformer(self, imgA, B, iters, taps):
+        rt, Ls = self.rt, self.layers
+        self._grids = {}
+        n = 2 * B
+        H, W = imgA.shape[1:3]
+        assert H % 32 == 0 and W % 32 == 0, "GIMM-VFI-F: working resolution must be a multiple of 32"
+        h8, w8 = H // 8, W // 8
+        P8 = h8 * w8
+        fe = "flow_estimator"
+        md = fe + ".memory_decoder"
+        cfeat = self._twins(imgA, fe + ".context_encoder")
+        context = cfeat[1]                                          # [n,h8,w8,256]
+        ctx_rows = context.view(n * P8, 256)
+        ff = self._twins(imgA, fe + ".memory_encoder.feat_encoder")[1]
+        fmap = rt.act(n, h8, w8, 256)
+        rt.conv(Ls[fe + ".memory_encoder.channel_convertor"], ff, fmap)
+        # all-pairs cost volume of both directions (encoder.py:489-506; no 1/sqrt(d)): image i against its partner
+        fswap = torch.cat([fmap[B:], fmap[:B]], 0)
+        vol = rt.f32(n * P8, P8)
+        rt.conv(None, fmap, View(vol.view(n, h8, w8, P8)), groups=n, w_group_stride=P8 * fmap.shape[-1], w_raw=fswap,
+                cout=P8)
+        mem = self._cost_encoder(vol, ctx_rows, n, B, h8, w8, taps)
+        if taps is not None:
+            taps["f01_context"] = context[:B]
+            taps["f01_cfeat4"] = cfeat[0][:B]
+            taps["f01_ffeat"] = fmap[:B]
+            taps["f01_cost_memory"] = mem.view(n, K_LAT, P8, 128)[:B]
+        # ---- MemoryDecoder   decoder.py:257-321
+        hA = rt.act(n, h8, w8, 128)
+        hB = rt.act(n, h8, w8, 128)
+        inp = rt.act(n, h8, w8, 128)
+        rt.conv(Ls["ff.proj_net"], context, hA, act1=A.ACT_TANH)
+        rt.conv(Ls["ff.proj_inp"], context, inp, act1=A.ACT_RELU)
+        # GMA attention (once): softmax(q k^T / sqrt(128))   gma.py:53-76
+        gq = rt.act(n, h8, w8, 128)
+        gk = rt.act(n, h8, w8, 128)
+        rt.conv(Ls["gma.q"], inp, gq, out_scale=128 ** -0.5)
+        rt.conv(Ls["gma.k"], inp, gk)
+        sim = rt.f32(n * P8, P8)
+        rt.conv(None, gq, View(sim.view(n, h8, w8, P8)), groups=n, w_group_stride=P8 * 128, w_raw=gk, cout=P8)
+        assert P8 % rt.VE == 0
+        attn = torch.empty((n, 1, P8, P8), dtype=rt.tdtype, device=rt.device)
+        rt.softmax_rows(sim, P8, attn.view(n * P8, P8), n * P8)
+        del sim
+        if n not in self._wv_rep:
+            self._wv_rep[n] = self._wv.view(1, 1, 128, 128).expand(n, 1, 128, 128).contiguous()
+        wv_rep = self._wv_rep[n]
+        ca = md + ".decoder_layer.cross_attend"
+        kvm = self._linear(ca + ".kv", mem)                         # [n*K*P8, 128] = [key(64) | value(64)]
+        coords = rt.coords_init(n, h8, w8)
+        corr = rt.act(n, h8, w8, 145, zero=True, pitch=rt.cp64(145))    # [cost_global(64) | cost_forward(81) | 0]
+        corr_rows = corr.view(n * P8, corr.shape[-1])
+        flow8 = rt.act(n, h8, w8, 2, zero=True)
+        X = rt.act(n, h8, w8, 256)          # [motion(126) flow(2) | aggregated motion(128)]   gru.py:150-152
+        mfc = rt.act(n, h8, w8, 128)
+        vT = torch.empty((n, 1, 128, P8), dtype=rt.tdtype, device=rt.device)
+        c1 = rt.act(n, h8, w8, 256)
+        corflo = rt.act(n, h8, w8, 256)
+        f1 = rt.act(n, h8, w8, 128)
+        zbuf = rt.act(n, h8, w8, 128)
+        rh = rt.act(n, h8, w8, 128)
+        fh = rt.act(n, h8, w8, 256)
+        u = md + ".update_block"
+        ctxg = {}
+        for key in ("gru.zr1", "gru.q1", "gru.zr2", "gru.q2"):
+            lay = Ls[key + ".ctx"]
+            ctxg[key] = rt.f32(n, h8, w8, lay.cout)
+            rt.conv(lay, inp, ctxg[key])
+        fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
+        fpart = rt.f32(n, h8, w8, 20)
+        rows = n * P8
+        lay_q = (P8, 1, 0)
+        lay_k = (K_LAT * P8, 1, P8)
+        iters = 32 if iters is None else iters
+        for it in range(iters):
+            # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
+            rt.cost_lookup(vol, coords, View(corr, 64, 81), rows, h8, w8)
+            t1 = self._linear(md + ".flow_token_encoder.0", View(corr_rows, 64, 81), act=A.ACT_GELU)
+            query = self._linear(md + ".flow_token_encoder.2", t1)
+            # cross-attention of the one query against the map's 8 latent tokens   decoder.py:84-120
+            qn = rt.layernorm(query, self.ln[ca + ".norm1"], 1e-5)
+            rt.pos_embed(coords, rows, 1.0, 0.0, 64, qn, rows, True)
+            q = self._linear(ca + ".q", qn)
+            a = self._tok(rows, 64)
+            rt.attn_global(q, lay_q, View(kvm, 0, 64), View(kvm, 64, 64), lay_k, a, lay_q, n, P8, 1, K_LAT, 8, 8)
+            x = self._linear(ca + ".proj", a, x1=query, res=query)
+            y = rt.layernorm(x, self.ln[ca + ".norm2"], 1e-5)
+            self._linear(ca + ".ffn.3", self._linear(ca + ".ffn.0", y, act=A.ACT_GELU), out=View(corr_rows, 0, 64), res=x)
+            # GMAUpdateBlock   gru.py:130-160
+            rt.flow_pack(coords, flow8, View(X, 126, 2))
+            rt.conv(Ls[u + ".encoder.convc1"], corr, c1, act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
+            rt.patch_conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, scratch=fcol, act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
+            rt.conv(Ls[u + ".encoder.conv"], corflo, View(X, 0, 126), act1=A.ACT_RELU)
+            # global motion aggregation: X[128:256] = mf + gamma * attn @ (mf Wv^T)   gma.py:101-115
+            rt.copy(View(X, 0, 128), mfc, 128)
+            rt.conv(None, wv_rep, vT, groups=n, w_group_stride=P8 * 128, w_raw=mfc, cout=P8)
+            Xr = X.view(n, 1, P8, 256)
+            rt.conv(None, attn, View(Xr, 128, 128), groups=n, w_group_stride=128 * P8, w_raw=vT, cout=128,
+                    res=View(Xr, 0, 128))
+            hc, hn = hA, hB
+            for nn_ in ("1", "2"):
+                rt.conv(Ls["gru.zr" + nn_], hc, zbuf, x1=X, epi=A.EPI_GRU_ZR, y2=rh, aux0=hc, res=ctxg["gru.zr" + nn_])
+                rt.conv(Ls["gru.q" + nn_], rh, hn, x1=X, epi=A.EPI_GRU_Q, aux0=hc, aux1=zbuf, res=ctxg["gru.q" + nn_])
+                hc, hn = hn, hc
+            rt.conv(Ls[u + ".flow_head.conv1"], hA, fh, act1=A.ACT_RELU)
+            rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh, View(coords), res=View(coords), scratch=fpart)
+            if taps is not None and it in (0, iters - 1):
+                taps[f"f01_cost_fwd_it{it}"] = corr[:B, ..., 64:145].clone()
+                taps[f"f01_cost_global_it{it}"] = corr[:B, ..., 0:64].clone()
+                taps[f"f01_net_it{it}"] = hA[:B].clone()
+                taps[f"f01_coords_it{it}"] = coords[:B].clone()
+        rt.conv(Ls[u + ".mask.0"], hA, fh, act1=A.ACT_RELU)
+        mask = rt.f32(n, h8, w8, 576)
+        rt.conv(Ls[u + ".mask.2"], fh, mask, out_scale=0.25)
+        flow_up = rt.convex_upsample(coords, mask)
+        return flow_up, fmap, cfeat, (h8, w8)
+
+    def _flow(self, imgA, B, iters, taps):
+        """gimmvfi_f.py:114-139: FlowFormer both ways, BidirCorrBlock on its (converted) features, context features
+        of the Twins context encoder at 1/4 and 1/8 -- no projections in this model."""
+        flow_up, fmap, cfeat, (h8, w8) = self._flowformer(imgA, B, iters, taps)
+        pyr, pyrT = self._bidir_pyramids(fmap, B, h8, w8)
+        return flow_up[:B], flow_up[B:], pyr, pyrT, cfeat[0], cfeat[1], (h8, w8)

@@ -20,7 +20,8 @@ import torch.nn as nn
 from . import lib as L
 from .engine import Engine
 from .ops import Runtime
-from .params import gimm_param_spec, gimm_state_dict, param_spec, random_state_dict
+from .params import (gimm_param_spec, gimm_state_dict, param_spec, param_spec_f, random_state_dict,
+                     random_state_dict_f)
 
 
 class _Node(nn.Module):
@@ -31,6 +32,10 @@ _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 
 
 class GIMMVFI_R(nn.Module):
+    _spec = staticmethod(param_spec)
+    _init_sd = staticmethod(random_state_dict)
+    _engine_cls = Engine
+
     def __init__(self, config=None, precision=None):
         super().__init__()
         self.config = config
@@ -44,8 +49,8 @@ class GIMMVFI_R(nn.Module):
             cr = config.get("coord_range") if isinstance(config, dict) else getattr(config, "coord_range", None)
             if cr is not None:
                 self.coord_range = (float(cr[0]), float(cr[1]))
-        sd0 = random_state_dict(0)
-        for name, shape in param_spec().items():
+        sd0 = self._init_sd(0)
+        for name, shape in self._spec().items():
             parts = name.split(".")
             node = self
             for p in parts[:-1]:
@@ -53,7 +58,7 @@ class GIMMVFI_R(nn.Module):
                     node.add_module(p, _Node())
                 node = node._modules[p]
             val = sd0[name].clone()
-            if parts[-1] in _BUFFER_SUFFIXES:
+            if parts[-1] in _BUFFER_SUFFIXES or not val.is_floating_point():
                 node.register_buffer(parts[-1], val)
             else:
                 node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
@@ -89,7 +94,7 @@ class GIMMVFI_R(nn.Module):
                         "'cuda' (there is no CPU fallback)"
                     )
                 runtime = Runtime(L.get(), self.precision, device)
-            self._engine = Engine(runtime, self.state_dict())
+            self._engine = self._engine_cls(runtime, self.state_dict())
             self._engine_key = key
         return self._engine
 
@@ -98,7 +103,7 @@ class GIMMVFI_R(nn.Module):
         assert isinstance(t, list)
         assert isinstance(coord, list)
         assert len(t) == len(coord)
-        iters = self.raft_iter  # gimmvfi_r.py:127-132 hard-codes 20
+        iters = self._iters()
         eng = self.engine(img_xs.device)
         if not (self.use_graph and img_xs.is_cuda and eng.rt.ev_log is None):
             return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
@@ -113,6 +118,9 @@ class GIMMVFI_R(nn.Module):
             self._graphs = {}
             torch.cuda.synchronize(img_xs.device)
             return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
+
+    def _iters(self):
+        return self.raft_iter  # gimmvfi_r.py:127-132 hard-codes 20
 
     def _forward_graph(self, eng, img_xs, coord, t, iters, ds_factor):
         """Capture once per input signature, then replay; inputs are copied into the graph's static buffers and
@@ -182,6 +190,31 @@ class GIMMVFI_R(nn.Module):
         mse = torch.reshape((preds - targets) ** 2, (b, -1)).mean(dim=-1)
         psnr = -10 * torch.log10(mse)
         return psnr.mean() if reduction == "mean" else (psnr.sum() if reduction == "sum" else psnr)
+
+
+class GIMMVFI_F(GIMMVFI_R):
+    """Drop-in for reference generalizable_INR/gimmvfi_f.py:27-419: the same model with the FlowFormer flow estimator
+    (Twins-SVT encoders, latent cost-volume encoder, 32-iteration GMA decoder) instead of RAFT.  Same 639
+    state_dict keys (``load_state_dict(strict=True)`` of reference checkpoints), ``forward(img_xs, coord, t,
+    ds_factor)`` without an ``iters`` argument (gimmvfi_f.py:304).  The constructor does not read
+    ``pretrained_ckpt/flowformer_sintel.pth`` (flowformer/__init__.py:10): those weights are part of the GIMM-VFI-F
+    checkpoint loaded afterwards.  Frames must be padded to multiples of 32 at the working resolution (the CLI's
+    InputPadder does that, src/video_Nx.py:146)."""
+
+    _spec = staticmethod(param_spec_f)
+    _init_sd = staticmethod(random_state_dict_f)
+
+    @property
+    def _engine_cls(self):
+        from .engine_f import EngineF
+
+        return EngineF
+
+    def _iters(self):
+        return None   # decoder_depth = 32 (flowformer/configs/submission.py:52, decoder.py:289-290)
+
+    def forward(self, img_xs, coord=None, t=None, ds_factor=None):
+        return super().forward(img_xs, coord=coord, t=t, iters=None, ds_factor=ds_factor)
 
 
 class GIMM(nn.Module):

@@ -66,7 +66,8 @@ class ConvLayer:
         # tile of a K chunk is one contiguous block (conv_igemm_glds.hip, w_layout = 1)
         bke = 8 * rt.VE
         self.w_glds = None
-        if cp % bke == 0 and pad_mode == L.PAD_ZEROS and not os.environ.get("GVFI_NO_WGLDS"):
+        # (the LDS-DMA kernel keeps tap validity in a 32-bit mask: filters with more than 32 taps take the generic kernel)
+        if cp % bke == 0 and pad_mode == L.PAD_ZEROS and kh * kw <= 32 and not os.environ.get("GVFI_NO_WGLDS"):
             k = kh * kw * cp
             # K chunks in the kernel's walk order: channel chunk outer, filter tap inner (L2 locality of the taps)
             wk = pk.reshape(cout, kh * kw, cp // bke, 8, rt.VE).permute(0, 2, 1, 3, 4).reshape(cout, k // bke, 8, rt.VE)
@@ -474,6 +475,70 @@ class Runtime:
                                          dst.is_f32, c, float(mul), dst.npix, self.dtype, self.stream()),
                   "copy_channels")
         return dst
+
+    # ------------------------------------------------------------------ FlowFormer glue (csrc/flowformer_ops.hip)
+    def layernorm(self, x, gb, eps, out=None):
+        """nn.LayerNorm over the channels of a token matrix / NHWC tensor (gb = (gamma, beta) float tensors)."""
+        x = V(x)
+        if out is None:
+            out = torch.empty_like(x.t)
+        o = V(out)
+        self._chk(self.lib.layernorm(x.ptr, x.ld, gb[0].data_ptr(), gb[1].data_ptr(), float(eps), o.ptr, o.ld, x.npix,
+                                     x.c, self.dtype, self.stream()), "layernorm")
+        return out
+
+    def dwconv3x3_res(self, x, w9c, bias):
+        n, h, w, c = x.shape
+        out = torch.empty_like(x)
+        self._chk(self.lib.dwconv3x3_res(x.data_ptr(), c, w9c.data_ptr(), bias.data_ptr(), out.data_ptr(), c, n, h, w, c,
+                                         self.dtype, self.stream()), "dwconv3x3_res")
+        return out
+
+    def pos_embed(self, coords, period, scale, offset, dim, out, rows, accumulate):
+        o = V(out)
+        self._chk(self.lib.pos_embed(coords.data_ptr(), period, float(scale), float(offset), dim, o.ptr, o.ld, rows,
+                                     1 if accumulate else 0, self.dtype, self.stream()), "pos_embed")
+
+    def cost_embed1(self, vol, w, b, maps, h, w_, ho, wo):
+        out = self.act(maps, ho, wo, 16)
+        self._chk(self.lib.cost_embed1(vol.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), out.shape[-1], maps,
+                                       h, w_, ho, wo, self.dtype, self.stream()), "cost_embed1")
+        return out
+
+    def cost_lookup(self, vol, coords, out, q, h, w, radius=4):
+        o = V(out)
+        self._chk(self.lib.cost_lookup(vol.data_ptr(), coords.data_ptr(), o.ptr, o.ld, q, h, w, radius, self.dtype,
+                                       self.stream()), "cost_lookup")
+
+    def attn_window(self, q, k, v, kpad, vpad, out, n_img, h, w, ws, heads, hd):
+        q, k, v, o = V(q), V(k), V(v), V(out)
+        self._chk(self.lib.attn_window(q.ptr, q.ld, k.ptr, k.ld, v.ptr, v.ld, kpad.data_ptr(), vpad.data_ptr(), o.ptr,
+                                       o.ld, n_img, h, w, ws, heads, hd, float(hd ** -0.5), self.dtype, self.stream()),
+                  "attn_window")
+        return out
+
+    def attn_global(self, q, qrow, k, v, krow, out, orow, g1, g0, nq, m, heads, hd):
+        """qrow / krow / orow = (b1, b0, s): row = g1*b1 + g0*b0 + i*s (see gvfi_attn_global)."""
+        q, k, v, o = V(q), V(k), V(v), V(out)
+        self._chk(self.lib.attn_global(q.ptr, q.ld, *qrow, k.ptr, k.ld, v.ptr, v.ld, *krow, o.ptr, o.ld, *orow, g1, g0, nq,
+                                       m, heads, hd, float(hd ** -0.5), self.dtype, self.stream()), "attn_global")
+        return out
+
+    def ff_xqk(self, x, ctx, out, n_img, h, w, k, nb, enc_mode, ws=7):
+        x, c, o = V(x), V(ctx), V(out)
+        self._chk(self.lib.ff_xqk(x.ptr, x.ld, x.c, c.ptr, c.ld, c.c, o.ptr, o.ld, n_img, h, w, k, nb, enc_mode, ws,
+                                  self.dtype, self.stream()), "ff_xqk")
+        return out
+
+    def tile_rows(self, table, out, rows, p, k, c):
+        o = V(out)
+        self._chk(self.lib.tile_rows(table.data_ptr(), o.ptr, o.ld, rows, p, k, c, self.dtype, self.stream()), "tile_rows")
+        return out
+
+    def softmax_rows(self, x, n, out, rows):
+        o = V(out)
+        self._chk(self.lib.softmax_rows(x.data_ptr(), n, o.ptr, o.ld, rows, self.dtype, self.stream()), "softmax_rows")
+        return out
 
     def frames_to_u8(self, frames_nchw):
         b, _, h, w = frames_nchw.shape

@@ -6,7 +6,7 @@ _PKG = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
-from .generalizable_INR import gimm, gimmvfi_r  # noqa: E402
+from .generalizable_INR import gimm, gimmvfi_f, gimmvfi_r  # noqa: E402
 
 
 def create_model(config, ema=False):
@@ -16,9 +16,7 @@ def create_model(config, ema=False):
     elif model_type == "gimm":
         model = gimm(config)
     elif model_type == "gimmvfi_f":
-        raise NotImplementedError(
-            "gimmvfi_f: the FlowFormer encoder is not implemented on the MI355X kernels yet (SURVEY.md section 8f)"
-        )
+        model = gimmvfi_f(config)
     else:
         raise ValueError(f"{model_type} is invalid..")
     if ema:

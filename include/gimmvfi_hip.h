@@ -29,7 +29,8 @@ enum {
     GVFI_ACT_PRELU = 3,   /* per-channel slope */
     GVFI_ACT_SIGMOID = 4,
     GVFI_ACT_TANH = 5,
-    GVFI_ACT_SIN = 6
+    GVFI_ACT_SIN = 6,
+    GVFI_ACT_GELU = 7     /* exact (erf) GELU: nn.GELU() of the FlowFormer MLPs / token encoders */
 };
 enum { GVFI_PAD_ZEROS = 0, GVFI_PAD_REFLECT = 1 };
 enum {
@@ -196,6 +197,50 @@ int gvfi_flow_split_t(const float* flow_t, const float* t, float* ft0, float* ft
 /* lookup coordinates of gimmvfi_r.py:494-507: c0 = grid + fl1/(1-t), c1 = grid + fl0/t */
 int gvfi_lookup_coords(const float* fl0, const float* fl1, const float* t, float* c0, float* c1,
                        int B, int h, int w, void* stream);
+
+/* ---- GIMM-VFI-F: FlowFormer flow estimator glue (flowformer/core/FlowFormer/LatentCostFormer/*; the Twins-SVT
+ * backbone is timm's twins_svt_large, vendored classes twins.py:814-983,1028-1150).  Token tensors are row matrices
+ * [rows][ld] in `dtype`; the linear layers, patch / sub-sampling convolutions, cost volume and the GMA contractions go
+ * through gvfi_conv2d. ------------------------------------------------------------------------------------------- */
+/* nn.LayerNorm(C): y = (x - mean) * rsqrt(var + eps) * gamma + beta   (twins.py:1146,1169; encoder.py:65,236-237) */
+int gvfi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                   long long rows, int C, int dtype, void* stream);
+/* PEG (twins.py:1100-1119): y = x + depthwise3x3(x) + bias, NHWC, w float [9][C] */
+int gvfi_dwconv3x3_res(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int H,
+                       int W, int C, int dtype, void* stream);
+/* LinearPositionEmbeddingSine (attention.py:170-182): out[row, 0:dim] (+)= enc(scale * coords[row % period] + offset),
+ * coords float [period][2] (x, y) */
+int gvfi_pos_embed(const float* coords, long long period, float scale, float offset, int dim, void* out, int ldo,
+                   long long rows, int accumulate, int dtype, void* stream);
+/* first cost-map convolution (encoder.py:39-41,70-75): Conv2d(1,16,6,s2,p2)+ReLU over float maps [maps][H][W]
+ * (zero-extended right/bottom to Ho*2 x Wo*2) -> out [maps][Ho][Wo][ldo >= 16]; w float [36][16] */
+int gvfi_cost_embed1(const float* vol, const float* w, const float* bias, void* out, int ldo, long long maps,
+                     int H, int W, int Ho, int Wo, int dtype, void* stream);
+/* MemoryDecoder.encode_flow_token (decoder.py:237-255): (2r+1)^2 bilinear taps of cost map q around coords[q] */
+int gvfi_cost_lookup(const float* maps, const float* coords, void* out, int ldo, long long Q, int h, int w,
+                     int radius, int dtype, void* stream);
+/* locally-grouped attention over ws x ws windows of an H x W token grid (twins.py:814-867, 331-427); kpad/vpad float
+ * [ws*ws][heads*head_dim]: key / value of the window positions outside the grid; head_dim 8, 16 or 32 */
+int gvfi_attn_window(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
+                     const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
+                     int head_dim, float scale, int dtype, void* stream);
+/* attention of NQ queries against M keys per group (g1 < G1, g0 < G0); rows: query g1*qb1 + g0*qb0 + i*qs,
+ * key/value g1*kb1 + g0*kb0 + j*ks, output g1*ob1 + g0*ob0 + i*os (twins.py:870-925, 430-546; attention.py:10-66;
+ * encoder.py:214-346; decoder.py:35-120) */
+int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
+                     const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
+                     long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
+                     int head_dim, float scale, int dtype, void* stream);
+/* out = [x | ctx[cimg(im)]] (+ positional code of the window position (enc_mode 1) or grid position (2)) for the
+ * context-aware attention of the cost encoder (twins.py:366-395, 465-493); cimg reproduces the reference's
+ * context.repeat() tiling over (batch, latent token): nb = pairs per direction, K = latent tokens */
+int gvfi_ff_xqk(const void* x, int ldx, int Cx, const void* ctx, int ldc, int Cc, void* out, int ldo, int n_img,
+                int H, int W, int K, int nb, int enc_mode, int ws, int dtype, void* stream);
+/* out[row, 0:C] = table[(row / P) % K]  (the learned latent tokens broadcast over the cost maps, encoder.py:420) */
+int gvfi_tile_rows(const float* table, void* out, int ldo, long long rows, int P, int K, int C, int dtype,
+                   void* stream);
+/* row soft-max of the GMA similarity (gma.py:70-74): x float [rows][n] -> y [rows][ldy] in dtype, pad columns zeroed */
+int gvfi_softmax_rows(const float* x, int n, void* y, int ldy, long long rows, int dtype, void* stream);
 
 /* ---- frame synthesis glue (modules/fi_components.py:57-94,255-340; gimmvfi_r.py:213-220,305-308) */
 /* out = clamp((sigmoid(mask)*warp(img0,f0) + (1-sigmoid(mask))*warp(img1,f1) + 1)/2, 0, 1), NCHW float */

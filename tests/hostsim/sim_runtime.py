@@ -54,6 +54,8 @@ def _act(v, kind, slope):
         return torch.tanh(v)
     if kind == L.ACT_SIN:
         return torch.sin(v)
+    if kind == L.ACT_GELU:
+        return F.gelu(v)
     raise ValueError(kind)
 
 
