@@ -1,0 +1,173 @@
+"""GIMM-VFI-F (FlowFormer flow estimator) on the HIP engine.
+
+CPU (`-m "not gpu"`): the whole EngineF launch list in the host emulator (glue kernels = the real .hip sources,
+contractions through the independent torch statement of sim_runtime) against the reference golden and, stage by
+stage, the oracle -- batch 2, so the reference's context.repeat() tiling over (batch, latent token) is exercised.
+GPU (`-m gpu`): libgimmvfi_hip.so through the drop-in model API against the same goldens.
+
+Tolerances: fp32 mode PSNR >= 80 dB, flows within 5e-3 px (32 recurrent iterations of lookup -> GRU); bf16 mode
+PSNR >= 35 dB and mean flow error < 0.1 px (bf16 token streams through two Twins encoders, 6 context-aware blocks
+and 32 decoder iterations; flows / cost volume / coordinates stay fp32)."""
+import pytest
+import torch
+
+import gimmvfi_f_oracle as forc
+from util import golden_inputs, load_golden, maxabs, nchw, psnr
+
+DEV = "cuda:0"
+
+
+def _lat(t, B, P8):
+    # image-major latent layout [(image, token k), pixel p, 128] -> the reference's (B*P8, 8, 128)
+    return t.float().reshape(-1, 8, P8, 128)[:B].permute(0, 2, 1, 3).reshape(B * P8, 8, 128)
+
+
+def _check_taps(taps, otaps, B, tol):
+    def rel(a, b):
+        return maxabs(a, b) / (float(b.abs().max()) + 1e-12)
+
+    P8 = otaps["f01_cost_memory"].shape[0] // B
+    assert rel(nchw(taps["f01_context"]), otaps["f01_context"]) < tol
+    assert rel(nchw(taps["f01_cfeat4"]), otaps["f01_cfeat4"]) < tol
+    assert rel(nchw(taps["f01_ffeat"]), otaps["f01_ffeat"]) < tol
+    assert rel(taps["f01_cost_tokens"], otaps["f01_cost_tokens"]) < tol
+    assert rel(_lat(taps["f01_latent_in"], B, P8), otaps["f01_latent_in"]) < tol
+    assert rel(_lat(taps["f01_latent_l0"], B, P8), otaps["f01_latent_l0"]) < tol
+    mem = taps["f01_cost_memory"].float().permute(0, 2, 1, 3).reshape(B * P8, 8, 128)
+    assert rel(mem, otaps["f01_cost_memory"]) < tol
+    assert rel(nchw(taps["f01_cost_fwd_it0"]), otaps["f01_cost_fwd_it0"]) < tol
+    assert rel(nchw(taps["f01_cost_global_it0"]), otaps["f01_cost_global_it0"]) < tol
+    assert rel(nchw(taps["f01_net_it0"]), otaps["f01_net_it0"]) < tol
+    assert rel(nchw(taps["f01_net_it31"]), otaps["f01_net_it31"]) < 10 * tol
+
+
+def test_engine_f_sim_fp32_matches_golden_and_oracle(sd_f):
+    from gimmvfi_hip.engine_f import EngineF
+    from sim_runtime import SimRuntime
+
+    meta, gold = load_golden("f_b2_128x128_t025_075")
+    x, coords, ts = golden_inputs(meta)
+    eng = EngineF(SimRuntime("fp32"), sd_f)
+    taps = {}
+    out = eng.forward(x, coords, ts, iters=None, taps=taps)
+    assert maxabs(out["raft_flow"], gold["raft_flow"]) < 2e-3
+    for i in range(2):
+        assert psnr(out["imgt_pred"][i], gold[f"imgt_pred_{i}"]) > 100.0
+        assert maxabs(out["flowt"][i], gold[f"flowt_{i}"]) < 5e-3
+        assert tuple(out["flowt"][i].shape) == tuple(gold[f"flowt_{i}"].shape)
+    otaps = {}
+    with torch.no_grad():
+        forc.forward(sd_f, x, coords, ts, None, taps=otaps)
+    _check_taps(taps, otaps, meta["B"], 1e-4)
+
+
+def test_create_model_f_contract(sd_f):
+    """create_model('gimmvfi_f') returns the drop-in module: reference key set, strict load, no CPU fallback."""
+    import json
+    import os
+
+    from src.models import create_model
+    from util import GOLDEN
+
+    m, ema = create_model({"type": "gimmvfi_f", "coord_range": [-1.0, 1.0]})
+    assert ema is None
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys_f.json")))
+    got = m.state_dict()
+    assert set(got.keys()) == set(keys.keys())
+    assert all(list(got[k].shape) == v for k, v in keys.items())
+    m.load_state_dict(sd_f, strict=True)
+    x = torch.rand(1, 3, 2, 128, 128)
+    c = m.sample_coord_input(1, (128, 128), [0.5], device=x.device)
+    with pytest.raises(RuntimeError):
+        m(x, [(c, None)], t=[0.5 * torch.ones(1)])     # CPU tensors: the product path has no fallback
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+def _model(sd, precision):
+    from gimmvfi_hip.model import GIMMVFI_F
+
+    m = GIMMVFI_F(precision=precision)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+def _run(m, x, coords, ts, ds=None):
+    out = m(x.to(DEV), [(c[0].to(DEV), None) for c in coords], t=[t.to(DEV) for t in ts], ds_factor=ds)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["f_128x192_t050", "f_b2_128x128_t025_075"])
+def test_gpu_f_fp32_matches_reference_golden(name, sd_f):
+    meta, gold = load_golden(name)
+    x, coords, ts = golden_inputs(meta)
+    out = _run(_model(sd_f, "fp32"), x, coords, ts, meta["ds"])
+    assert maxabs(out["raft_flow"], gold["raft_flow"]) < 5e-3
+    for i in range(len(meta["t"])):
+        p = psnr(out["imgt_pred"][i], gold[f"imgt_pred_{i}"])
+        assert p >= 80.0, p
+        assert tuple(out["flowt"][i].shape) == tuple(gold[f"flowt_{i}"].shape)
+        d = (out["flowt"][i].cpu() - gold[f"flowt_{i}"]).abs().flatten()
+        assert float(d.kthvalue(int(d.numel() * 0.999))[0]) < 5e-3
+
+
+@pytest.mark.gpu
+def test_gpu_f_fp32_stage_taps_vs_oracle(sd_f):
+    meta, _ = load_golden("f_b2_128x128_t025_075")
+    x, coords, ts = golden_inputs(meta)
+    otaps = {}
+    with torch.no_grad():
+        forc.forward(sd_f, x, coords, ts, None, taps=otaps)
+    m = _model(sd_f, "fp32")
+    taps = {}
+    m.engine(DEV).forward(x.to(DEV), [(c[0].to(DEV), None) for c in coords], [t.to(DEV) for t in ts], iters=None,
+                          taps=taps)
+    torch.cuda.synchronize()
+    _check_taps({k: v.cpu() for k, v in taps.items()}, otaps, meta["B"], 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["f_128x192_t050", "f_b2_128x128_t025_075"])
+def test_gpu_f_bf16_matches_reference_golden(name, sd_f):
+    meta, gold = load_golden(name)
+    x, coords, ts = golden_inputs(meta)
+    out = _run(_model(sd_f, "bf16"), x, coords, ts, meta["ds"])
+    for i in range(len(meta["t"])):
+        assert torch.isfinite(out["imgt_pred"][i]).all()
+        p = psnr(out["imgt_pred"][i], gold[f"imgt_pred_{i}"])
+        assert p >= 35.0, p
+        d = (out["flowt"][i].cpu().float() - gold[f"flowt_{i}"]).abs().flatten()
+        assert float(d.mean()) < 0.1
+
+
+@pytest.mark.gpu
+def test_gpu_f_benchmark_size_bf16_vs_fp32(sd_f):
+    """BASELINE.json configs[3] shape (448x256, batch 8): finite output, bf16 vs fp32-mode PSNR, graph replay equals
+    the first (captured) call."""
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    B, H, W = 8, 256, 448
+    x = synthetic_pairs(B, H, W, seed=42)
+    coords = [(forc.sample_coord_input(B, (H, W), [0.5], 1.0), None)]
+    ts = [0.5 * torch.ones(B)]
+    m16 = _model(sd_f, "bf16")
+    o16 = _run(m16, x, coords, ts)
+    o16b = _run(m16, x, coords, ts)
+    assert torch.isfinite(o16["imgt_pred"][0]).all()
+    assert psnr(o16b["imgt_pred"][0], o16["imgt_pred"][0]) >= 60.0
+    # informational: graph-replay time of the whole forward (not a pass criterion)
+    xd, cd, td = x.to(DEV), [(coords[0][0].to(DEV), None)], [ts[0].to(DEV)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        m16(xd, cd, t=td)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(f"\n[gimmvfi_f bf16 448x256 B=8] {ms:.1f} ms/step = {B / ms * 1e3:.1f} interpolated frames/s")
+    del m16
+    torch.cuda.empty_cache()
+    o32 = _run(_model(sd_f, "fp32"), x, coords, ts)
+    p = psnr(o16["imgt_pred"][0], o32["imgt_pred"][0])
+    assert p >= 35.0, p
