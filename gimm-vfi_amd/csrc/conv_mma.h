@@ -200,6 +200,10 @@ __device__ __forceinline__ void act8s(float (&v)[8], int act, const float (&s)[8
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
             break;
+        case GVFI_ACT_GELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            break;
         default:
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = sinf(v[e]);
