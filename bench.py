@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--ds", type=float, default=1.0, help="DS_SCALE of the reference CLI (flow estimated at ds x resolution)")
     ap.add_argument("--n-interp", type=int, default=2, help="N of 'Nx interpolation': N-1 frames per pair (t = i/N)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="r", choices=["r", "f"],
+                    help="r = GIMM-VFI-R (RAFT flow estimator, BASELINE.json configs[1], the default bench line); "
+                         "f = GIMM-VFI-F (FlowFormer flow estimator, configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default=None, help="write a per-conv-shape time table (markdown) to this path")
     args = ap.parse_args()
@@ -53,13 +56,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
 
-    from gimmvfi_hip.model import GIMMVFI_R
-    from gimmvfi_hip.params import random_state_dict
+    from gimmvfi_hip.model import GIMMVFI_F, GIMMVFI_R
+    from gimmvfi_hip.params import random_state_dict, random_state_dict_f
     from gimmvfi_hip.synth import synthetic_pairs
 
     B, H, W = args.batch, args.height, args.width
-    model = GIMMVFI_R(precision=args.precision)
-    model.load_state_dict(random_state_dict(0), strict=True)
+    if args.model == "f":
+        model = GIMMVFI_F(precision=args.precision)
+        model.load_state_dict(random_state_dict_f(0), strict=True)
+    else:
+        model = GIMMVFI_R(precision=args.precision)
+        model.load_state_dict(random_state_dict(0), strict=True)
     model = model.to(dev).eval()
     x = synthetic_pairs(B, H, W, seed=100 + rank).to(dev)
     # src/video_Nx.py:164-181: one coordinate grid / timestep per inserted frame, flow at ds x resolution
@@ -153,7 +160,7 @@ def main():
             "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / ev_steps * 1e3, 3),
             "timing": f"HIP events around each launch, eager pass of {ev_steps} steps after the timed graph-replay region",
         }
-        if (H, W, NI, ds) == (256, 448, 2, None):
+        if (H, W, NI, ds) == (256, 448, 2, None) and args.model == "r":
             # whole-path figure SURVEY.md 8(d) asks for: MINIMAL algorithmic FLOPs per frame (2 065 GF at 448x256, T=1,
             # redundant reference work removed) x frames/s against the same dense peak
             path_tf = 2065e9 * value / world / 1e12
@@ -161,15 +168,16 @@ def main():
                                 "frac": round(path_tf / peak, 4)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(H, W)
+            cpu = cpu_baseline(H, W, args.model)
         line = {
             "metric": "interpolated frames/sec", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"GIMM-VFI-R {W}x{H} batch={B} pairs/GPU, {NI}x interpolation (t=i/{NI}), DS_SCALE={args.ds:g}, "
-                                   "seeded random-init weights",
-                       "pairs_per_step_per_gpu": B, "raft_iters": 20, "parallelism": f"pair-sharded x{world}"},
+            "config": {"workload": f"GIMM-VFI-{args.model.upper()} {W}x{H} batch={B} pairs/GPU, {NI}x interpolation (t=i/{NI}), "
+                                   f"DS_SCALE={args.ds:g}, seeded random-init weights",
+                       "pairs_per_step_per_gpu": B, "flow_iters": 20 if args.model == "r" else 32,
+                       "parallelism": f"pair-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
@@ -177,14 +185,20 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(H, W):
+def cpu_baseline(H, W, model="r"):
     """Oracle (CPU port of the reference algorithm) on the host cores: B=1 pair, 1 warm-up + 2 timed."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gimmvfi_r_oracle as orc
-    from gimmvfi_hip.params import random_state_dict
+    from gimmvfi_hip.params import random_state_dict, random_state_dict_f
     from gimmvfi_hip.synth import synthetic_pairs
 
-    sd = random_state_dict(0)
+    if model == "f":
+        import gimmvfi_f_oracle as orc
+
+        sd = random_state_dict_f(0)
+    else:
+        import gimmvfi_r_oracle as orc
+
+        sd = random_state_dict(0)
     x = synthetic_pairs(1, H, W, seed=100)
     coords = [(orc.sample_coord_input(1, (H, W), [0.5], 1.0), None)]
     ts = [0.5 * torch.ones(1)]
