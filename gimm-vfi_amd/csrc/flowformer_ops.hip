@@ -14,38 +14,106 @@ static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK 
 
 // ------------------------------------------------------------------ nn.LayerNorm over the channel axis
 // twins.py:1169 (eps 1e-6 in the Twins blocks), torch default 1e-5 elsewhere (twins.py:1146, encoder.py:65,...)
+// Input: the residual stream (float when x_f32, else the activation type); output: activation type (the operand
+// of the next contraction).  A row is shared by C/VE lanes (one 16-byte output vector each, 64/(C/VE) rows per
+// wave); mean and variance are two shuffle reductions over registers.
 template <typename T>
-__global__ void layernorm_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
+__global__ void layernorm_vec_kernel(const void* __restrict__ x, int ldx, int x_f32, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float eps, T* __restrict__ y, int ldy,
+                                     long long rows, int C, int lpr) {
+    constexpr int VE = Elem<T>::VE;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % lpr;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long r = wave * (64 / lpr) + lane / lpr;
+    const bool live = r < rows;
+    float v[VE];
+    if (live) {
+        if (x_f32) {
+            const float* xr = (const float*)x + r * ldx + sub * VE;
+#pragma unroll
+            for (int e = 0; e < VE; e += 4) {
+                const float4 f = *(const float4*)(xr + e);
+                v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+            }
+        } else {
+            struct alignas(16) Vec { T e[VE]; };
+            const Vec q = *(const Vec*)((const T*)x + r * ldx + sub * VE);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = Elem<T>::ld(&q.e[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s += v[e];
+    for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) q2 += (v[e] - mean) * (v[e] - mean);
+    for (int off = lpr >> 1; off > 0; off >>= 1) q2 += __shfl_xor(q2, off);
+    if (!live) return;
+    const float rstd = 1.0f / sqrtf(q2 / (float)C + eps);
+    struct alignas(16) VecO { T e[VE]; } o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+        Elem<T>::st(&o.e[e], (v[e] - mean) * rstd * gamma[sub * VE + e] + beta[sub * VE + e]);
+    *(VecO*)(y + r * ldy + sub * VE) = o;
+}
+template <typename T>
+__global__ void layernorm_kernel(const void* __restrict__ x, int ldx, int x_f32, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float eps, T* __restrict__ y, int ldy, long long rows,
                                  int C) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    const T* xr = x + r * ldx;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += Elem<T>::ld(xr + c);
+    for (int c = 0; c < C; ++c) s += ld_any<T>(x, r * ldx + c, x_f32);
     const float mean = s / (float)C;
     float v = 0.f;
     for (int c = 0; c < C; ++c) {
-        const float d = Elem<T>::ld(xr + c) - mean;
+        const float d = ld_any<T>(x, r * ldx + c, x_f32) - mean;
         v += d * d;
     }
     const float rstd = 1.0f / sqrtf(v / (float)C + eps);
     T* yr = y + r * ldy;
-    for (int c = 0; c < C; ++c) Elem<T>::st(yr + c, (Elem<T>::ld(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+    for (int c = 0; c < C; ++c) Elem<T>::st(yr + c, (ld_any<T>(x, r * ldx + c, x_f32) - mean) * rstd * gamma[c] + beta[c]);
 }
-extern "C" int gvfi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
-                              long long rows, int C, int dtype, void* stream) {
+extern "C" int gvfi_layernorm(const void* x, int ldx, int x_f32, const float* gamma, const float* beta, float eps, void* y,
+                              int ldy, long long rows, int C, int dtype, void* stream) {
     if (C <= 0 || ldx < C || ldy < C) return -2;
-    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((layernorm_kernel<T>), grid1d(rows), dim3(GVFI_BLOCK), (hipStream_t)stream,
-                                              (const T*)x, ldx, gamma, beta, eps, (T*)y, ldy, rows, C));
+    const int ve = dtype == GVFI_F32 ? 4 : 8;
+    const int lpr = C / ve;
+    const int xbytes = (x_f32 || dtype == GVFI_F32) ? 4 : 2;
+    const bool vec = (C % ve) == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && (ldy % ve) == 0 &&
+                     (((uintptr_t)y) & 15) == 0 && (((uintptr_t)x) & 15) == 0 && ((ldx * xbytes) & 15) == 0;
+#ifdef GVFI_HOSTSIM
+    // the emulator runs cooperative launches with one OS thread per lane: keep the CPU suite fast, the vector kernel
+    // is exercised by the unit tests at small row counts
+    const bool vec_ok_rows = rows <= 256;
+#else
+    const bool vec_ok_rows = true;
+#endif
+    if (vec && vec_ok_rows) {
+        const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+        GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((layernorm_vec_kernel<T>), grid1d(waves * 64), dim3(GVFI_BLOCK),
+                                                (hipStream_t)stream, x, ldx, x_f32, gamma, beta, eps, (T*)y, ldy, rows, C,
+                                                lpr));
+    } else {
+        GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((layernorm_kernel<T>), grid1d(rows), dim3(GVFI_BLOCK),
+                                                  (hipStream_t)stream, x, ldx, x_f32, gamma, beta, eps, (T*)y, ldy, rows, C));
+    }
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------ PEG: y = x + depthwise3x3(x) + bias   twins.py:1100-1119
+// io_f32: x and y are the float residual stream, else the activation type
 template <typename T>
-__global__ void dwconv3x3_res_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w /*[9][C]*/,
-                                     const float* __restrict__ bias, T* __restrict__ y, int ldy, long long total, int H,
-                                     int W, int C) {
+__global__ void dwconv3x3_res_kernel(const void* __restrict__ x, int ldx, const float* __restrict__ w /*[9][C]*/,
+                                     const float* __restrict__ bias, void* __restrict__ y, int ldy, int io_f32,
+                                     long long total, int H, int W, int C) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (pixel, channel)
     if (idx >= total) return;
     const int c = (int)(idx % C);
@@ -58,16 +126,16 @@ __global__ void dwconv3x3_res_kernel(const T* __restrict__ x, int ldx, const flo
         for (int kx = 0; kx < 3; ++kx) {
             const int xx = px + kx - 1;
             if ((unsigned)xx >= (unsigned)W) continue;
-            acc += w[(ky * 3 + kx) * C + c] * Elem<T>::ld(x + (pix + (long long)(ky - 1) * W + (kx - 1)) * ldx + c);
+            acc += w[(ky * 3 + kx) * C + c] * ld_any<T>(x, (pix + (long long)(ky - 1) * W + (kx - 1)) * ldx + c, io_f32);
         }
     }
-    Elem<T>::st(y + pix * ldy + c, acc + bias[c] + Elem<T>::ld(x + pix * ldx + c));
+    st_any<T>(y, pix * ldy + c, io_f32, acc + bias[c] + ld_any<T>(x, pix * ldx + c, io_f32));
 }
-extern "C" int gvfi_dwconv3x3_res(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int H,
-                                  int W, int C, int dtype, void* stream) {
+extern "C" int gvfi_dwconv3x3_res(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int io_f32,
+                                  int N, int H, int W, int C, int dtype, void* stream) {
     const long long total = (long long)N * H * W * C;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((dwconv3x3_res_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
-                                              (hipStream_t)stream, (const T*)x, ldx, w, bias, (T*)y, ldy, total, H, W, C));
+                                              (hipStream_t)stream, x, ldx, w, bias, y, ldy, io_f32, total, H, W, C));
     return (int)hipGetLastError();
 }
 
@@ -351,19 +419,19 @@ extern "C" int gvfi_ff_xqk(const void* x, int ldx, int Cx, const void* ctx, int 
 
 // ------------------------------------------------------------------ out[row] = table[(row / P) % K]   encoder.py:420 (latent tokens)
 template <typename T>
-__global__ void tile_rows_kernel(const float* __restrict__ table, T* __restrict__ out, int ldo, long long total, int P,
-                                 int K, int C) {
+__global__ void tile_rows_kernel(const float* __restrict__ table, void* __restrict__ out, int ldo, int out_f32,
+                                 long long total, int P, int K, int C) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % C);
     const long long r = idx / C;
-    Elem<T>::st(out + r * ldo + c, table[((r / P) % K) * C + c]);
+    st_any<T>(out, r * ldo + c, out_f32, table[((r / P) % K) * C + c]);
 }
-extern "C" int gvfi_tile_rows(const float* table, void* out, int ldo, long long rows, int P, int K, int C, int dtype,
-                              void* stream) {
+extern "C" int gvfi_tile_rows(const float* table, void* out, int ldo, int out_f32, long long rows, int P, int K, int C,
+                              int dtype, void* stream) {
     const long long total = rows * C;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((tile_rows_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
-                                              table, (T*)out, ldo, total, P, K, C));
+                                              table, out, ldo, out_f32, total, P, K, C));
     return (int)hipGetLastError();
 }
 

@@ -188,19 +188,24 @@ class EngineF(Engine):
     def _tok(self, rows, c):
         return torch.empty((rows, c), dtype=self.rt.tdtype, device=self.rt.device)
 
+    def _tok32(self, rows, c):
+        return torch.empty((rows, c), dtype=torch.float32, device=self.rt.device)
+
     @staticmethod
     def _img(t):
         """[rows, C] token matrix as the [1, 1, rows, C] NHWC tensor gvfi_conv2d reads."""
         return t if t.dim() == 4 else t.view(1, 1, t.shape[0], t.shape[1])
 
-    def _linear(self, name, x, cout=None, out=None, act=A.ACT_NONE, res=None, x1=None):
-        """out = act(x [| x1] W^T + b) (+ res); x, out: token matrices or Views of them."""
+    def _linear(self, name, x, cout=None, out=None, act=A.ACT_NONE, res=None, x1=None, f32=False):
+        """out = act(x [| x1] W^T + b) (+ res); x, out: token matrices or Views of them.  f32: the result is a float
+        tensor -- the residual streams of the transformer blocks stay in float (bf16 only rounds the operands of
+        the contractions, never the running sum of the block updates)."""
         rt = self.rt
         lay = self.layers[name]
         xv = x if isinstance(x, View) else View(x)
         rows = xv.npix
         if out is None:
-            out = self._tok(rows, lay.cout)
+            out = self._tok32(rows, lay.cout) if f32 else self._tok(rows, lay.cout)
         ov = out if isinstance(out, View) else View(out)
         mk = lambda v: View(v.t.view(1, 1, rows, v.t.shape[-1]), v.coff, v.c)
         rv = None
@@ -213,10 +218,10 @@ class EngineF(Engine):
         return out
 
     def _mlp_res(self, p, x, norm, eps, fc1, fc2):
-        """x + fc2(gelu(fc1(LN(x))))."""
+        """x + fc2(gelu(fc1(LN(x)))) on the float residual stream."""
         y = self.rt.layernorm(x, self.ln[norm], eps)
         h = self._linear(fc1, y, act=A.ACT_GELU)
-        return self._linear(fc2, h, res=x)
+        return self._linear(fc2, h, res=x, f32=True)
 
     # ------------------------------------------------------------------ Twins-SVT (two stages)   encoders.py:21-48
     def _twins(self, img, p):
@@ -242,7 +247,7 @@ class EngineF(Engine):
             a = self._tok(rows, c)
             rt.attn_window(View(qkv, 0, c), View(qkv, c, c), View(qkv, 2 * c, c), C_[b + ".kpad"], C_[b + ".vpad"], a,
                            n, h, w, 7, heads, hd)
-            t = self._linear(b + ".attn.proj", a, res=t)
+            t = self._linear(b + ".attn.proj", a, res=t, f32=True)
             t = self._mlp_res(b, t, b + ".norm2", 1e-6, b + ".mlp.fc1", b + ".mlp.fc2")
             # ---- PEG   twins.py:1100-1119
             k = f"{p}.svt.pos_block.{i}.proj.0"
@@ -260,8 +265,10 @@ class EngineF(Engine):
             a = self._tok(rows, c)
             N = h * w
             rt.attn_global(q, (N, 0, 1), View(kv, 0, c), View(kv, c, c), (m, 0, 1), a, (N, 0, 1), n, 1, N, m, heads, hd)
-            t = self._linear(b + ".attn.proj", a, res=t)
+            t = self._linear(b + ".attn.proj", a, res=t, f32=True)
             t = self._mlp_res(b, t, b + ".norm2", 1e-6, b + ".mlp.fc1", b + ".mlp.fc2")
+            if t.dtype != rt.tdtype:     # stage output in the activation type: operand of the next convolutions
+                t = rt.copy(t, self._tok(rows, c), c).t
             x = t.view(n, h, w, c)
             feats.append(x)
         return feats
@@ -303,7 +310,7 @@ class EngineF(Engine):
             k = self._linear(a_ + ".k", sk)
             v = self._linear(a_ + ".v", sv)
             rt.attn_global(q, (P8, 0, 1), k, v, (m, 0, 1), att, (P8, 0, 1), n_img, 1, P8, m, 8, 16)
-        x = self._linear(a_ + ".proj", att, res=x)
+        x = self._linear(a_ + ".proj", att, res=x, f32=True)
         return self._mlp_res(p, x, p + ".norm2", 1e-5, p + ".mlp.fc1", p + ".mlp.fc2")
 
     def _grid(self, h, w):
@@ -343,11 +350,11 @@ class EngineF(Engine):
         lay = (K_LAT * P8, 1, P8)          # row of (image b, pixel p, token i) in the image-major latent layout
         rt.attn_global(qlat, (0, 0, 1), View(kv, 0, 128), View(kv, 128, 128), (P8 * T, T, 1), att, lay, n, P8, K_LAT, T,
                        8, 16)
-        short = self._tok(rows, 128)
+        short = self._tok32(rows, 128)
         rt.tile_rows(C_["latent"], short, rows, P8, K_LAT, 128)
-        x = self._linear(ip + ".proj", att, res=short)
+        x = self._linear(ip + ".proj", att, res=short, f32=True)
         y = rt.layernorm(x, self.ln[ip + ".norm2"], 1e-5)
-        x = self._linear(ip + ".ffn.3", self._linear(ip + ".ffn.0", y, act=A.ACT_GELU), res=x)
+        x = self._linear(ip + ".ffn.3", self._linear(ip + ".ffn.0", y, act=A.ACT_GELU), res=x, f32=True)
         short_cut = x
         if taps is not None:
             taps["f01_latent_in"] = x
@@ -359,9 +366,9 @@ class EngineF(Engine):
             att = self._tok(rows, 128)
             rt.attn_global(View(qkv, 0, 128), lay, View(qkv, 128, 128), View(qkv, 256, 128), lay, att, lay, n, P8, K_LAT,
                            K_LAT, 8, 16)
-            x = self._linear(ep + ".proj", att, res=x)
+            x = self._linear(ep + ".proj", att, res=x, f32=True)
             y = rt.layernorm(x, self.ln[ep + ".norm2"], 1e-5)
-            x = self._linear(ep + ".ffn.3", self._linear(ep + ".ffn.0", y, act=A.ACT_GELU), res=x)
+            x = self._linear(ep + ".ffn.3", self._linear(ep + ".ffn.0", y, act=A.ACT_GELU), res=x, f32=True)
             vp = f"{ce}.vertical_encoder_layers.{idx}"
             x = self._vertical(vp + ".local_block", x, ctx, n, B, h8, w8, True)
             x = self._vertical(vp + ".global_block", x, ctx, n, B, h8, w8, False)

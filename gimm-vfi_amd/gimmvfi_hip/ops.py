@@ -481,17 +481,19 @@ class Runtime:
         """nn.LayerNorm over the channels of a token matrix / NHWC tensor (gb = (gamma, beta) float tensors)."""
         x = V(x)
         if out is None:
-            out = torch.empty_like(x.t)
+            out = torch.empty(x.t.shape, dtype=self.tdtype, device=self.device)
         o = V(out)
-        self._chk(self.lib.layernorm(x.ptr, x.ld, gb[0].data_ptr(), gb[1].data_ptr(), float(eps), o.ptr, o.ld, x.npix,
-                                     x.c, self.dtype, self.stream()), "layernorm")
+        assert not o.is_f32 or self.dtype == L.F32
+        self._chk(self.lib.layernorm(x.ptr, x.ld, x.is_f32, gb[0].data_ptr(), gb[1].data_ptr(), float(eps), o.ptr, o.ld,
+                                     x.npix, x.c, self.dtype, self.stream()), "layernorm")
         return out
 
     def dwconv3x3_res(self, x, w9c, bias):
         n, h, w, c = x.shape
         out = torch.empty_like(x)
-        self._chk(self.lib.dwconv3x3_res(x.data_ptr(), c, w9c.data_ptr(), bias.data_ptr(), out.data_ptr(), c, n, h, w, c,
-                                         self.dtype, self.stream()), "dwconv3x3_res")
+        self._chk(self.lib.dwconv3x3_res(x.data_ptr(), c, w9c.data_ptr(), bias.data_ptr(), out.data_ptr(), c,
+                                         1 if x.dtype == torch.float32 else 0, n, h, w, c, self.dtype, self.stream()),
+                  "dwconv3x3_res")
         return out
 
     def pos_embed(self, coords, period, scale, offset, dim, out, rows, accumulate):
@@ -532,7 +534,8 @@ class Runtime:
 
     def tile_rows(self, table, out, rows, p, k, c):
         o = V(out)
-        self._chk(self.lib.tile_rows(table.data_ptr(), o.ptr, o.ld, rows, p, k, c, self.dtype, self.stream()), "tile_rows")
+        self._chk(self.lib.tile_rows(table.data_ptr(), o.ptr, o.ld, o.is_f32, rows, p, k, c, self.dtype, self.stream()),
+                  "tile_rows")
         return out
 
     def softmax_rows(self, x, n, out, rows):

@@ -202,12 +202,13 @@ int gvfi_lookup_coords(const float* fl0, const float* fl1, const float* t, float
  * backbone is timm's twins_svt_large, vendored classes twins.py:814-983,1028-1150).  Token tensors are row matrices
  * [rows][ld] in `dtype`; the linear layers, patch / sub-sampling convolutions, cost volume and the GMA contractions go
  * through gvfi_conv2d. ------------------------------------------------------------------------------------------- */
-/* nn.LayerNorm(C): y = (x - mean) * rsqrt(var + eps) * gamma + beta   (twins.py:1146,1169; encoder.py:65,236-237) */
-int gvfi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
-                   long long rows, int C, int dtype, void* stream);
-/* PEG (twins.py:1100-1119): y = x + depthwise3x3(x) + bias, NHWC, w float [9][C] */
-int gvfi_dwconv3x3_res(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int H,
-                       int W, int C, int dtype, void* stream);
+/* nn.LayerNorm(C): y = (x - mean) * rsqrt(var + eps) * gamma + beta   (twins.py:1146,1169; encoder.py:65,236-237);
+ * x is float when x_f32 (the residual streams of the transformer blocks are kept in float), y is in dtype */
+int gvfi_layernorm(const void* x, int ldx, int x_f32, const float* gamma, const float* beta, float eps, void* y,
+                   int ldy, long long rows, int C, int dtype, void* stream);
+/* PEG (twins.py:1100-1119): y = x + depthwise3x3(x) + bias, NHWC, w float [9][C]; io_f32: x, y float */
+int gvfi_dwconv3x3_res(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int io_f32,
+                       int N, int H, int W, int C, int dtype, void* stream);
 /* LinearPositionEmbeddingSine (attention.py:170-182): out[row, 0:dim] (+)= enc(scale * coords[row % period] + offset),
  * coords float [period][2] (x, y) */
 int gvfi_pos_embed(const float* coords, long long period, float scale, float offset, int dim, void* out, int ldo,
@@ -237,8 +238,8 @@ int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long 
 int gvfi_ff_xqk(const void* x, int ldx, int Cx, const void* ctx, int ldc, int Cc, void* out, int ldo, int n_img,
                 int H, int W, int K, int nb, int enc_mode, int ws, int dtype, void* stream);
 /* out[row, 0:C] = table[(row / P) % K]  (the learned latent tokens broadcast over the cost maps, encoder.py:420) */
-int gvfi_tile_rows(const float* table, void* out, int ldo, long long rows, int P, int K, int C, int dtype,
-                   void* stream);
+int gvfi_tile_rows(const float* table, void* out, int ldo, int out_f32, long long rows, int P, int K, int C,
+                   int dtype, void* stream);
 /* row soft-max of the GMA similarity (gma.py:70-74): x float [rows][n] -> y [rows][ldy] in dtype, pad columns zeroed */
 int gvfi_softmax_rows(const float* x, int n, void* y, int ldy, long long rows, int dtype, void* stream);
 

@@ -34,7 +34,7 @@ def tol(rt, scale):
 
 
 def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.ACT_NONE, with_res=False,
-              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0):
+              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0, pad=None):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
@@ -42,7 +42,8 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     slope = torch.rand(Cout, generator=g) * 0.3 + 0.1
     x, w = _rounded(rt, x), _rounded(rt, w)
     dev = _dev(rt)
-    lay = ConvLayer(rt, w, b, stride=stride, pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope)
+    lay = ConvLayer(rt, w, b, stride=stride, pad=None if pad is None else (pad, pad),
+                    pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope)
     if split is None:
         xa = _to_act(rt, x).to(dev)
         x0, x1 = View(xa, 0, Cin), None
@@ -52,7 +53,7 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
         xb = _to_act(rt, x[:, split:])
         wide, xb = wide.to(dev), xb.to(dev)
         x0, x1 = View(wide, rt.VE, split), View(xb, 0, Cin - split)
-    ph, pw = KH // 2, KW // 2
+    ph, pw = (KH // 2, KW // 2) if pad is None else (pad, pad)
     Ho, Wo = (H + 2 * ph - KH) // stride + 1, (W + 2 * pw - KW) // stride + 1
     res = None
     r = None
@@ -78,6 +79,8 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
             return torch.tanh(v)
         if k == L.ACT_SIN:
             return torch.sin(v)
+        if k == L.ACT_GELU:
+            return F.gelu(v)
         return v
 
     ref = act(ref, act1)

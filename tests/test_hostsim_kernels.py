@@ -42,6 +42,16 @@ CONV_SHAPES = [
     (1, 9, 12, 96, 40, 3, 3, dict(act1=L.ACT_LRELU)),
     (1, 18, 20, 32, 32, 3, 3, dict(tile=32 | (256 << 10), act1=L.ACT_LRELU, with_res=True)),
     (1, 18, 20, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),
+    # FlowFormer (GIMM-VFI-F): patch / sub-sampling convolutions with stride == kernel and no padding, the 6x6 stride-2
+    # cost-map convolutions, GELU epilogues on both kernels, token-matrix linears ([1,1,rows,C])
+    (2, 16, 24, 3, 128, 4, 4, dict(stride=4, pad=0)),
+    (1, 8, 12, 128, 40, 2, 2, dict(stride=2, pad=0)),
+    (1, 16, 16, 64, 24, 8, 8, dict(stride=8, pad=0)),
+    (2, 8, 12, 96, 32, 4, 4, dict(stride=4, pad=0)),
+    (3, 8, 12, 16, 32, 6, 6, dict(stride=2, pad=2, act1=L.ACT_RELU)),
+    (1, 1, 200, 64, 72, 1, 1, dict(act1=L.ACT_GELU)),
+    (1, 1, 200, 24, 40, 1, 1, dict(act1=L.ACT_GELU, with_res=True, out_f32=True)),
+    (1, 1, 8, 64, 64, 1, 1, {}),
 ]
 
 
