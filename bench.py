@@ -149,12 +149,14 @@ def main():
         # MI355X_MICROARCH.md + WRITE_SIZE), valid for the default workload's 256->256 3x3 layer only
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r1_hotconv_pmc_hbm.json")
-        if os.path.isfile(pmc_path) and tag.startswith("conv_igemm_glds_kernel<bf16,256,256") and (B, H, W, NI, ds) == (8, 256, 448, 2, None):
+        if (os.path.isfile(pmc_path) and args.model == "r" and tag.startswith("conv_igemm_glds_kernel<bf16,256,256")
+                and (B, H, W, NI, ds) == (8, 256, 448, 2, None)):
             traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]
         roofline = {
             "bound": "mfma", "kernel": tag, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": "HBM bytes/launch from profiles/r1_hotconv_pmc_hbm.json (PMC, separate run); algorithmic 0.94 GB",
+            "traffic_note": ("HBM bytes/launch from profiles/r1_hotconv_pmc_hbm.json (PMC, separate run); algorithmic 0.94 GB"
+                             if traffic is not None else "no PMC pass for this workload"),
             "launches_per_step": cnt // ev_steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
             "avg_launch_gflop": round(fl / cnt / 1e9, 3),
             "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / ev_steps * 1e3, 3),
