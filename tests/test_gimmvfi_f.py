@@ -7,7 +7,7 @@ GPU (`-m gpu`): libgimmvfi_hip.so through the drop-in model API against the same
 
 Tolerances: fp32 mode PSNR >= 80 dB, flows within 5e-3 px (32 recurrent iterations of lookup -> GRU; measured on
 MI355X: 139 dB, 3e-5 px); bf16 mode PSNR >= 35 dB and mean flow error < 0.5 px on flows of up to 30 px (measured:
-36-50 dB, 0.15-0.21 px with the seeded random weights -- bf16 operands through two Twins encoders, 6 context-aware
+43.7-49.0 dB, 0.15-0.21 px with the seeded random weights -- bf16 operands through two Twins encoders, 6 context-aware
 blocks and 32 decoder iterations; flows / cost volume / coordinates / residual streams stay fp32)."""
 import pytest
 import torch
