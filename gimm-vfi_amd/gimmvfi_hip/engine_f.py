@@ -234,7 +234,6 @@ class EngineF(Engine):
             H, W = src.t.shape[1:3]
             assert H % patch == 0 and W % patch == 0
             h, w = H // patch, W // patch
-            assert h % sr == 0 and w % sr == 0, "token grid must be a multiple of the sub-sampling ratio"
             hd = c // heads
             rows = n * h * w
             emb = rt.act(n, h, w, c)
@@ -292,18 +291,24 @@ class EngineF(Engine):
             rt.attn_window(View(qk, 0, 128), View(qk, 128, 128), v, C_[a_ + ".kpad"], C_[a_ + ".vpad"], att, n_img, h8, w8,
                            7, 8, 16)
         else:
-            assert h8 % 4 == 0 and w8 % 4 == 0, "1/8 grid must be a multiple of sr_ratio 4 (frames padded to /32)"
             xq = self._tok(rows, 192)
             rt.ff_xqk(y, ctxp, xq, n_img, h8, w8, K_LAT, B, 2)
             q = self._linear(a_ + ".q", xq)
             xk = self._tok(rows, 192)
             rt.ff_xqk(y, ctxp, xk, n_img, h8, w8, K_LAT, B, 0)
-            hs, ws_ = h8 // 4, w8 // 4
+            # the reference zero-extends the token grid to a multiple of sr_ratio on the right / bottom before the
+            # sub-sampling convolutions (twins.py:471-476); queries of the extension are dropped (:540-541)
+            hp, wp = (h8 + 3) // 4 * 4, (w8 + 3) // 4 * 4
+            xk4, y4 = xk.view(n_img, h8, w8, 192), y.view(n_img, h8, w8, 128)
+            if (hp, wp) != (h8, w8):    # memory plumbing only
+                xk4 = torch.nn.functional.pad(xk4, (0, 0, 0, wp - w8, 0, hp - h8))
+                y4 = torch.nn.functional.pad(y4, (0, 0, 0, wp - w8, 0, hp - h8))
+            hs, ws_ = hp // 4, wp // 4
             m = hs * ws_
             sk = rt.act(n_img, hs, ws_, 128)
-            rt.conv(Ls[a_ + ".sr_key"], xk.view(n_img, h8, w8, 192), sk)
+            rt.conv(Ls[a_ + ".sr_key"], xk4, sk)
             sv = rt.act(n_img, hs, ws_, 128)
-            rt.conv(Ls[a_ + ".sr_value"], y.view(n_img, h8, w8, 128), sv)
+            rt.conv(Ls[a_ + ".sr_value"], y4, sv)
             sk = rt.layernorm(sk.view(n_img * m, 128), self.ln[a_ + ".norm"], 1e-5)
             sv = rt.layernorm(sv.view(n_img * m, 128), self.ln[a_ + ".norm"], 1e-5)
             rt.pos_embed(self._grid(hs, ws_), m, 4.0, 0.0, 128, sk, n_img * m, True)
@@ -384,7 +389,6 @@ class EngineF(Engine):
         self._grids = {}
         n = 2 * B
         H, W = imgA.shape[1:3]
-        assert H % 32 == 0 and W % 32 == 0, "GIMM-VFI-F: working resolution must be a multiple of 32"
         h8, w8 = H // 8, W // 8
         P8 = h8 * w8
         fe = "flow_estimator"
@@ -419,9 +423,9 @@ class EngineF(Engine):
         rt.conv(Ls["gma.k"], inp, gk)
         sim = rt.f32(n * P8, P8)
         rt.conv(None, gq, View(sim.view(n, h8, w8, P8)), groups=n, w_group_stride=P8 * 128, w_raw=gk, cout=P8)
-        assert P8 % rt.VE == 0
-        attn = torch.empty((n, 1, P8, P8), dtype=rt.tdtype, device=rt.device)
-        rt.softmax_rows(sim, P8, attn.view(n * P8, P8), n * P8)
+        P8p = rt.cp(P8)              # row pitch of the attention matrix / of V^T: pad columns are zero
+        attn = torch.empty((n, 1, P8, P8p), dtype=rt.tdtype, device=rt.device)
+        rt.softmax_rows(sim, P8, attn.view(n * P8, P8p), n * P8)
         del sim
         if n not in self._wv_rep:
             self._wv_rep[n] = self._wv.view(1, 1, 128, 128).expand(n, 1, 128, 128).contiguous()
@@ -434,7 +438,7 @@ class EngineF(Engine):
         flow8 = rt.act(n, h8, w8, 2, zero=True)
         X = rt.act(n, h8, w8, 256)          # [motion(126) flow(2) | aggregated motion(128)]   gru.py:150-152
         mfc = rt.act(n, h8, w8, 128)
-        vT = torch.empty((n, 1, 128, P8), dtype=rt.tdtype, device=rt.device)
+        vT = torch.zeros((n, 1, 128, P8p), dtype=rt.tdtype, device=rt.device)
         c1 = rt.act(n, h8, w8, 256)
         corflo = rt.act(n, h8, w8, 256)
         f1 = rt.act(n, h8, w8, 128)
@@ -476,9 +480,9 @@ class EngineF(Engine):
             rt.conv(Ls[u + ".encoder.conv"], corflo, View(X, 0, 126), act1=A.ACT_RELU)
             # global motion aggregation: X[128:256] = mf + gamma * attn @ (mf Wv^T)   gma.py:101-115
             rt.copy(View(X, 0, 128), mfc, 128)
-            rt.conv(None, wv_rep, vT, groups=n, w_group_stride=P8 * 128, w_raw=mfc, cout=P8)
+            rt.conv(None, wv_rep, View(vT, 0, P8), groups=n, w_group_stride=P8 * 128, w_raw=mfc, cout=P8)
             Xr = X.view(n, 1, P8, 256)
-            rt.conv(None, attn, View(Xr, 128, 128), groups=n, w_group_stride=128 * P8, w_raw=vT, cout=128,
+            rt.conv(None, View(attn, 0, P8), View(Xr, 128, 128), groups=n, w_group_stride=128 * P8p, w_raw=vT, cout=128,
                     res=View(Xr, 0, 128))
             hc, hn = hA, hB
             for nn_ in ("1", "2"):

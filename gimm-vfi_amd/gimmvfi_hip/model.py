@@ -198,8 +198,8 @@ class GIMMVFI_F(GIMMVFI_R):
     state_dict keys (``load_state_dict(strict=True)`` of reference checkpoints), ``forward(img_xs, coord, t,
     ds_factor)`` without an ``iters`` argument (gimmvfi_f.py:304).  The constructor does not read
     ``pretrained_ckpt/flowformer_sintel.pth`` (flowformer/__init__.py:10): those weights are part of the GIMM-VFI-F
-    checkpoint loaded afterwards.  Frames must be padded to multiples of 32 at the working resolution (the CLI's
-    InputPadder does that, src/video_Nx.py:146)."""
+    checkpoint loaded afterwards.  Working resolutions are multiples of 8, >= 128 (as for GIMM-VFI-R); grids that are not
+    multiples of the window / sub-sampling sizes take the reference's zero-extension branches."""
 
     _spec = staticmethod(param_spec_f)
     _init_sd = staticmethod(random_state_dict_f)

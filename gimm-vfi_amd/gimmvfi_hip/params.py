@@ -397,3 +397,13 @@ def random_state_dict_f(seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, t
         else:
             raise KeyError(name)
     return sd
+
+
+def random_state_dict_for(model_type: str, seed: int = 0):
+    """Seeded random weights of the architecture `config.arch.type` names (the CLIs' --random-init)."""
+    t = model_type.lower()
+    if t == "gimmvfi_f":
+        return random_state_dict_f(seed)
+    if t == "gimm":
+        return gimm_state_dict(random_state_dict(seed))
+    return random_state_dict(seed)

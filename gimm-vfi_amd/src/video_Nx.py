@@ -115,9 +115,10 @@ def main(argv=None):
         ckpt = torch.load(args.load_path, map_location="cpu")
         model.load_state_dict(ckpt["state_dict"], strict=True)
     elif args.random_init:
-        from gimmvfi_hip.params import random_state_dict
+        from gimmvfi_hip.params import random_state_dict_for
 
-        model.load_state_dict(random_state_dict(args.seed), strict=True)
+        mtype = config.arch["type"] if isinstance(config.arch, dict) else config.arch.type
+        model.load_state_dict(random_state_dict_for(mtype, args.seed), strict=True)
     elif args.eval:
         raise ValueError("--load-path must be specified in evaluation or resume mode")
     model = model.to(device).eval()

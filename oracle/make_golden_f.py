@@ -25,6 +25,8 @@ CASES = {
     # name: (B, H, W, seed, ds_factor, t list)
     "f_128x192_t050": (1, 128, 192, 3, None, [0.5]),
     "f_b2_128x128_t025_075": (2, 128, 128, 4, None, [0.25, 0.75]),
+    # 17 x 19 grid at 1/8: ragged 7x7 windows, zero-extended sub-sampling (sr 4) and cost-map patches, odd P8
+    "f_136x152_t040": (1, 136, 152, 21, None, [0.4]),
 }
 
 

@@ -62,6 +62,19 @@ def test_engine_f_sim_fp32_matches_golden_and_oracle(sd_f):
     _check_taps(taps, otaps, meta["B"], 1e-4)
 
 
+def test_engine_f_sim_ragged_grid(sd_f):
+    """136 x 152 frames -> 17 x 19 grid at 1/8: ragged 7x7 windows (bias / positional-code keys), zero-extended
+    sub-sampling convolutions and cost-map patches, odd P8 (padded pitch of the GMA attention matrix)."""
+    from gimmvfi_hip.engine_f import EngineF
+    from sim_runtime import SimRuntime
+
+    meta, gold = load_golden("f_136x152_t040")
+    x, coords, ts = golden_inputs(meta)
+    out = EngineF(SimRuntime("fp32"), sd_f).forward(x, coords, ts, iters=None)
+    assert maxabs(out["raft_flow"], gold["raft_flow"]) < 2e-3
+    assert psnr(out["imgt_pred"][0], gold["imgt_pred_0"]) > 100.0
+
+
 def test_create_model_f_contract(sd_f):
     """create_model('gimmvfi_f') returns the drop-in module: reference key set, strict load, no CPU fallback."""
     import json
@@ -99,7 +112,7 @@ def _run(m, x, coords, ts, ds=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["f_128x192_t050", "f_b2_128x128_t025_075"])
+@pytest.mark.parametrize("name", ["f_128x192_t050", "f_b2_128x128_t025_075", "f_136x152_t040"])
 def test_gpu_f_fp32_matches_reference_golden(name, sd_f):
     meta, gold = load_golden(name)
     x, coords, ts = golden_inputs(meta)
@@ -129,7 +142,7 @@ def test_gpu_f_fp32_stage_taps_vs_oracle(sd_f):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["f_128x192_t050", "f_b2_128x128_t025_075"])
+@pytest.mark.parametrize("name", ["f_128x192_t050", "f_b2_128x128_t025_075", "f_136x152_t040"])
 def test_gpu_f_bf16_matches_reference_golden(name, sd_f):
     meta, gold = load_golden(name)
     x, coords, ts = golden_inputs(meta)

@@ -126,8 +126,10 @@ def test_2k_ds_half_8x_properties(sd):
         assert o16["flowt"][i].shape[-2:] == (H // 2, W // 2)
 
 
-def test_cli_video_Nx_random_init(tmp_path, sd):
-    """Drop-in CLI (src/video_Nx.py flags) end to end on synthetic PNG frames (non-/32 size -> padder)."""
+@pytest.mark.parametrize("cfg", ["gimmvfi_r_arb.yaml", "gimmvfi_f_arb.yaml"])
+def test_cli_video_Nx_random_init(tmp_path, sd, cfg):
+    """Drop-in CLI (src/video_Nx.py flags) end to end on synthetic PNG frames (non-/32 size -> padder), for both
+    flow estimators (RAFT: GIMM-VFI-R, FlowFormer: GIMM-VFI-F)."""
     import os
     import sys
 
@@ -151,7 +153,7 @@ def test_cli_video_Nx_random_init(tmp_path, sd):
 
         mod = importlib.import_module("video_Nx")
         mod.main(["--source-path", str(src), "--output-path", str(out), "--ds-factor", "1.0", "--N", "2",
-                  "-m", os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml"),
+                  "-m", os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", cfg),
                   "--eval", "--random-init"])
     finally:
         sys.path.remove(cli)

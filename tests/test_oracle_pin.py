@@ -58,7 +58,7 @@ def test_reference_accepts_our_state_dict_strict(sd):
 
 
 # ---- GIMM-VFI-F (FlowFormer flow estimator): oracle/gimmvfi_f_oracle.py
-F_CASES = ["f_128x192_t050", "f_b2_128x128_t025_075"]
+F_CASES = ["f_128x192_t050", "f_b2_128x128_t025_075", "f_136x152_t040"]
 
 
 @pytest.mark.parametrize("name", F_CASES)
@@ -85,7 +85,7 @@ def test_f_oracle_matches_reference_live(sd_f):
 
     ref = rh.build_reference_model_f(sd_f)
     assert list(ref.state_dict().keys()) == list(sd_f.keys())  # strict=True load + same order as the reference
-    x = synthetic_pairs(1, 128, 160, 11)
+    x = synthetic_pairs(1, 136, 160, 11)     # 17 x 20 grid at 1/8: the padded-window / zero-extension branches
     tl = [0.3, 0.8]
     ro = rh.reference_forward(ref, x, tl, None)
     coords = [(forc.sample_coord_input(1, x.shape[-2:], [t], 1.0), None) for t in tl]
