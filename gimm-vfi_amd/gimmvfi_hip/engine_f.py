@@ -16,13 +16,11 @@ Work the reference performs but never uses is not executed: the feature encoder 
 per direction (encoder.py:507-509 re-encodes both images for each direction), the mask head + convex upsampling run
 for the last of the 32 decoder iterations only (decoder.py:312-314 evaluates all and returns the last).
 """
-import math
-
 import torch
 
 from . import lib as L
 from .engine import Engine
-from .ops import ConvLayer, PatchConvLayer, TapSplitConvLayer, View
+from .ops import PatchConvLayer, TapSplitConvLayer, View
 
 A = L
 K_LAT = 8          # cost_latent_token_num   configs/submission.py:30
@@ -196,7 +194,7 @@ class EngineF(Engine):
         """[rows, C] token matrix as the [1, 1, rows, C] NHWC tensor gvfi_conv2d reads."""
         return t if t.dim() == 4 else t.view(1, 1, t.shape[0], t.shape[1])
 
-    def _linear(self, name, x, cout=None, out=None, act=A.ACT_NONE, res=None, x1=None, f32=False):
+    def _linear(self, name, x, out=None, act=A.ACT_NONE, res=None, x1=None, f32=False):
         """out = act(x [| x1] W^T + b) (+ res); x, out: token matrices or Views of them.  f32: the result is a float
         tensor -- the residual streams of the transformer blocks stay in float (bf16 only rounds the operands of
         the contractions, never the running sum of the block updates)."""

@@ -1,5 +1,6 @@
 /* gimmvfi_hip.h -- C ABI of libgimmvfi_hip.so (MI355X / gfx950 HIP kernels for the
- * GIMM-VFI-R inference path).
+ * GIMM-VFI-R / GIMM-VFI-F inference path: RAFT or FlowFormer flow estimator, GIMM motion INR,
+ * softmax splatting, frame synthesis).
  *
  * Plain pointers and sizes only: every pointer is a DEVICE pointer, every entry point
  * enqueues on the hipStream_t passed last (cast to void*; 0 = default stream) and returns

@@ -62,6 +62,19 @@ def test_engine_f_sim_fp32_matches_golden_and_oracle(sd_f):
     _check_taps(taps, otaps, meta["B"], 1e-4)
 
 
+def test_engine_f_sim_bf16(sd_f):
+    """bf16 mode in the emulator: bf16 contraction operands, float residual streams / cost volume / coordinates."""
+    from gimmvfi_hip.engine_f import EngineF
+    from sim_runtime import SimRuntime
+
+    meta, gold = load_golden("f_128x192_t050")
+    x, coords, ts = golden_inputs(meta)
+    out = EngineF(SimRuntime("bf16"), sd_f).forward(x, coords, ts, iters=None)
+    assert psnr(out["imgt_pred"][0], gold["imgt_pred_0"]) > 40.0
+    d = (out["flowt"][0].float() - gold["flowt_0"]).abs().flatten()
+    assert float(d.mean()) < 0.5
+
+
 def test_engine_f_sim_ragged_grid(sd_f):
     """136 x 152 frames -> 17 x 19 grid at 1/8: ragged 7x7 windows (bias / positional-code keys), zero-extended
     sub-sampling convolutions and cost-map patches, odd P8 (padded pitch of the GMA attention matrix)."""
