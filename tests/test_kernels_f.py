@@ -24,6 +24,8 @@ def _all(rt):
     kf.layernorm_case(rt)
     kf.layernorm_case(rt, rows=300, C=256, x_f32=True, eps=1e-5)     # > emulator's vector limit: scalar path on CPU
     kf.layernorm_case(rt, rows=5, C=64)
+    kf.layernorm_case(rt, rows=70, C=256, x_f32=True, eps=1e-5)      # vector kernel, float stream, 32 / 64 lanes per row
+    kf.layernorm_case(rt, rows=100, C=128, x_f32=True)
     kf.layernorm_case(rt, rows=9, C=20)                               # not a power-of-two lane count: scalar kernel
     kf.dwconv_case(rt)
     kf.dwconv_case(rt, f32=True)
