@@ -173,10 +173,13 @@ extern "C" int gvfi_pos_embed(const float* coords, long long period, float scale
 // ------------------------------------------------------------------ first cost-map convolution   encoder.py:39-41
 // Conv2d(1, 16, 6, stride 2, padding 2) + ReLU over the cost maps [maps][H][W] (float, the all-pairs volume itself),
 // zero-extended to a multiple of the patch size on the right / bottom (encoder.py:70-75): out [maps][Ho][Wo][16].
+// s2d: the output is written space-to-depth(2): pixel (oy, ox) -> pixel (oy/2, ox/2), channel block (oy&1)*2 + (ox&1)
+// of a [maps][Ho/2][Wo/2][4*16] tensor, the layout in which the following 6x6 stride-2 convolution is a 3x3 stride-1
+// convolution over 64 channels (LDS-DMA kernel); Ho, Wo even.
 template <typename T>
 __global__ void cost_embed1_kernel(const float* __restrict__ vol, const float* __restrict__ w /*[36][16]*/,
                                    const float* __restrict__ bias, T* __restrict__ out, int ldo, long long total, int H,
-                                   int W, int Ho, int Wo) {
+                                   int W, int Ho, int Wo, int s2d) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over output pixels
     if (idx >= total) return;
     const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho);
@@ -197,16 +200,38 @@ __global__ void cost_embed1_kernel(const float* __restrict__ vol, const float* _
             for (int c = 0; c < 16; ++c) acc[c] += v * wk[c];
         }
     }
-    T* o = out + idx * ldo;
+    T* o = s2d ? out + ((m * (Ho / 2) + oy / 2) * (long long)(Wo / 2) + ox / 2) * ldo + ((oy & 1) * 2 + (ox & 1)) * 16
+               : out + idx * ldo;
 #pragma unroll
     for (int c = 0; c < 16; ++c) Elem<T>::st(o + c, acc[c] > 0.f ? acc[c] : 0.f);
 }
 extern "C" int gvfi_cost_embed1(const float* vol, const float* w, const float* bias, void* out, int ldo, long long maps,
-                                int H, int W, int Ho, int Wo, int dtype, void* stream) {
-    if (ldo < 16) return -2;
+                                int H, int W, int Ho, int Wo, int s2d, int dtype, void* stream) {
+    if (ldo < (s2d ? 64 : 16) || (s2d && ((Ho | Wo) & 1))) return -2;
     const long long total = maps * Ho * Wo;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((cost_embed1_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
-                                              vol, w, bias, (T*)out, ldo, total, H, W, Ho, Wo));
+                                              vol, w, bias, (T*)out, ldo, total, H, W, Ho, Wo, s2d));
+    return (int)hipGetLastError();
+}
+
+// space-to-depth(2) of an NHWC tensor: dst[n, y/2, x/2, ((y&1)*2 + (x&1))*C + c] = src[n, y, x, c]   (H, W even)
+template <typename T>
+__global__ void space_to_depth2_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, long long total,
+                                       int H, int W, int C) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (pixel, channel)
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long pix = idx / C;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    dst[((n * (H / 2) + y / 2) * (long long)(W / 2) + x / 2) * ldd + ((y & 1) * 2 + (x & 1)) * C + c] = src[pix * lds + c];
+}
+extern "C" int gvfi_space_to_depth2(const void* src, int lds, void* dst, int ldd, int C, int N, int H, int W, int dtype,
+                                    void* stream) {
+    if (((H | W) & 1) || ldd < 4 * C) return -2;
+    const long long total = (long long)N * H * W * C;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((space_to_depth2_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, (const T*)src, lds, (T*)dst, ldd, total, H, W, C));
     return (int)hipGetLastError();
 }
 

@@ -16,6 +16,8 @@ Work the reference performs but never uses is not executed: the feature encoder 
 per direction (encoder.py:507-509 re-encodes both images for each direction), the mask head + convex upsampling run
 for the last of the 32 decoder iterations only (decoder.py:312-314 evaluates all and returns the last).
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -136,8 +138,17 @@ class EngineF(Engine):
         k = ce + ".patch_embed.proj.0"
         self.consts[k + ".w"] = self._f32(sd[k + ".weight"].reshape(16, 36).t())    # [36][16]
         self.consts[k + ".b"] = self._f32(sd[k + ".bias"])
+        # GVFI_F_S2D=1 (A/B switch, not yet measured): the two 6x6 stride-2 convolutions as 3x3 stride-1 convolutions
+        # over space-to-depth(2) inputs (64 / 128 channels -> LDS-DMA kernel instead of the generic one)
+        self.s2d = os.environ.get("GVFI_F_S2D", "0") == "1"
         for k in (ce + ".patch_embed.proj.2", ce + ".patch_embed.proj.4"):
-            self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=2, pad=(2, 2))
+            w = sd[k + ".weight"]
+            if self.s2d:
+                co, ci = w.shape[:2]
+                w2 = w.reshape(co, ci, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * ci, 3, 3)   # [(dy,dx,c)][a][b]
+                self._add(k, w2, sd[k + ".bias"], stride=1, pad=(1, 1))
+            else:
+                self._add(k, w, sd[k + ".bias"], stride=2, pad=(2, 2))
         self._conv(sd, ce + ".patch_embed.ffn_with_coord.0")
         self._conv(sd, ce + ".patch_embed.ffn_with_coord.2")
         self._ln(sd, ce + ".patch_embed.norm")
@@ -330,9 +341,11 @@ class EngineF(Engine):
         pe = ce + ".patch_embed"
         # ---- PatchEmbed of the cost maps   encoder.py:30-96
         hp, wp = (h8 + 7) // 8 * 8, (w8 + 7) // 8 * 8
-        e1 = rt.cost_embed1(vol, C_[pe + ".proj.0.w"], C_[pe + ".proj.0.b"], maps, h8, w8, hp // 2, wp // 2)
+        e1 = rt.cost_embed1(vol, C_[pe + ".proj.0.w"], C_[pe + ".proj.0.b"], maps, h8, w8, hp // 2, wp // 2, s2d=self.s2d)
         e2 = rt.act(maps, hp // 4, wp // 4, 32)
         rt.conv(Ls[pe + ".proj.2"], e1, e2, act1=A.ACT_RELU)
+        if self.s2d:
+            e2 = rt.space_to_depth2(e2, 32)
         h3, w3 = hp // 8, wp // 8
         T = h3 * w3
         tok = rt.act(maps, h3, w3, 128)

@@ -171,3 +171,34 @@ def tile_softmax_case(rt):
     got = y.float().cpu()
     assert float((got[:, :ncol] - x.softmax(-1)).abs().max()) <= tol(rt, 1.0)
     assert float(got[:, ncol:].abs().max()) == 0.0
+
+
+def s2d_conv_case(rt, maps=3, h=9, w=11):
+    """6x6 stride-2 padding-2 cost-map convolutions as 3x3 convolutions over space-to-depth(2) inputs
+    (GVFI_F_S2D path of engine_f): first convolution written space-to-depth, second through gvfi_space_to_depth2."""
+    from gimmvfi_hip import lib as L
+    from gimmvfi_hip.ops import ConvLayer
+
+    g = _g(9)
+    vol = torch.randn(maps, h, w, generator=g) * 2
+    w0, b0 = torch.randn(16, 1, 6, 6, generator=g) * 0.2, torch.randn(16, generator=g) * 0.1
+    w1, b1 = _r(rt, torch.randn(32, 16, 6, 6, generator=g) / 24), torch.randn(32, generator=g) * 0.1
+    w2, b2 = _r(rt, torch.randn(64, 32, 6, 6, generator=g) / 34), torch.randn(64, generator=g) * 0.1
+    hp, wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+    e1 = rt.cost_embed1(vol.to(rt.device), w0.reshape(16, 36).t().contiguous().to(rt.device), b0.to(rt.device), maps, h, w,
+                        hp // 2, wp // 2, s2d=True)
+
+    def s2d_w(wt):
+        co, ci = wt.shape[:2]
+        return wt.reshape(co, ci, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * ci, 3, 3)
+
+    e2 = rt.act(maps, hp // 4, wp // 4, 32)
+    rt.conv(ConvLayer(rt, s2d_w(w1), b1, stride=1, pad=(1, 1)), e1, e2, act1=L.ACT_RELU)
+    e3 = rt.act(maps, hp // 8, wp // 8, 64)
+    rt.conv(ConvLayer(rt, s2d_w(w2), b2, stride=1, pad=(1, 1)), rt.space_to_depth2(e2, 32), e3)
+    x = F.pad(vol[:, None], (0, wp - w, 0, hp - h))
+    r1 = _r(rt, F.relu(F.conv2d(x, w0, b0, stride=2, padding=2)))
+    r2 = _r(rt, F.relu(F.conv2d(r1, w1, b1, stride=2, padding=2)))
+    r3 = F.conv2d(r2, w2, b2, stride=2, padding=2)
+    got = e3.float().cpu().permute(0, 3, 1, 2)
+    assert float((got - r3).abs().max()) <= 3 * tol(rt, float(r3.abs().max()) + 1.0)

@@ -75,6 +75,22 @@ def test_engine_f_sim_bf16(sd_f):
     assert float(d.mean()) < 0.5
 
 
+def test_engine_f_sim_s2d_switch(sd_f, monkeypatch):
+    """GVFI_F_S2D=1 (A/B switch): the 6x6 stride-2 cost-map convolutions as 3x3 convolutions over space-to-depth
+    inputs give the same result."""
+    from gimmvfi_hip.engine_f import EngineF
+    from sim_runtime import SimRuntime
+
+    monkeypatch.setenv("GVFI_F_S2D", "1")
+    meta, gold = load_golden("f_136x152_t040")
+    x, coords, ts = golden_inputs(meta)
+    eng = EngineF(SimRuntime("fp32"), sd_f)
+    assert eng.s2d
+    out = eng.forward(x, coords, ts, iters=None)
+    assert maxabs(out["raft_flow"], gold["raft_flow"]) < 2e-3
+    assert psnr(out["imgt_pred"][0], gold["imgt_pred_0"]) > 100.0
+
+
 def test_engine_f_sim_ragged_grid(sd_f):
     """136 x 152 frames -> 17 x 19 grid at 1/8: ragged 7x7 windows (bias / positional-code keys), zero-extended
     sub-sampling convolutions and cost-map patches, odd P8 (padded pitch of the GMA attention matrix)."""
@@ -137,6 +153,20 @@ def test_gpu_f_fp32_matches_reference_golden(name, sd_f):
         assert tuple(out["flowt"][i].shape) == tuple(gold[f"flowt_{i}"].shape)
         d = (out["flowt"][i].cpu() - gold[f"flowt_{i}"]).abs().flatten()
         assert float(d.kthvalue(int(d.numel() * 0.999))[0]) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gpu_f_s2d_switch(sd_f, monkeypatch, precision):
+    """GVFI_F_S2D=1: cost-map convolutions on the LDS-DMA kernel through the space-to-depth layout (A/B switch)."""
+    monkeypatch.setenv("GVFI_F_S2D", "1")
+    meta, gold = load_golden("f_136x152_t040")
+    x, coords, ts = golden_inputs(meta)
+    m = _model(sd_f, precision)
+    out = _run(m, x, coords, ts)
+    assert m.engine(DEV).s2d
+    p = psnr(out["imgt_pred"][0], gold["imgt_pred_0"])
+    assert p >= (80.0 if precision == "fp32" else 35.0), p
 
 
 @pytest.mark.gpu

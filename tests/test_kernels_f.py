@@ -36,6 +36,7 @@ def _all(rt):
     kf.attn_global_case(rt)
     kf.xqk_case(rt)
     kf.tile_softmax_case(rt)
+    kf.s2d_conv_case(rt)
 
 
 def test_flowformer_kernels_emulated(rt_sim):
