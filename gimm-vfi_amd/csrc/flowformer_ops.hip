@@ -8,6 +8,7 @@
 // First correct version: one thread per output row / (query, head); the heavy parts of the path are the
 // contractions, these kernels stream a few hundred bytes per token.
 #include "common.h"
+#include <stdlib.h>
 
 #define GVFI_BLOCK 256
 static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK - 1) / GVFI_BLOCK)); }
@@ -338,10 +339,71 @@ __global__ void attn_window_kernel(const T* __restrict__ q, int ldq, const T* __
         }
     acc.store(out + row * ldo + hd * HD);
 }
+// LDS-staged variant (A/B switch GVFI_ATTN_LDS=1, not yet measured): one workgroup per window stages its ws*ws key and
+// value rows (padded positions from kpad / vpad, rounded to the activation type) once; a lane owns one (query, head)
+// and reads the keys from LDS -- lanes of a wave are (8 queries x 8 heads): same-head lanes broadcast, different heads
+// are HD elements apart (no bank conflict for HD*sizeof(T) >= 16 bytes).
+template <typename T, int HD>
+__global__ void attn_window_lds_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                       const T* __restrict__ v, int ldv, const float* __restrict__ kpad,
+                                       const float* __restrict__ vpad, T* __restrict__ out, int ldo, int H, int W, int ws,
+                                       int heads, float scale) {
+    GVFI_DYN_SMEM(smem);
+    const int C = heads * HD, nk = ws * ws;
+    T* Ks = (T*)smem;
+    T* Vs = Ks + nk * C;
+    const int nwx = (W + ws - 1) / ws, nwy = (H + ws - 1) / ws;
+    int b = blockIdx.x;
+    const int wx = (b % nwx) * ws;
+    b /= nwx;
+    const int wy = (b % nwy) * ws;
+    const long long img0 = (long long)(b / nwy) * H * W;
+    for (int i = threadIdx.x; i < nk * C; i += blockDim.x) {
+        const int pos = i / C, c = i - pos * C;
+        const int yy = wy + pos / ws, xx = wx + pos % ws;
+        if (yy < H && xx < W) {
+            const long long row = img0 + (long long)yy * W + xx;
+            Ks[i] = k[row * ldk + c];
+            Vs[i] = v[row * ldv + c];
+        } else {
+            Elem<T>::st(&Ks[i], kpad[pos * C + c]);
+            Elem<T>::st(&Vs[i], vpad[pos * C + c]);
+        }
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < nk * heads; item += blockDim.x) {
+        const int hd = item % heads, pos = item / heads;
+        const int yy = wy + pos / ws, xx = wx + pos % ws;
+        if (yy >= H || xx >= W) continue;
+        const long long row = img0 + (long long)yy * W + xx;
+        AttnAcc<T, HD> acc;
+        acc.init(q + row * ldq + hd * HD);
+        for (int j = 0; j < nk; ++j) acc.key(Ks + j * C + hd * HD, Vs + j * C + hd * HD, scale);
+        acc.store(out + row * ldo + hd * HD);
+    }
+}
+static inline bool gvfi_attn_lds() {
+    const char* e = getenv("GVFI_ATTN_LDS");
+    return e && e[0] == '1';
+}
 extern "C" int gvfi_attn_window(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
                                 const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
                                 int head_dim, float scale, int dtype, void* stream) {
     const long long total = (long long)n_img * H * W * heads;
+    const size_t shm = (size_t)2 * ws * ws * heads * head_dim * (dtype == GVFI_F32 ? 4 : 2);
+    if (gvfi_attn_lds() && shm <= 150 * 1024) {
+        dim3 grid((unsigned)((long long)n_img * ((H + ws - 1) / ws) * ((W + ws - 1) / ws)));
+#define GVFI_AWL(HD_)                                                                                                 \
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP_SHM((attn_window_lds_kernel<T, HD_>), grid, dim3(GVFI_BLOCK), shm,         \
+                                                (hipStream_t)stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v,   \
+                                                ldv, kpad, vpad, (T*)out, ldo, H, W, ws, heads, scale))
+        if (head_dim == 8) GVFI_AWL(8);
+        else if (head_dim == 16) GVFI_AWL(16);
+        else if (head_dim == 32) GVFI_AWL(32);
+        else return -2;
+#undef GVFI_AWL
+        return (int)hipGetLastError();
+    }
 #define GVFI_AW(HD_)                                                                                                 \
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_window_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),          \
                                               (hipStream_t)stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
@@ -381,12 +443,57 @@ __global__ void attn_global_kernel(const T* __restrict__ q, int ldq, long long q
     }
     acc.store(out + (g1 * ob1 + g0 * ob0 + i * os) * ldo + hd * HD);
 }
+// LDS-staged variant of the batched case (G0 == 1, unit strides: sub-sampled global attention): a workgroup stages
+// the M key / value rows of its group once and serves QB consecutive queries x all heads (GVFI_ATTN_LDS=1).
+template <typename T, int HD>
+__global__ void attn_global_lds_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                       const T* __restrict__ v, int ldv, T* __restrict__ out, int ldo, int NQ, int M,
+                                       int heads, float scale, int QB) {
+    GVFI_DYN_SMEM(smem);
+    const int C = heads * HD;
+    T* Ks = (T*)smem;
+    T* Vs = Ks + M * C;
+    const int chunks = (NQ + QB - 1) / QB;
+    const long long g1 = blockIdx.x / chunks;
+    const int q0 = (int)(blockIdx.x % chunks) * QB;
+    for (int i = threadIdx.x; i < M * C; i += blockDim.x) {
+        const int j = i / C, c = i - j * C;
+        Ks[i] = k[(g1 * M + j) * ldk + c];
+        Vs[i] = v[(g1 * M + j) * ldv + c];
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < QB * heads; item += blockDim.x) {
+        const int hd = item % heads, qi = q0 + item / heads;
+        if (qi >= NQ) continue;
+        const long long row = g1 * NQ + qi;
+        AttnAcc<T, HD> acc;
+        acc.init(q + row * ldq + hd * HD);
+        for (int j = 0; j < M; ++j) acc.key(Ks + j * C + hd * HD, Vs + j * C + hd * HD, scale);
+        acc.store(out + row * ldo + hd * HD);
+    }
+}
 extern "C" int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
                                 const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
                                 long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
                                 int head_dim, float scale, int dtype, void* stream) {
     if (G0 <= 0 || NQ <= 0 || M <= 0) return -2;
     const long long total = G1 * G0 * NQ * heads;
+    const size_t shm = (size_t)2 * M * heads * head_dim * (dtype == GVFI_F32 ? 4 : 2);
+    if (gvfi_attn_lds() && G0 == 1 && qs == 1 && ks == 1 && os == 1 && qb1 == NQ && ob1 == NQ && kb1 == M && NQ >= 64 &&
+        shm <= 150 * 1024) {
+        const int QB = GVFI_BLOCK / heads;
+        dim3 grid((unsigned)(G1 * ((NQ + QB - 1) / QB)));
+#define GVFI_AGL(HD_)                                                                                                  \
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP_SHM((attn_global_lds_kernel<T, HD_>), grid, dim3(GVFI_BLOCK), shm,          \
+                                                (hipStream_t)stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v,    \
+                                                ldv, (T*)out, ldo, NQ, M, heads, scale, QB))
+        if (head_dim == 8) GVFI_AGL(8);
+        else if (head_dim == 16) GVFI_AGL(16);
+        else if (head_dim == 32) GVFI_AGL(32);
+        else return -2;
+#undef GVFI_AGL
+        return (int)hipGetLastError();
+    }
 #define GVFI_AG(HD_)                                                                                                   \
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_global_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),            \
                                               (hipStream_t)stream, (const T*)q, ldq, qb1, qb0, qs, (const T*)k, ldk,     \

@@ -202,3 +202,25 @@ def s2d_conv_case(rt, maps=3, h=9, w=11):
     r3 = F.conv2d(r2, w2, b2, stride=2, padding=2)
     got = e3.float().cpu().permute(0, 3, 1, 2)
     assert float((got - r3).abs().max()) <= 3 * tol(rt, float(r3.abs().max()) + 1.0)
+
+
+def attn_lds_case(rt):
+    """GVFI_ATTN_LDS=1: the LDS-staged window / batched-global attention variants against the same oracle functions."""
+    import os
+
+    os.environ["GVFI_ATTN_LDS"] = "1"
+    try:
+        attn_window_case(rt)                                   # ragged grid: padded window positions from kpad / vpad
+        attn_window_case(rt, B=1, H=7, W=14, C=128, heads=4)   # head_dim 32
+        g = _g(11)
+        heads, hd = 8, 16
+        C = heads * hd
+        B, N, M = 2, 70, 12                                   # N >= 64 -> LDS variant, ragged last query chunk
+        q, k, v = (_r(rt, torch.randn(B, n_, C, generator=g)) for n_ in (N, M, M))
+        ref = forc._mha(q, k, v, heads)
+        dev = lambda t: t.reshape(-1, C).to(rt.tdtype).to(rt.device)
+        out = torch.empty(B * N, C, dtype=rt.tdtype, device=rt.device)
+        rt.attn_global(dev(q), (N, 0, 1), dev(k), dev(v), (M, 0, 1), out, (N, 0, 1), B, 1, N, M, heads, hd)
+        assert float((out.float().cpu().reshape(B, N, C) - ref).abs().max()) <= 2 * tol(rt, float(ref.abs().max()) + 1.0)
+    finally:
+        del os.environ["GVFI_ATTN_LDS"]

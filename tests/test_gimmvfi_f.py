@@ -157,14 +157,16 @@ def test_gpu_f_fp32_matches_reference_golden(name, sd_f):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_gpu_f_s2d_switch(sd_f, monkeypatch, precision):
-    """GVFI_F_S2D=1: cost-map convolutions on the LDS-DMA kernel through the space-to-depth layout (A/B switch)."""
-    monkeypatch.setenv("GVFI_F_S2D", "1")
+@pytest.mark.parametrize("switch", ["GVFI_F_S2D", "GVFI_ATTN_LDS"])
+def test_gpu_f_ab_switches(sd_f, monkeypatch, precision, switch):
+    """A/B switches prepared for the next measurement round (off by default): GVFI_F_S2D=1 = cost-map convolutions on
+    the LDS-DMA kernel through the space-to-depth layout; GVFI_ATTN_LDS=1 = LDS-staged window / sub-sampled attention."""
+    monkeypatch.setenv(switch, "1")
     meta, gold = load_golden("f_136x152_t040")
     x, coords, ts = golden_inputs(meta)
     m = _model(sd_f, precision)
     out = _run(m, x, coords, ts)
-    assert m.engine(DEV).s2d
+    assert m.engine(DEV).s2d == (switch == "GVFI_F_S2D")
     p = psnr(out["imgt_pred"][0], gold["imgt_pred_0"])
     assert p >= (80.0 if precision == "fp32" else 35.0), p
 

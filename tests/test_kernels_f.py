@@ -37,6 +37,7 @@ def _all(rt):
     kf.xqk_case(rt)
     kf.tile_softmax_case(rt)
     kf.s2d_conv_case(rt)
+    kf.attn_lds_case(rt)
 
 
 def test_flowformer_kernels_emulated(rt_sim):
