@@ -9,6 +9,8 @@ Tolerances: fp32 mode PSNR >= 80 dB, flows within 5e-3 px (32 recurrent iteratio
 MI355X: 139 dB, 3e-5 px); bf16 mode PSNR >= 35 dB and mean flow error < 0.5 px on flows of up to 30 px (measured:
 43.7-49.0 dB, 0.15-0.21 px with the seeded random weights -- bf16 operands through two Twins encoders, 6 context-aware
 blocks and 32 decoder iterations; flows / cost volume / coordinates / residual streams stay fp32)."""
+import os
+
 import pytest
 import torch
 
@@ -156,6 +158,9 @@ def test_gpu_f_fp32_matches_reference_golden(name, sd_f):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("GVFI_TEST_UNMEASURED") != "1",
+                    reason="A/B switches are emulator-verified but not yet run on an MI355X; opt in with "
+                           "GVFI_TEST_UNMEASURED=1 (tools/f_profile.sh does)")
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("switch", ["GVFI_F_S2D", "GVFI_ATTN_LDS"])
 def test_gpu_f_ab_switches(sd_f, monkeypatch, precision, switch):

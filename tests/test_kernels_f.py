@@ -1,5 +1,7 @@
 """FlowFormer glue kernels (csrc/flowformer_ops.hip): CPU emulator build of the real sources (`-m "not gpu"`) and the
 gfx950 library on the GPU (`-m gpu`), same cases (tests/kernel_cases_f.py)."""
+import os
+
 import pytest
 
 import kernel_cases_f as kf
@@ -36,12 +38,16 @@ def _all(rt):
     kf.attn_global_case(rt)
     kf.xqk_case(rt)
     kf.tile_softmax_case(rt)
+
+
+def _switches(rt):
     kf.s2d_conv_case(rt)
     kf.attn_lds_case(rt)
 
 
 def test_flowformer_kernels_emulated(rt_sim):
     _all(rt_sim)
+    _switches(rt_sim)
 
 
 @pytest.mark.gpu
@@ -49,4 +55,15 @@ def test_flowformer_kernels_gpu(rt_gpu):
     import torch
 
     _all(rt_gpu)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("GVFI_TEST_UNMEASURED") != "1",
+                    reason="A/B switch kernels (GVFI_F_S2D / GVFI_ATTN_LDS): emulator-verified, not yet run on an MI355X; "
+                           "opt in with GVFI_TEST_UNMEASURED=1 (tools/f_profile.sh does)")
+def test_flowformer_switch_kernels_gpu(rt_gpu):
+    import torch
+
+    _switches(rt_gpu)
     torch.cuda.synchronize()
