@@ -25,10 +25,13 @@
 #define GVFI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define GVFI_LAUNCH_COOP_SHM(kernel, grid, block, shm, stream, ...)                                         \
     do {                                                                                                    \
-        static int gvfi_attr_set_ = 0;                                                                      \
-        if (gvfi_attr_set_ < (int)(shm)) {                                                                  \
+        static int gvfi_attr_set_[16] = {0}; /* per device: the attribute belongs to the device's code object */ \
+        int gvfi_dev_ = 0;                                                                                  \
+        (void)hipGetDevice(&gvfi_dev_);                                                                     \
+        gvfi_dev_ &= 15;                                                                                    \
+        if (gvfi_attr_set_[gvfi_dev_] < (int)(shm)) {                                                       \
             hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shm)); \
-            gvfi_attr_set_ = (int)(shm);                                                                    \
+            gvfi_attr_set_[gvfi_dev_] = (int)(shm);                                                         \
         }                                                                                                   \
         hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                                  \
     } while (0)

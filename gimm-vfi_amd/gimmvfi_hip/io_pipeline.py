@@ -77,7 +77,12 @@ class FramePrefetcher:
                 self.ready[i] = (host, None, None)
         dev, ev, _ = self.ready[i]
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            # the block was allocated on copy_stream's pool: tell the caching allocator that the consumer stream reads
+            # it, otherwise dropping the entry below hands the block back to copy_stream while kernels queued on `cur`
+            # (the host runs several pairs ahead of the GPU) have not read it yet and a later upload overwrites it
+            dev.record_stream(cur)
         for k in [k for k in self.ready if k < i - 1]:      # frames behind the sliding pair window are done
             del self.ready[k]
         return dev

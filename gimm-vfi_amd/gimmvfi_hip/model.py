@@ -31,6 +31,47 @@ class _Node(nn.Module):
 _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 
 
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def check_supported_config(config):
+    """The kernels hard-wire the architecture values of the reference's shipped configs
+    (configs/gimmvfi/gimmvfi_{r,f}_arb.yaml, configs/gimm/gimm.yaml + the dataclass defaults of
+    generalizable_INR/configs.py:38-57, modules/module_config.py:28-41).  Anything else would silently compute a
+    different function than the reference does with that yaml, so it is rejected here."""
+    if config is None:
+        return
+    want = {"fwarp_type": "linear"}
+    for k, v in want.items():
+        got = _cfg_get(config, k, v)
+        if got != v:
+            raise ValueError(f"gimmvfi_hip supports arch.{k} = {v!r} only (got {got!r})")
+    hyp = _cfg_get(config, "hyponet")
+    if hyp is None:
+        return
+    hwant = {"type": "mlp", "n_layer": 5, "use_bias": True, "input_dim": 3, "output_dim": 2, "output_bias": 0.5,
+             "normalize_weight": True, "linear_interpo": False}
+    for k, v in hwant.items():
+        got = _cfg_get(hyp, k, v)
+        if got != v:
+            raise ValueError(f"gimmvfi_hip supports arch.hyponet.{k} = {v!r} only (got {got!r})")
+    hd = _cfg_get(hyp, "hidden_dim", [128])
+    if list(hd) != [128]:
+        raise ValueError(f"gimmvfi_hip supports arch.hyponet.hidden_dim = [128] only (got {list(hd)!r})")
+    act = _cfg_get(hyp, "activation")
+    if act is not None:
+        if _cfg_get(act, "type", "siren") != "siren" or float(_cfg_get(act, "siren_w0", 1.0)) != 1.0:
+            raise ValueError("gimmvfi_hip supports arch.hyponet.activation = {type: siren, siren_w0: 1.0} only")
+    mod = _cfg_get(config, "modulated_layer_idxs")
+    if mod is not None and list(mod) != [1]:
+        raise ValueError(f"gimmvfi_hip supports arch.modulated_layer_idxs = [1] only (got {list(mod)!r})")
+
+
 class GIMMVFI_R(nn.Module):
     _spec = staticmethod(param_spec)
     _init_sd = staticmethod(random_state_dict)
@@ -38,6 +79,7 @@ class GIMMVFI_R(nn.Module):
 
     def __init__(self, config=None, precision=None):
         super().__init__()
+        check_supported_config(config)
         self.config = config
         self.raft_iter = 20  # gimmvfi_r.py:41 (config.raft_iter is ignored by the reference too)
         cfg_prec = None
@@ -96,6 +138,7 @@ class GIMMVFI_R(nn.Module):
                 runtime = Runtime(L.get(), self.precision, device)
             self._engine = self._engine_cls(runtime, self.state_dict())
             self._engine_key = key
+            self._graphs = {}     # graphs captured on the previous engine replay ITS buffers and packed weights
         return self._engine
 
     # ---- reference API -------------------------------------------------------------------
@@ -114,6 +157,9 @@ class GIMMVFI_R(nn.Module):
             # the eager launch list is the same kernels -- never a different arithmetic path
             if "capture" not in str(e).lower() and "graph" not in str(e).lower():
                 raise
+            import warnings
+
+            warnings.warn(f"gimmvfi_hip: hipGraph capture failed ({e}); this model now launches eagerly (same kernels)")
             self.use_graph = False
             self._graphs = {}
             torch.cuda.synchronize(img_xs.device)
@@ -226,6 +272,7 @@ class GIMM(nn.Module):
 
     def __init__(self, config=None, precision=None):
         super().__init__()
+        check_supported_config(config)
         self.config = config
         cfg_prec = None
         if config is not None:

@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests need an MI355X: on a box without one a plain `pytest` run skips them instead of failing."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible (gpu-marked tests run on the MI355X box)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def sd():
     from gimmvfi_hip.params import random_state_dict

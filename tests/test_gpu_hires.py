@@ -1,0 +1,177 @@
+"""Parity at the configurations BASELINE.json's metric is quoted on.
+
+(a) 448x256 (configs[0]/[1]): the HIP path against the CPU oracle run LIVE on the GPU box's host cores on the bench
+    input (B=1, t=0.5) -- fp32 mode PSNR >= 80 dB / flows p99.9 < 2e-3 px, bf16 mode PSNR >= 40 dB / mean flow error
+    < 0.05 px; and the B=8 bench batch in bf16 against the same oracle sample.
+(b) 2K DS 0.5 and 4K DS 0.25, 8x (configs[2]/[4], reference README.md:87-96) on a seeded synthetic pair, and the
+    reference's own demo frames (844x720 padded to 864x736 at DS 1; 2048x1080 padded to 2048x1088 at DS 0.5), against
+    fixtures produced by the REFERENCE ITSELF (oracle/make_golden_hires.py; tests/golden/hr_r_*.npz): uint8 crops
+    within 1 LSB (fp32 mode) / PSNR >= 40 dB (bf16), 16x16 block means of the whole frame, INR flows.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gimmvfi_r_oracle as orc
+from util import GOLDEN, psnr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(sd, precision):
+    from gimmvfi_hip.model import GIMMVFI_R
+
+    m = GIMMVFI_R(precision=precision)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+# ------------------------------------------------------------------------------------------------ (a) 448x256, live oracle
+@pytest.fixture(scope="module")
+def bench_oracle(sd):
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    x = synthetic_pairs(8, 256, 448, seed=100)           # bench.py's rank-0 batch
+    coords = [(orc.sample_coord_input(1, (256, 448), [0.5], 1.0), None)]
+    ts = [0.5 * torch.ones(1)]
+    with torch.no_grad():
+        ref = orc.forward(sd, x[:1], coords, ts, None)
+    return x, ref
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_448x256_b1_vs_live_oracle(sd, bench_oracle, prec):
+    x, ref = bench_oracle
+    m = _model(sd, prec)
+    c = [(m.sample_coord_input(1, (256, 448), [0.5], device=DEV), None)]
+    out = m(x[:1].to(DEV), c, t=[0.5 * torch.ones(1, device=DEV)])
+    torch.cuda.synchronize()
+    p = psnr(out["imgt_pred"][0], ref["imgt_pred"][0])
+    d = (out["flowt"][0].cpu().float() - ref["flowt"][0]).abs().flatten()
+    dr = (out["raft_flow"].cpu().float() - ref["raft_flow"]).abs().flatten()
+    print(f"448x256 B=1 {prec}: PSNR {p:.2f} dB, flowt mean {float(d.mean()):.2e} p99.9 "
+          f"{float(d.kthvalue(int(d.numel() * 0.999))[0]):.2e}, raft_flow max {float(dr.max()):.2e}")
+    if prec == "fp32":
+        assert p >= 80.0, p
+        assert float(d.kthvalue(int(d.numel() * 0.999))[0]) < 2e-3
+        assert float(dr.max()) < 2e-3
+    else:
+        assert p >= 40.0, p
+        assert float(d.mean()) < 0.05
+
+
+def test_448x256_b8_bench_batch_bf16_sample0_vs_live_oracle(sd, bench_oracle):
+    """The very forward bench.py times (8 pairs, bf16, hipGraph replay): sample 0 of the batch against the oracle."""
+    x, ref = bench_oracle
+    m = _model(sd, "bf16")
+    c = [(m.sample_coord_input(8, (256, 448), [0.5], device=DEV), None)]
+    t = [0.5 * torch.ones(8, device=DEV)]
+    for _ in range(2):                                   # second call = graph replay
+        out = m(x.to(DEV), c, t=t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["imgt_pred"][0]).all()
+    p = psnr(out["imgt_pred"][0][:1], ref["imgt_pred"][0])
+    d = (out["flowt"][0][0].cpu().float() - ref["flowt"][0]).abs().flatten()
+    print(f"448x256 B=8 bf16 sample 0: PSNR {p:.2f} dB, flowt mean err {float(d.mean()):.2e}")
+    assert p >= 40.0, p
+    assert float(d.mean()) < 0.05
+
+
+# ------------------------------------------------------------------------------------------------ (b) reference fixtures
+HR_CASES = ["demo_864x736", "2k_ds050", "demo2k_ds050", "4k_ds025"]
+
+
+def load_hr(name, model="r"):
+    path = os.path.join(GOLDEN, f"hr_{model}_{name}.npz")
+    if not os.path.isfile(path):
+        pytest.skip(f"{path} not generated")
+    z = np.load(path)
+    return json.loads(str(z["meta"])), z
+
+
+def hr_inputs(meta, z):
+    """The padded (1,3,2,Hp,Wp) input of a fixture: synthetic pairs are re-generated from the seed (guarded by the
+    stored pixel sum), demo frames come from the fixture and go through the CLI's InputPadder (src/video_Nx.py:155-157)."""
+    if meta["kind"] == "synthetic":
+        from gimmvfi_hip.synth import synthetic_pairs
+
+        x = synthetic_pairs(1, meta["H"], meta["W"], meta["seed"])
+    else:
+        import sys
+
+        from util import ROOT
+
+        sys.path.insert(0, os.path.join(ROOT, "gimm-vfi_amd", "src"))
+        from utils.utils import InputPadder
+
+        fr = [torch.from_numpy(np.ascontiguousarray(f)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
+              for f in z["frames_u8"]]
+        i0, i2 = InputPadder(fr[0].shape, 32).pad(fr[0], fr[1])
+        x = torch.stack([i0, i2], 2)
+    assert tuple(x.shape[-2:]) == (meta["Hp"], meta["Wp"])
+    assert int(torch.round(x * 255.0).to(torch.int64).sum()) == meta["in_sum"], "input re-generation differs"
+    return x
+
+
+def run_hr(m, meta, x):
+    N, ds = meta["N"], meta["ds"]
+    B, (Hp, Wp) = 1, x.shape[-2:]
+    ratio = 1.0 if ds is None else ds
+    coords = [(m.sample_coord_input(B, (Hp, Wp), [i / N], device=DEV, upsample_ratio=ratio), None) for i in range(1, N)]
+    ts = [(i / N) * torch.ones(B, device=DEV) for i in range(1, N)]
+    out = m(x.to(DEV), coords, t=ts, ds_factor=ds)
+    torch.cuda.synchronize()
+    return out
+
+
+def check_hr(out, meta, z, prec, tag):
+    T = meta["N"] - 1
+    assert len(out["imgt_pred"]) == T
+    cyx = z["crop_yx"]
+    worst_psnr, worst_lsb, worst_bm, worst_flow = 1e9, 0, 0.0, 0.0
+    for i in range(T):
+        img = out["imgt_pred"][i][0].float().cpu()
+        assert tuple(img.shape) == (3, meta["Hp"], meta["Wp"]) and torch.isfinite(img).all()
+        bm = img.reshape(3, meta["Hp"] // 16, 16, meta["Wp"] // 16, 16).mean(dim=(2, 4))
+        worst_bm = max(worst_bm, float((bm - torch.from_numpy(z[f"bm_{i}"])).abs().max()))
+        if i not in meta["keep"]:
+            continue
+        u8 = torch.round(img.clamp(0, 1) * 255.0)
+        ref = torch.from_numpy(z[f"crops_{i}"]).float()
+        got = torch.stack([u8[:, y:y + ref.shape[-2], x_:x_ + ref.shape[-1]] for y, x_ in cyx])
+        worst_lsb = max(worst_lsb, int((got - ref).abs().max()))
+        mse = float(((got - ref) / 255.0).pow(2).mean())
+        worst_psnr = min(worst_psnr, 99.0 if mse == 0 else -10.0 * np.log10(mse))
+        ft = out["flowt"][i].float().cpu()
+        ft = ft if ft.dim() == 3 else ft[0]
+        rf = torch.from_numpy(z[f"flowt_{i}"].astype(np.float32))
+        assert tuple(ft[:, ::2, ::2].shape) == tuple(rf.shape)
+        d = (ft[:, ::2, ::2] - rf).abs() - 1.5e-3 * rf.abs()        # fp16 storage of the fixture: 2^-11 relative
+        worst_flow = max(worst_flow, float(d.flatten().kthvalue(int(d.numel() * 0.999))[0]))
+    print(f"{tag} {prec}: crops max |d| {worst_lsb} LSB, min PSNR {worst_psnr:.2f} dB, block-mean max |d| {worst_bm:.2e}, "
+          f"flowt p99.9 |d| {worst_flow:.2e} px (max |flow| {meta['flow_absmax']:.1f})")
+    if prec == "fp32":
+        assert worst_lsb <= 1, worst_lsb                    # +-1 LSB of the 8-bit frame
+        assert worst_psnr >= 60.0, worst_psnr
+        assert worst_bm <= 2e-4, worst_bm
+        assert worst_flow <= 2e-3, worst_flow
+    else:
+        assert worst_psnr >= 40.0, worst_psnr
+        assert worst_bm <= 2e-2, worst_bm
+        assert worst_flow <= 0.25, worst_flow
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", HR_CASES)
+def test_hires_matches_reference_fixture(sd, name, prec):
+    meta, z = load_hr(name)
+    x = hr_inputs(meta, z)
+    m = _model(sd, prec)
+    out = run_hr(m, meta, x)
+    check_hr(out, meta, z, prec, name)
+    del out, m
+    torch.cuda.empty_cache()

@@ -120,5 +120,13 @@ def test_softsplat_edge_cases(rt):
     kc.splat_case(rt)
 
 
+def test_softsplat_owner_tiles(rt):
+    kc.splat_tile_case(rt)
+
+
+def test_softsplat_native_op_contract(rt):
+    kc.splat_nchw_case(rt)
+
+
 def test_splat_weights_and_flow_norm(rt, sd):
     kc.splat_weights_and_norm_case(rt, sd)
