@@ -9,6 +9,7 @@ iterations 1..19, and the t-independent decoder `upsample` stacks inside the tim
 """
 import functools
 import math
+import os
 
 import torch
 
@@ -52,6 +53,8 @@ class Engine:
         self.alpha_v = float(sd["alpha_v"].float().cpu().item())
         self.alpha_fe = float(sd["alpha_fe"].float().cpu().item())
         self.g9 = sd["g_filter"].float().reshape(9).contiguous().to(rt.device)
+        # number of parallel launch sequences the flow estimator's recurrence is split into (sub-batches of images)
+        self.raft_lanes = int(os.environ.get("GVFI_RAFT_LANES", "2"))
         self.layers = {}
         self._build(sd)
 
@@ -302,31 +305,51 @@ class Engine:
             rt.conv(lay, View(xbuf, 0, 128), ctx[key])
         fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
         fpart = rt.f32(n, h8, w8, 20)   # 9 taps x 2 partial sums of the flow head (+ pad)
-        for it in range(iters):
-            rt.corr_lookup(pyr_ab, coords, corrf, n, h8, w8, h8, w8)
-            rt.flow_pack(coords, flow8, View(xbuf, 254, 2))
-            # the correlation and flow branches of the motion encoder are independent and each under-fills the chip
-            # (224-448 workgroups): fork the flow branch onto a second stream (a parallel branch of the hipGraph)
-            with rt.fork() as branch:
-                rt.conv(Ls[u + ".encoder.convc1"], corrf, c1, act1=A.ACT_RELU)
-                rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
-                with branch:
-                    rt.patch_conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, scratch=fcol, act1=A.ACT_RELU)
-                    rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".encoder.conv"], corflo, View(xbuf, 128, 126), act1=A.ACT_RELU)
-            hc, hn = hA, hB
-            for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73
-                xm = View(xbuf, 128, 128)   # [motion(126) | flow(2)]
-                rt.conv(Ls["gru.zr" + nn_], hc, zbuf, x1=xm, epi=A.EPI_GRU_ZR, y2=rh, aux0=hc, res=ctx["gru.zr" + nn_])
-                rt.conv(Ls["gru.q" + nn_], rh, hn, x1=xm, epi=A.EPI_GRU_Q, aux0=hc, aux1=zbuf, res=ctx["gru.q" + nn_])
-                hc, hn = hn, hc
-            # after two passes the state is back in hA
-            rt.conv(Ls[u + ".flow_head.conv1"], hA, fh, act1=A.ACT_RELU)
-            rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh, View(coords), res=View(coords), scratch=fpart)   # coords1 += delta
-            if taps is not None and it in (0, iters - 1):
-                taps[f"r01_corr_it{it}"] = corrf[:B, ..., :324].clone()
-                taps[f"r01_net_it{it}"] = hA[:B].clone()
-                taps[f"r01_coords_it{it}"] = coords[:B].clone()
+        P8 = h8 * w8
+
+        def chain(a, b):
+            """The 20 update iterations of images [a, b) (raft/raft.py:144-161): every tensor of the recurrence is
+            per image, so sub-batches are independent launch sequences."""
+            m = b - a
+            pyr_s = [p[a * P8:b * P8] for p in pyr_ab]
+            co, cf, fl, xb = coords[a:b], corrf[a:b], flow8[a:b], xbuf[a:b]
+            c1_, cfl, f1_, zb, rh_, fh_ = c1[a:b], corflo[a:b], f1[a:b], zbuf[a:b], rh[a:b], fh[a:b]
+            ha, hb, fc, fp = hA[a:b], hB[a:b], fcol[a:b], fpart[a:b]
+            cx = {k: v[a:b] for k, v in ctx.items()}
+            for it in range(iters):
+                rt.corr_lookup(pyr_s, co, cf, m, h8, w8, h8, w8)
+                rt.flow_pack(co, fl, View(xb, 254, 2))
+                # the correlation and flow branches of the motion encoder are independent and each under-fills the chip:
+                # fork the flow branch onto a second stream (a parallel branch of the hipGraph)
+                with rt.fork() as branch:
+                    rt.conv(Ls[u + ".encoder.convc1"], cf, c1_, act1=A.ACT_RELU)
+                    rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
+                    with branch:
+                        rt.patch_conv(Ls[u + ".encoder.convf1"], View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
+                        rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
+                rt.conv(Ls[u + ".encoder.conv"], cfl, View(xb, 128, 126), act1=A.ACT_RELU)
+                hc, hn = ha, hb
+                for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73
+                    xm = View(xb, 128, 128)   # [motion(126) | flow(2)]
+                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=xm, epi=A.EPI_GRU_ZR, y2=rh_, aux0=hc, res=cx["gru.zr" + nn_])
+                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=xm, epi=A.EPI_GRU_Q, aux0=hc, aux1=zb, res=cx["gru.q" + nn_])
+                    hc, hn = hn, hc
+                # after two passes the state is back in hA
+                rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)
+                rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh_, View(co), res=View(co), scratch=fp)   # coords1 += delta
+                if taps is not None and it in (0, iters - 1):
+                    taps[f"r01_corr_it{it}"] = corrf[:B, ..., :324].clone()
+                    taps[f"r01_net_it{it}"] = hA[:B].clone()
+                    taps[f"r01_coords_it{it}"] = coords[:B].clone()
+
+        # k sub-batches of images run their recurrences as k parallel launch sequences (hipGraph branches): each launch
+        # of the recurrence under-fills the chip (M = n*h8*w8 rows -> 224-448 workgroups with serial phases), so
+        # independent sequences overlap each other's prologues, tails and epilogues.  Same arithmetic per image.
+        k = 1 if taps is not None else max(1, min(self.raft_lanes, n))
+        with rt.lanes(k) as lanes:
+            for i in range(k):
+                with lanes[i]:
+                    chain(i * n // k, (i + 1) * n // k)
         rt.conv(Ls[u + ".mask.0"], hA, fh, act1=A.ACT_RELU)
         mask = rt.f32(n, h8, w8, 576)
         rt.conv(Ls[u + ".mask.2"], fh, mask, out_scale=0.25)

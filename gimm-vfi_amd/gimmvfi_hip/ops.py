@@ -140,7 +140,8 @@ class InrMlp:
 class _Fork:
     """`with rt.fork() as branch:` ... `with branch:` runs the inner block on a second HIP stream that starts after
     everything enqueued so far and is joined when the outer block exits (a fork/join in a captured hipGraph).
-    Buffers touched inside must be allocated before the fork (no allocator traffic on the side stream)."""
+    Buffers touched inside must be allocated before the fork (no allocator traffic on the side stream).  Every
+    stream has its own side stream, so forks inside the lanes of ``rt.lanes()`` stay independent."""
 
     def __init__(self, rt):
         self.rt = rt
@@ -149,10 +150,9 @@ class _Fork:
 
     def __enter__(self):
         if self.rt.on_gpu and self.rt.ev_log is None:
-            if self.rt._side is None:
-                self.rt._side = torch.cuda.Stream(device=self.rt.device)
-            self.side = self.rt._side
-            self.side.wait_stream(torch.cuda.current_stream(self.rt.device))
+            cur = torch.cuda.current_stream(self.rt.device)
+            self.side = self.rt._side_of(cur)
+            self.side.wait_stream(cur)
         return _Branch(self)
 
     def __exit__(self, *exc):
@@ -178,6 +178,48 @@ class _Branch:
         return False
 
 
+class _Lanes:
+    """`with rt.lanes(k) as lanes:` then `with lanes[i]: ...` for i < k: k independent launch sequences (e.g. the
+    recurrences of k sub-batches), each on its own HIP stream, all started after the work enqueued so far and joined
+    when the outer block exits.  Inside a hipGraph capture they become k parallel branches, so the under-filled
+    launches of one sequence (224-448 workgroups, each with a serial prologue / K loop / epilogue) overlap those of
+    the others.  Lane 0 is the current stream.  Without a GPU, or while launches are being timed one by one
+    (``rt.ev_log``), the lanes simply run one after another on the current stream."""
+
+    def __init__(self, rt, k):
+        self.rt, self.k = rt, k
+        self.cur = None
+        self.streams = []
+
+    def __enter__(self):
+        rt = self.rt
+        if rt.on_gpu and rt.ev_log is None and self.k > 1:
+            self.cur = torch.cuda.current_stream(rt.device)
+            self.streams = rt._lane_streams(self.cur, self.k - 1)
+            for st in self.streams:
+                st.wait_stream(self.cur)
+        return self
+
+    def __getitem__(self, i):
+        assert 0 <= i < self.k
+        if not self.streams or i == 0:
+            return _NullCtx()
+        return torch.cuda.stream(self.streams[i - 1])
+
+    def __exit__(self, *exc):
+        for st in self.streams:
+            self.cur.wait_stream(st)
+        return False
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class Runtime:
     def __init__(self, lib, precision, device):
         self.lib = lib
@@ -193,7 +235,8 @@ class Runtime:
         self.n_launch = 0
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
-        self._side = None        # second stream for fork()
+        self._sides = {}         # stream id -> its side stream for fork()
+        self._lanes = {}         # stream id -> extra streams for lanes()
         self.last_stats_fused = False
 
     # ------------------------------------------------------------------ memory
@@ -202,6 +245,21 @@ class Runtime:
 
     def fork(self):
         return _Fork(self)
+
+    def lanes(self, k):
+        return _Lanes(self, k)
+
+    def _side_of(self, cur):
+        key = cur.cuda_stream
+        if key not in self._sides:
+            self._sides[key] = torch.cuda.Stream(device=self.device)
+        return self._sides[key]
+
+    def _lane_streams(self, cur, k):
+        lst = self._lanes.setdefault(cur.cuda_stream, [])
+        while len(lst) < k:
+            lst.append(torch.cuda.Stream(device=self.device))
+        return lst[:k]
 
     def cp(self, c):
         return roundup(c, self.VE)
