@@ -319,14 +319,13 @@ class Engine:
             for it in range(iters):
                 rt.corr_lookup(pyr_s, co, cf, m, h8, w8, h8, w8)
                 rt.flow_pack(co, fl, View(xb, 254, 2))
-                # the correlation and flow branches of the motion encoder are independent and each under-fills the chip:
-                # fork the flow branch onto a second stream (a parallel branch of the hipGraph)
-                with rt.fork() as branch:
-                    rt.conv(Ls[u + ".encoder.convc1"], cf, c1_, act1=A.ACT_RELU)
-                    rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
-                    with branch:
-                        rt.patch_conv(Ls[u + ".encoder.convf1"], View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
-                        rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
+                # (measured r2: running the flow branch of the motion encoder as a parallel graph branch is worth
+                # nothing -- the CUs already hold the 2 workgroups their LDS admits -- and forks nested inside lanes()
+                # crash hipStreamEndCapture on ROCm 7.0, so the branches are launched in sequence)
+                rt.conv(Ls[u + ".encoder.convc1"], cf, c1_, act1=A.ACT_RELU)
+                rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
+                rt.patch_conv(Ls[u + ".encoder.convf1"], View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
+                rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.conv"], cfl, View(xb, 128, 126), act1=A.ACT_RELU)
                 hc, hn = ha, hb
                 for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73

@@ -128,6 +128,7 @@ class EngineF(Engine):
     def _build_flow(self, sd):
         """FlowFormer (flowformer/__init__.py:6-18, transformer.py:29-42)."""
         self.ln, self.consts = {}, {}
+        self.raft_lanes = int(os.environ.get("GVFI_F_LANES", "1"))   # parallel decoder sequences (see Engine._raft)
         fe = "flow_estimator"
         self._build_twins(sd, fe + ".context_encoder")
         me = fe + ".memory_encoder"
@@ -464,49 +465,70 @@ class EngineF(Engine):
             rt.conv(lay, inp, ctxg[key])
         fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
         fpart = rt.f32(n, h8, w8, 20)
-        rows = n * P8
         lay_q = (P8, 1, 0)
         lay_k = (K_LAT * P8, 1, P8)
         iters = 32 if iters is None else iters
-        for it in range(iters):
-            # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
-            rt.cost_lookup(vol, coords, View(corr, 64, 81), rows, h8, w8)
-            t1 = self._linear(md + ".flow_token_encoder.0", View(corr_rows, 64, 81), act=A.ACT_GELU)
-            query = self._linear(md + ".flow_token_encoder.2", t1)
-            # cross-attention of the one query against the map's 8 latent tokens   decoder.py:84-120
-            qn = rt.layernorm(query, self.ln[ca + ".norm1"], 1e-5)
-            rt.pos_embed(coords, rows, 1.0, 0.0, 64, qn, rows, True)
-            q = self._linear(ca + ".q", qn)
-            a = self._tok(rows, 64)
-            rt.attn_global(q, lay_q, View(kvm, 0, 64), View(kvm, 64, 64), lay_k, a, lay_q, n, P8, 1, K_LAT, 8, 8)
-            x = self._linear(ca + ".proj", a, x1=query, res=query)
-            y = rt.layernorm(x, self.ln[ca + ".norm2"], 1e-5)
-            self._linear(ca + ".ffn.3", self._linear(ca + ".ffn.0", y, act=A.ACT_GELU), out=View(corr_rows, 0, 64), res=x)
-            # GMAUpdateBlock   gru.py:130-160
-            rt.flow_pack(coords, flow8, View(X, 126, 2))
-            rt.conv(Ls[u + ".encoder.convc1"], corr, c1, act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".encoder.convc2"], c1, View(corflo, 0, 192), act1=A.ACT_RELU)
-            rt.patch_conv(Ls[u + ".encoder.convf1"], View(flow8, 0, 2), f1, scratch=fcol, act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".encoder.convf2"], f1, View(corflo, 192, 64), act1=A.ACT_RELU)
-            rt.conv(Ls[u + ".encoder.conv"], corflo, View(X, 0, 126), act1=A.ACT_RELU)
-            # global motion aggregation: X[128:256] = mf + gamma * attn @ (mf Wv^T)   gma.py:101-115
-            rt.copy(View(X, 0, 128), mfc, 128)
-            rt.conv(None, wv_rep, View(vT, 0, P8), groups=n, w_group_stride=P8 * 128, w_raw=mfc, cout=P8)
-            Xr = X.view(n, 1, P8, 256)
-            rt.conv(None, View(attn, 0, P8), View(Xr, 128, 128), groups=n, w_group_stride=128 * P8p, w_raw=vT, cout=128,
-                    res=View(Xr, 0, 128))
-            hc, hn = hA, hB
-            for nn_ in ("1", "2"):
-                rt.conv(Ls["gru.zr" + nn_], hc, zbuf, x1=X, epi=A.EPI_GRU_ZR, y2=rh, aux0=hc, res=ctxg["gru.zr" + nn_])
-                rt.conv(Ls["gru.q" + nn_], rh, hn, x1=X, epi=A.EPI_GRU_Q, aux0=hc, aux1=zbuf, res=ctxg["gru.q" + nn_])
-                hc, hn = hn, hc
-            rt.conv(Ls[u + ".flow_head.conv1"], hA, fh, act1=A.ACT_RELU)
-            rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh, View(coords), res=View(coords), scratch=fpart)
-            if taps is not None and it in (0, iters - 1):
-                taps[f"f01_cost_fwd_it{it}"] = corr[:B, ..., 64:145].clone()
-                taps[f"f01_cost_global_it{it}"] = corr[:B, ..., 0:64].clone()
-                taps[f"f01_net_it{it}"] = hA[:B].clone()
-                taps[f"f01_coords_it{it}"] = coords[:B].clone()
+
+        def chain(a, b):
+            """The decoder iterations of images [a, b) (decoder.py:289-314): every tensor of the recurrence is per image
+            (cost maps, latent memory, GMA attention matrix, GRU state), so sub-batches are independent sequences."""
+            m = b - a
+            rows = m * P8
+            vol_s = vol[a * P8:b * P8]
+            kvm_s = kvm[a * K_LAT * P8:b * K_LAT * P8]
+            co, cr, fl, Xs, mf, vt = coords[a:b], corr[a:b], flow8[a:b], X[a:b], mfc[a:b], vT[a:b]
+            at, wv = attn[a:b], wv_rep[a:b]
+            c1_, cfl, f1_, zb, rh_, fh_ = c1[a:b], corflo[a:b], f1[a:b], zbuf[a:b], rh[a:b], fh[a:b]
+            ha, hb, fc, fp = hA[a:b], hB[a:b], fcol[a:b], fpart[a:b]
+            cx = {k_: v[a:b] for k_, v in ctxg.items()}
+            cr_rows = cr.view(rows, cr.shape[-1])
+            for it in range(iters):
+                # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
+                rt.cost_lookup(vol_s, co, View(cr, 64, 81), rows, h8, w8)
+                t1 = self._linear(md + ".flow_token_encoder.0", View(cr_rows, 64, 81), act=A.ACT_GELU)
+                query = self._linear(md + ".flow_token_encoder.2", t1)
+                # cross-attention of the one query against the map's 8 latent tokens   decoder.py:84-120
+                qn = rt.layernorm(query, self.ln[ca + ".norm1"], 1e-5)
+                rt.pos_embed(co, rows, 1.0, 0.0, 64, qn, rows, True)
+                q = self._linear(ca + ".q", qn)
+                a_ = self._tok(rows, 64)
+                rt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)
+                x = self._linear(ca + ".proj", a_, x1=query, res=query)
+                y = rt.layernorm(x, self.ln[ca + ".norm2"], 1e-5)
+                self._linear(ca + ".ffn.3", self._linear(ca + ".ffn.0", y, act=A.ACT_GELU), out=View(cr_rows, 0, 64), res=x)
+                # GMAUpdateBlock   gru.py:130-160
+                rt.flow_pack(co, fl, View(Xs, 126, 2))
+                rt.conv(Ls[u + ".encoder.convc1"], cr, c1_, act1=A.ACT_RELU)
+                rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
+                rt.patch_conv(Ls[u + ".encoder.convf1"], View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
+                rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
+                rt.conv(Ls[u + ".encoder.conv"], cfl, View(Xs, 0, 126), act1=A.ACT_RELU)
+                # global motion aggregation: X[128:256] = mf + gamma * attn @ (mf Wv^T)   gma.py:101-115
+                rt.copy(View(Xs, 0, 128), mf, 128)
+                rt.conv(None, wv, View(vt, 0, P8), groups=m, w_group_stride=P8 * 128, w_raw=mf, cout=P8)
+                Xr = Xs.view(m, 1, P8, 256)
+                rt.conv(None, View(at, 0, P8), View(Xr, 128, 128), groups=m, w_group_stride=128 * P8p, w_raw=vt, cout=128,
+                        res=View(Xr, 0, 128))
+                hc, hn = ha, hb
+                for nn_ in ("1", "2"):
+                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=Xs, epi=A.EPI_GRU_ZR, y2=rh_, aux0=hc, res=cx["gru.zr" + nn_])
+                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=Xs, epi=A.EPI_GRU_Q, aux0=hc, aux1=zb, res=cx["gru.q" + nn_])
+                    hc, hn = hn, hc
+                rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)
+                rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh_, View(co), res=View(co), scratch=fp)
+                if taps is not None and it in (0, iters - 1):
+                    taps[f"f01_cost_fwd_it{it}"] = corr[:B, ..., 64:145].clone()
+                    taps[f"f01_cost_global_it{it}"] = corr[:B, ..., 0:64].clone()
+                    taps[f"f01_net_it{it}"] = hA[:B].clone()
+                    taps[f"f01_coords_it{it}"] = coords[:B].clone()
+
+        # parallel launch sequences over image sub-batches, as in Engine._raft (the 32 x 27 launches of the decoder are
+        # M = n*h8*w8-row problems that under-fill the chip one at a time)
+        k = 1 if taps is not None else max(1, min(self.raft_lanes, n))
+        with rt.lanes(k) as lanes:
+            for i in range(k):
+                with lanes[i]:
+                    chain(i * n // k, (i + 1) * n // k)
         rt.conv(Ls[u + ".mask.0"], hA, fh, act1=A.ACT_RELU)
         mask = rt.f32(n, h8, w8, 576)
         rt.conv(Ls[u + ".mask.2"], fh, mask, out_scale=0.25)

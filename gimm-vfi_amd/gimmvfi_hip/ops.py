@@ -137,54 +137,14 @@ class InrMlp:
         self.layers = list(zip(ws, bs))   # un-packed copies (host): kept for inspection / test restatements
 
 
-class _Fork:
-    """`with rt.fork() as branch:` ... `with branch:` runs the inner block on a second HIP stream that starts after
-    everything enqueued so far and is joined when the outer block exits (a fork/join in a captured hipGraph).
-    Buffers touched inside must be allocated before the fork (no allocator traffic on the side stream).  Every
-    stream has its own side stream, so forks inside the lanes of ``rt.lanes()`` stay independent."""
-
-    def __init__(self, rt):
-        self.rt = rt
-        self.side = None
-        self.ctx = None
-
-    def __enter__(self):
-        if self.rt.on_gpu and self.rt.ev_log is None:
-            cur = torch.cuda.current_stream(self.rt.device)
-            self.side = self.rt._side_of(cur)
-            self.side.wait_stream(cur)
-        return _Branch(self)
-
-    def __exit__(self, *exc):
-        if self.side is not None:
-            torch.cuda.current_stream(self.rt.device).wait_stream(self.side)
-        return False
-
-
-class _Branch:
-    def __init__(self, fork):
-        self.fork = fork
-        self.ctx = None
-
-    def __enter__(self):
-        if self.fork.side is not None:
-            self.ctx = torch.cuda.stream(self.fork.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-
 class _Lanes:
     """`with rt.lanes(k) as lanes:` then `with lanes[i]: ...` for i < k: k independent launch sequences (e.g. the
     recurrences of k sub-batches), each on its own HIP stream, all started after the work enqueued so far and joined
     when the outer block exits.  Inside a hipGraph capture they become k parallel branches, so the under-filled
     launches of one sequence (224-448 workgroups, each with a serial prologue / K loop / epilogue) overlap those of
     the others.  Lane 0 is the current stream.  Without a GPU, or while launches are being timed one by one
-    (``rt.ev_log``), the lanes simply run one after another on the current stream."""
+    (``rt.ev_log``), the lanes simply run one after another on the current stream.  Do not nest: a stream forked from
+    a forked stream crashes hipStreamEndCapture (ROCm 7.0, tools/lanes_probe.py)."""
 
     def __init__(self, rt, k):
         self.rt, self.k = rt, k
@@ -235,7 +195,6 @@ class Runtime:
         self.n_launch = 0
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
-        self._sides = {}         # stream id -> its side stream for fork()
         self._lanes = {}         # stream id -> extra streams for lanes()
         self.last_stats_fused = False
 
@@ -243,17 +202,8 @@ class Runtime:
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else 0
 
-    def fork(self):
-        return _Fork(self)
-
     def lanes(self, k):
         return _Lanes(self, k)
-
-    def _side_of(self, cur):
-        key = cur.cuda_stream
-        if key not in self._sides:
-            self._sides[key] = torch.cuda.Stream(device=self.device)
-        return self._sides[key]
 
     def _lane_streams(self, cur, k):
         lst = self._lanes.setdefault(cur.cuda_stream, [])

@@ -6,7 +6,7 @@ timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -rP --duration
 grep -E "passed|failed|error" $O/gpu_tests.log | tail -3
 grep -E "^(448x256|demo|2k_|4k_|demo2k)" $O/gpu_tests.log
 timeout 300 python bench.py --shapes $O/conv_shapes_r_448.md > $O/bench_r_448.json 2> $O/bench_r_448.err; tail -1 $O/bench_r_448.json | cut -c1-400
-for L in 1 4 8; do GVFI_RAFT_LANES=$L timeout 120 python bench.py --no-cpu-baseline --steps 10 2>/dev/null | tail -1 | cut -c1-120 > $O/bench_r_448_lanes$L.json; echo "lanes $L: $(cat $O/bench_r_448_lanes$L.json)"; done
+timeout 400 python tools/lanes_probe.py 2>&1 | grep -v amdgpu.ids > $O/lanes_probe.txt; cat $O/lanes_probe.txt
 timeout 200 python bench.py --height 1088 --width 2048 --ds 0.5 --n-interp 8 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --shapes $O/conv_shapes_r_2k.md > $O/bench_r_2k.json 2> $O/bench_r_2k.err; tail -1 $O/bench_r_2k.json | cut -c1-300
 timeout 200 python bench.py --height 2176 --width 4096 --ds 0.25 --n-interp 8 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --shapes $O/conv_shapes_r_4k.md > $O/bench_r_4k.json 2> $O/bench_r_4k.err; tail -1 $O/bench_r_4k.json | cut -c1-300
 timeout 200 python bench.py --model f --steps 5 --warmup 2 --no-cpu-baseline --shapes $O/conv_shapes_f_448.md > $O/bench_f_448.json 2> $O/bench_f_448.err; tail -1 $O/bench_f_448.json | cut -c1-200
