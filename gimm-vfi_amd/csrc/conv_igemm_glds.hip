@@ -41,7 +41,7 @@ struct ConvArgs2 {
 // 8 consecutive output channels of one pixel: bias / activation / residual / GRU gate math on 8 values
 // and ONE 16-byte store (bf16) or two (f32), fully coalesced along the channel axis.  This keeps the
 // register footprint of the epilogue tiny (no spills with 128 accumulators) and replaces 2-byte stores.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel(ConvArgs2 a) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int VE = Elem<T>::VE;
@@ -175,10 +175,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     const int fhalf = lane >> 5;
 
     int kh = 0, kw = 0, ck = 0, tap = 0;   // wave-uniform K walker of the NEXT chunk to stage
+    // The three buffer descriptors are constant for the kernel (source 0 / source 1 at the tile's reference pixel, the
+    // weights of this group); a K chunk is selected by a 32-bit byte offset in the instruction's SGPR-offset operand.
+    // (Re-building two 128-bit descriptors per chunk with 64-bit address arithmetic had been ~50 scalar instructions at
+    // the head of every chunk, in front of the first fragment read.)
+    const gvfi_i32x4 srd_a0 = make_srd(x0 + (long long)pix_ref * p.ld0);
+    const gvfi_i32x4 srd_a1 = make_srd(x1 != nullptr ? x1 + (long long)pix_ref * p.ld1 : x0);
+    const gvfi_i32x4 srd_b = make_srd(wg);
     // per-chunk uniform staging state (set by stage_begin, consumed by stage_piece)
-    gvfi_i32x4 st_srd_a = make_srd(x0), st_srd_b = make_srd(wg);
     bool st_from0 = true;
-    unsigned st_tapbit = 1u;
+    unsigned st_tapbit = 1u, st_soff_a = 0u, st_soff_b = 0u;
     const unsigned smem_lds = lds_address(smem);
     unsigned st_sa = smem_lds;
     // K order: channel chunk OUTER, filter tap INNER.  While a chunk's taps are walked, the workgroups of an XCD only
@@ -188,12 +194,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     auto stage_begin = [&](int kt) {
         st_sa = smem_lds + (kt % NSTAGE) * STAGE;
         st_from0 = ck < a.chunks0;
-        const T* xs = st_from0 ? x0 : x1;
         const int ld = st_from0 ? p.ld0 : p.ld1;
         const int cbase = (st_from0 ? ck : ck - a.chunks0) * BKE;
-        st_srd_a = make_srd(xs + ((long long)(pix_ref + kh * p.W + kw) * ld + cbase));
-        st_srd_b = make_srd(wg + (p.w_layout == 1 ? (long long)kt * p.Cout * BKE
-                                                  : (long long)(tap * a.chunks_tap + ck) * BKE));
+        st_soff_a = (unsigned)(((kh * p.W + kw) * ld + cbase) * esz);
+        st_soff_b = (unsigned)((p.w_layout == 1 ? kt * p.Cout : tap * a.chunks_tap + ck) * (BKE * esz));
         st_tapbit = 1u << tap;
         ++tap;
         if (++kw == p.KW) {
@@ -203,14 +207,17 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     };
     // one LDS-DMA instruction (1 KiB per wave): pieces [0, A_INSTR) are A rows, [A_INSTR, NPIECE) B rows
     auto stage_piece = [&](int pc) {
+        if ((a.dbg & 1) && pc < A_INSTR) return;      // profiling only: no A-tile DMA
+        if ((a.dbg & 2) && pc >= A_INSTR) return;     // profiling only: no B-tile DMA
         if (pc < A_INSTR) {
             const int i = pc;
             if (A_TOTAL % NW != 0 && (i * NW + wave) >= A_TOTAL) return;
             const unsigned off = st_from0 ? a_off0[i] : a_off1[i];
-            bufdma16((a_mask[i] & st_tapbit) ? off : GVFI_DMA_OOB, st_srd_a, st_sa + ((i * NW + wave) * RPI) * RB);
+            bufdma16((a_mask[i] & st_tapbit) ? off : GVFI_DMA_OOB, st_from0 ? srd_a0 : srd_a1, st_soff_a,
+                     st_sa + ((i * NW + wave) * RPI) * RB);
         } else if (pc < NPIECE) {
             const int i = pc - A_INSTR;
-            bufdma16(b_off[i], st_srd_b, st_sa + BM * RB + (((i * NW + wave) % B_TOTAL) * RPI) * RB);
+            bufdma16(b_off[i], srd_b, st_soff_b, st_sa + BM * RB + (((i * NW + wave) % B_TOTAL) * RPI) * RB);
         }
     };
 
@@ -295,41 +302,57 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     // per chunk, so (AHEAD-1)*NPIECE is the count to wait for.  The last AHEAD chunks are drained without prefetch.
     stamp(1);
     int kt = (a.dbg & 16) ? a.KT : 0;   // profiling only: skip the K loop
-    if constexpr (NSTAGE == 2 && KK >= 2 && NW >= 8) {
-        // ---- (8-wave tile only: with 2-3 resident 4-wave workgroups another workgroup fills the bubble and the shorter
-        // DMA slack of this schedule costs 5-10 %)  two-buffer ring, software-pipelined across chunks: the barrier that publishes chunk kt+1 sits INSIDE the
+    if constexpr (NSTAGE == 2 && KK >= 2 && PIPE) {
+        // ---- two-buffer ring, software-pipelined across chunks: the barrier that publishes chunk kt+1 sits INSIDE the
         // MFMA stream of chunk kt -- after it every wave issues the first fragment reads of chunk kt+1 and then still
         // has the last k-step of chunk kt to feed the matrix pipe, so the LDS round trip that used to follow every
-        // barrier (all 8 waves idle, ~10 % of a K step) is covered.
+        // barrier (all waves idle, ~10 % of a K step) is covered.
         //   hazards: the DMA of chunk kt+1 (into the buffer of chunk kt-1) is issued after the barrier of the previous
         //   iteration, which every wave passes only with all its reads of that buffer complete (__syncthreads waits
         //   lgkmcnt(0)); chunk kt+1 is read only after vmcnt(0) + that same barrier.
+        // The last chunk is a separate copy of the body (HAS_NEXT = false): inside the steady-state loop there is no
+        // control-flow merge between "barrier + prefetch" and "no next chunk", so hipcc's waitcnt pass does not make the
+        // last k-step wait for the fragment reads of the NEXT chunk that were issued a few instructions earlier (it did:
+        // s_waitcnt lgkmcnt(1) in front of the first MFMA after the barrier -- the round trip was back), and the DMA
+        // pieces carry no branches.
         uint4 fa[2][MI], fb[2][NI];
+        const bool no_mma = (a.dbg & 4) != 0, no_frag = (a.dbg & 32) != 0;   // profiling only
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[q][i] = zero4();
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[q][j] = zero4();
+        }
         auto load_frags = [&](const unsigned char* sa, int kk, int buf) {
+            if (no_frag) return;
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[buf][i] = *(const uint4*)(sa + a_rd[kk] + i * 32 * RB);
 #pragma unroll
             for (int j = 0; j < NI; ++j) fb[buf][j] = *(const uint4*)(sa + b_rd[kk] + j * 32 * RB);
         };
-        if (kt < a.KT) {
-            glds_wait_n<0>();
-            __syncthreads();          // chunk 0 visible
-            stamp(2);
-            load_frags(smem, 0, 0);
-        }
-        for (; kt < a.KT; ++kt) {
-            const bool has_next = kt + 1 < a.KT;
-            const unsigned char* sa = smem + (kt & 1) * STAGE;
-            if (has_next) stage_begin(kt + 1);
+        auto mma_step = [&](int kk) {
+            if (no_mma) return;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+        };
+        auto chunk = [&](int kt_, auto next_tag) {
+            constexpr bool HAS_NEXT = decltype(next_tag)::value;
+            const unsigned char* sa = smem + (kt_ & 1) * STAGE;
+            if (HAS_NEXT) stage_begin(kt_ + 1);
 #pragma unroll
             for (int kk = 0; kk + 1 < KK; ++kk) {
                 load_frags(sa, kk + 1, (kk + 1) & 1);
                 GVFI_SCHED_BARRIER();
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
+                    if (!no_mma) {
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
-                    if (has_next) {   // all DMA pieces of chunk kt+1 go out before the barrier below
+                        for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+                    }
+                    if (HAS_NEXT) {   // all DMA pieces of chunk kt+1 go out before the barrier below
                         constexpr int NSLOT = (KK - 1) * MI;
                         const int slot_id = kk * MI + i;
 #pragma unroll
@@ -339,17 +362,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                 }
                 GVFI_SCHED_BARRIER();
             }
-            if (has_next) {
+            if (HAS_NEXT) {
                 glds_wait_n<0>();
                 __syncthreads();      // chunk kt+1 visible; every wave's reads of chunk kt are complete
-                load_frags(smem + ((kt + 1) & 1) * STAGE, 0, KK & 1);
+                load_frags(smem + ((kt_ + 1) & 1) * STAGE, 0, KK & 1);
                 GVFI_SCHED_BARRIER();
             }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[(KK - 1) & 1][i], fb[(KK - 1) & 1][j]);
+            mma_step(KK - 1);
             GVFI_SCHED_BARRIER();
+        };
+        if (kt < a.KT) {
+            glds_wait_n<0>();
+            __syncthreads();          // chunk 0 visible
+            stamp(2);
+            load_frags(smem, 0, 0);
+            for (; kt + 1 < a.KT; ++kt) chunk(kt, std::true_type{});
+            chunk(kt, std::false_type{});
+            ++kt;
         }
     } else {
     for (; kt + AHEAD < a.KT; ++kt) {
@@ -675,7 +704,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE = false>
 static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     constexpr int BKE = KB / (int)sizeof(T);
     ConvArgs2 a;
@@ -693,7 +722,7 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     gvfi_magic_div((unsigned)p.Wo, a.wo_mul, a.wo_sh);
     a.dbg = (p.algo >> 8) & 0xff;   // profiling switches: algo bits 8.. (8 = no epilogue, 16 = no K loop)
     dim3 grid(a.per_xcd * 8, 1, groups);
-    GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
+    GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
     return (int)hipGetLastError();
 }
 
@@ -777,27 +806,32 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (p.stats != nullptr && !gvfi_conv2d_stats_ok(pp)) return -6;   // statistics requested but not computable here
     hipStream_t st = (hipStream_t)stream;
     const int bm = plan[1], tile = plan[2], k = plan[3];
+    // algo bit 64 (A/B switch): the chunk-pipelined K loop (barrier inside the MFMA stream) for the 4-wave tiles too
+    const bool pipe = (p.algo & 64) != 0;
+#define GLDS_PIPE_AB(TT, BM_, BN_, WM_, WN_)                                                                  \
+    return pipe ? launch_glds<TT, BM_, BN_, WM_, WN_, 128, 2, true>(p, st) : launch_glds<TT, BM_, BN_, WM_, WN_, 128, 2, false>(p, st);
 #define GLDS_DISPATCH(TT)                                                                                     \
     if (tile == 256) {                                                                                        \
         if (k == 64) return launch_glds<TT, 256, 256, 2, 4, 64, 4>(p, st);                                    \
-        return launch_glds<TT, 256, 256, 2, 4, 128, 2>(p, st);                                                \
+        return launch_glds<TT, 256, 256, 2, 4, 128, 2, true>(p, st);                                          \
     }                                                                                                         \
     if (tile == 128) {                                                                                        \
         if (k == 64) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
-        if (bm == 64) return launch_glds<TT, 64, 128, 2, 2, 128, 2>(p, st);                                   \
-        return launch_glds<TT, 128, 128, 2, 2, 128, 2>(p, st);                                                \
+        if (bm == 64) { GLDS_PIPE_AB(TT, 64, 128, 2, 2) }                                                     \
+        GLDS_PIPE_AB(TT, 128, 128, 2, 2)                                                                      \
     }                                                                                                         \
     if (tile == 64) {                                                                                         \
         if (k == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                     \
-        return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                                 \
+        GLDS_PIPE_AB(TT, 128, 64, 2, 2)                                                                       \
     }                                                                                                         \
     if (bm == 256) {                                                                                          \
         if (k == 64) return launch_glds<TT, 256, 32, 4, 1, 64, 2>(p, st);                                     \
-        return launch_glds<TT, 256, 32, 4, 1, 128, 2>(p, st);                                                 \
+        GLDS_PIPE_AB(TT, 256, 32, 4, 1)                                                                       \
     }                                                                                                         \
     if (k == 64) return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);                                         \
-    return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);
+    GLDS_PIPE_AB(TT, 128, 32, 4, 1)
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }
     GLDS_DISPATCH(bf16_t)
 #undef GLDS_DISPATCH
+#undef GLDS_PIPE_AB
 }

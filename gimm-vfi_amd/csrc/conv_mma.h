@@ -50,16 +50,19 @@ __device__ __forceinline__ gvfi_i32x4 make_srd(const void* base) {
 __device__ __forceinline__ unsigned lds_address(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p);
 }
-__device__ __forceinline__ void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned lds_addr) {
+// soff: wave-uniform byte offset added to the descriptor base (the instruction's SGPR offset operand).  The range check
+// of a raw buffer compares the per-lane offset with num_records - soff, so the out-of-range marker below still reads
+// zeros.  With it the descriptors are CONSTANT for a kernel and a K chunk only costs one 32-bit offset per operand.
+__device__ __forceinline__ void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned soff, unsigned lds_addr) {
     asm volatile(
-        // hipcc pads nothing inside an asm string: a descriptor SGPR written by the SALU just before this statement
-        // needs 5 wait states before a VMEM instruction reads it (and M0 needs 1): s_mov + s_nop 4 = 6 states.
-        "s_mov_b32 m0, %2\n\t"
+        // hipcc pads nothing inside an asm string: an SGPR written by the SALU just before this statement needs 5 wait
+        // states before a VMEM instruction reads it (and M0 needs 1): s_mov + s_nop 4 = 6 states.
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 4\n\t"
-        "buffer_load_dwordx4 %0, %1, 0 offen lds\n\t"
+        "buffer_load_dwordx4 %0, %1, %2 offen lds\n\t"
         "s_nop 0"
         :
-        : "v"(voff), "s"(srd), "s"(lds_addr)
+        : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr)
         : "memory");
 }
 #define GVFI_DMA_OOB 0xffffff00u
@@ -75,14 +78,20 @@ static inline gvfi_i32x4 make_srd(const void* base) { return gvfi_i32x4{(const u
 // host emulation: an "LDS address" is an offset from a per-thread-block base pointer registered by lds_address()
 inline thread_local unsigned char* gvfi_emu_lds_base = nullptr;
 static inline unsigned lds_address(const void* p) { gvfi_emu_lds_base = (unsigned char*)p; return 0u; }
-static inline void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned lds_addr) {
+static inline void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned soff, unsigned lds_addr) {
     static const unsigned char zeros[16] = {0};
-    emu_glds16(voff >= 0x7fffff00u ? (const void*)zeros : (const void*)(srd.base + voff), gvfi_emu_lds_base + lds_addr);
+    emu_glds16(voff >= 0x7fffff00u - soff ? (const void*)zeros : (const void*)(srd.base + soff + voff),
+               gvfi_emu_lds_base + lds_addr);
 }
 static inline void glds_wait() {}
 template <int N> static inline void glds_wait_n() {}
 #endif
 
+__device__ __forceinline__ uint4 zero4() {
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0u;
+    return z;
+}
 // instruction-scheduling fence: nothing is moved across it (keeps hand-written software pipelining in place)
 #ifndef GVFI_HOSTSIM
 #define GVFI_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)

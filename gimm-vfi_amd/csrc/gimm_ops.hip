@@ -208,147 +208,6 @@ extern "C" int gvfi_softsplat_normalize(const float* acc, int C, void* dst, int 
     return (int)hipGetLastError();
 }
 
-// ------------------------------------------------------------------ softmax-splat, owner-computes tiles (the path's kernel)
-// Same result as softsplat_accum + softsplat_normalize for C = 16 without a global accumulator.  Device-scope float
-// atomics execute at the memory side of the fabric as one 4-byte transaction each (68 per source pixel: 0.55 TB/s of
-// useful traffic, profiles/r1), so the sums are formed in LDS instead: one workgroup OWNS a 32x32 tile of target
-// pixels, scans the source pixels that can reach it -- the tile grown by D = ceil(max|flow| * tscale) + 1 pixels,
-// max|flow| being the per-sample flow scaler the path has already computed (fi_utils.py:52-57) -- and adds the corners
-// that land inside its tile with ds_add_f32 ([pixel][17] floats, odd pitch: neighbouring pixels sit in different banks).
-// The tile is then normalised ("linear-zeroeps", softsplat.py:325-344) and written once in the activation type.
-// HBM traffic: 16 channels + flow + Z in (L2 serves the window overlap), 16 channels out.  Corner weights, the
-// skip of non-finite targets and the dropped out-of-image corners are the expressions of softsplat.py:384-420.
-#define GVFI_SPLAT_TX 32
-#define GVFI_SPLAT_TY 32
-template <typename T>
-__device__ __forceinline__ void load16(const T* __restrict__ p, bool vec, float (&v)[16]) {
-    if (sizeof(T) == 2 && vec) {
-        const uint4 a = ((const uint4*)p)[0], b = ((const uint4*)p)[1];
-        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[2 * i] = bf2f((bf16_t)(w[i] & 0xffffu));
-            v[2 * i + 1] = bf2f((bf16_t)(w[i] >> 16));
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = Elem<T>::ld(p + i);
-    }
-}
-template <typename T>
-__device__ __forceinline__ void store16(T* __restrict__ p, bool vec, const float (&v)[16]) {
-    if (sizeof(T) == 2 && vec) {
-        uint32_t w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
-        uint4 a, b;
-        a.x = w[0]; a.y = w[1]; a.z = w[2]; a.w = w[3];
-        b.x = w[4]; b.y = w[5]; b.z = w[6]; b.w = w[7];
-        ((uint4*)p)[0] = a;
-        ((uint4*)p)[1] = b;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Elem<T>::st(p + i, v[i]);
-    }
-}
-template <typename T>
-__global__ void __launch_bounds__(256) softsplat_tile_kernel(const T* __restrict__ lat, int ldl,
-                                                             const float* __restrict__ flow, const float* __restrict__ z,
-                                                             const float* __restrict__ t, int one_minus_t,
-                                                             const float* __restrict__ bound, T* __restrict__ dst, int ldd,
-                                                             int H, int W, int tiles_x, int tiles_y, int vec) {
-    constexpr int C = 16, C1 = 17, TX = GVFI_SPLAT_TX, TY = GVFI_SPLAT_TY;
-    __shared__ float acc[TY * TX * C1];
-    const int tid = threadIdx.x;
-    const int bid = blockIdx.x;
-    const int txi = bid % tiles_x, tyi = (bid / tiles_x) % tiles_y;
-    const long long b = bid / (tiles_x * tiles_y);
-    const int tx0 = txi * TX, ty0 = tyi * TY;
-    for (int i = tid; i < TY * TX * C1; i += 256) acc[i] = 0.f;
-    const float ts = one_minus_t ? (1.0f - t[b]) : t[b];
-    const float m = fabsf(bound[b] * ts);
-    const int D = (m < 1.0e6f ? (int)ceilf(m) : 1000000) + 1;   // (a NaN / inf bound scans the whole image)
-    auto imax = [](int a, int b_) { return a > b_ ? a : b_; };
-    auto imin = [](int a, int b_) { return a < b_ ? a : b_; };
-    const int x_lo = imax(tx0 - D - 1, 0), x_hi = imin(tx0 + TX - 1 + D, W - 1);
-    const int y_lo = imax(ty0 - D - 1, 0), y_hi = imin(ty0 + TY - 1 + D, H - 1);
-    const int nwx = x_hi - x_lo + 1, nwy = y_hi - y_lo + 1;
-    __syncthreads();
-    const long long img = b * (long long)H * W;
-    for (int i = tid; i < nwx * nwy; i += 256) {
-        const int wy = i / nwx;
-        const int sx = x_lo + (i - wy * nwx), sy = y_lo + wy;
-        const long long pix = img + (long long)sy * W + sx;
-        const float fx = (float)sx + flow[pix * 2 + 0] * ts;
-        const float fy = (float)sy + flow[pix * 2 + 1] * ts;
-        if (!isfinite(fx) || !isfinite(fy)) continue;
-        const float x0f = floorf(fx), y0f = floorf(fy);
-        // corners (x0, x0+1) x (y0, y0+1); this tile takes those with tx0 <= x < tx0+TX (and inside the image)
-        if (!(x0f >= (float)(tx0 - 1) && x0f <= (float)(tx0 + TX - 1) && y0f >= (float)(ty0 - 1) && y0f <= (float)(ty0 + TY - 1)))
-            continue;
-        const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-        const float wnw = ((float)x1 - fx) * ((float)y1 - fy);
-        const float wne = (fx - (float)x0) * ((float)y1 - fy);
-        const float wsw = ((float)x1 - fx) * (fy - (float)y0);
-        const float wse = (fx - (float)x0) * (fy - (float)y0);
-        const bool x0in = x0 >= tx0 && x0 < W, x1in = x1 < tx0 + TX && x1 < W;      // (x0 <= tx0+TX-1, x1 >= tx0 hold)
-        const bool y0in = y0 >= ty0 && y0 < H, y1in = y1 < ty0 + TY && y1 < H;
-        const float zz = z[pix];
-        float v[C1];
-        {
-            float l[16];
-            load16<T>(lat + pix * ldl, vec != 0, l);
-#pragma unroll
-            for (int c = 0; c < C; ++c) v[c] = l[c] * zz;
-            v[C] = zz;
-        }
-        const int lx = x0 - tx0, ly = y0 - ty0;
-        float* o = acc + (ly * TX + lx) * C1;
-        if (x0in && y0in) {
-#pragma unroll
-            for (int c = 0; c < C1; ++c) atomicAdd(o + c, v[c] * wnw);
-        }
-        if (x1in && y0in) {
-#pragma unroll
-            for (int c = 0; c < C1; ++c) atomicAdd(o + C1 + c, v[c] * wne);
-        }
-        if (x0in && y1in) {
-#pragma unroll
-            for (int c = 0; c < C1; ++c) atomicAdd(o + TX * C1 + c, v[c] * wsw);
-        }
-        if (x1in && y1in) {
-#pragma unroll
-            for (int c = 0; c < C1; ++c) atomicAdd(o + (TX + 1) * C1 + c, v[c] * wse);
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < TY * TX; i += 256) {
-        const int ly = i / TX, lx = i - ly * TX;
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= W || y >= H) continue;
-        const float* a = acc + i * C1;
-        float nrm = a[C];
-        if (nrm == 0.0f) nrm = 1.0f;
-        float r[16];
-#pragma unroll
-        for (int c = 0; c < C; ++c) r[c] = a[c] / nrm;
-        store16<T>(dst + (img + (long long)y * W + x) * ldd, vec != 0, r);
-    }
-}
-extern "C" int gvfi_softsplat_tile(const void* lat, int ldl, const float* flow, const float* z, const float* t,
-                                   int one_minus_t, const float* bound, void* dst, int ldd, int B, int H, int W,
-                                   int dtype, void* stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || bound == nullptr) return -2;
-    const int tiles_x = cdiv(W, GVFI_SPLAT_TX), tiles_y = cdiv(H, GVFI_SPLAT_TY);
-    const int esz = dtype == GVFI_F32 ? 4 : 2;
-    const int vec = ((((uintptr_t)lat) | ((uintptr_t)dst)) & 15) == 0 && ((ldl * esz) & 15) == 0 && ((ldd * esz) & 15) == 0;
-    dim3 grid((unsigned)((long long)tiles_x * tiles_y * B));
-    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((softsplat_tile_kernel<T>), grid, dim3(256), (hipStream_t)stream,
-                                            (const T*)lat, ldl, flow, z, t, one_minus_t, bound, (T*)dst, ldd, H, W,
-                                            tiles_x, tiles_y, vec));
-    return (int)hipGetLastError();
-}
-
 // ------------------------------------------------------------------ the reference's native op, same contract
 // softsplat_func.forward / kernel `softsplat_out` (modules/softsplat.py:358-446): tenIn (N,C,H,W) f32, tenFlow (N,2,H,W)
 // f32, tenOut (N,C,H,W) f32 ZERO-INITIALISED BY THE CALLER, accumulated with float atomics.  One thread per (n, y, x);

@@ -417,19 +417,20 @@ class Engine:
         rt.conv(Ls["cnn_encoder.7"], e[B:], View(latcat, 16, 16))
         return z0, z1, latcat
 
-    def _motion_inr(self, latcat, f01, f10, z0, z1, bound, cg, tv, B, H, W, taps=None, tag=""):
+    def _motion_inr(self, latcat, f01, f10, z0, z1, cg, tv, B, H, W, taps=None, tag=""):
         """One timestep: softmax-splat both latents to t, refine, evaluate the hypo-network on the coordinate grid
         cg [B,1,Hc,Wc,3] (gimmvfi_r.py:171-205 == gimm.py:147-179).  Returns the normalised flow [B,Hc,Wc,2] f32."""
         rt, Ls, lib, st = self.rt, self.layers, self.rt.lib, self.rt.stream
         HW = H * W
         Hc, Wc = cg.shape[2], cg.shape[3]
         # softmax splatting of the two latents to time t   gimmvfi_r.py:171-193
-        # one pass per direction: 32x32 target tiles summed in LDS, normalised and written once (csrc/gimm_ops.hip);
-        # `bound` = per-sample max |flow| limits the source window a tile has to scan
         for d, (fl, zz) in enumerate(((f01, z0), (f10, z1))):
-            rt._chk(lib.softsplat_tile(View(latcat, 16 * d, 16).ptr, latcat.shape[-1], fl.data_ptr(), zz.data_ptr(),
-                                       tv.data_ptr(), d, bound.data_ptr(), View(latcat, 32 + 16 * d, 16).ptr,
-                                       latcat.shape[-1], B, H, W, rt.dtype, st()), "softsplat_tile")
+            acc = rt.f32(B, H, W, 17, zero=True)
+            rt._chk(lib.softsplat_accum(View(latcat, 16 * d, 16).ptr, latcat.shape[-1], 16, fl.data_ptr(),
+                                        zz.data_ptr(), tv.data_ptr(), d, acc.data_ptr(), B, H, W, rt.dtype, st()),
+                    "softsplat_accum")
+            rt._chk(lib.softsplat_normalize(acc.data_ptr(), 16, View(latcat, 32 + 16 * d, 16).ptr,
+                                            latcat.shape[-1], B * HW, rt.dtype, st()), "softsplat_normalize")
         r0 = rt.act(B, H, W, 32)
         rt.conv(Ls["res_conv.0"], latcat, r0)
         r1 = rt.act(B, H, W, 64)
@@ -478,8 +479,6 @@ class Engine:
         nfA[:B, ..., :2] = xs[:, :, 0].permute(0, 2, 3, 1).to(nfA.dtype)
         nfA[B:, ..., :2] = xs[:, :, 1].permute(0, 2, 3, 1).to(nfA.dtype)
         z0, z1, latcat = self._motion_encode(nfA, f01, f10, B, H, W)
-        bound = rt.f32(B, zero=True)     # max |flow| per sample: the splat's source-window bound
-        rt._chk(rt.lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), bound.data_ptr(), B, H * W, rt.stream()), "flow_absmax")
         single = not isinstance(timesteps, list)
         if single:
             coord, timesteps = [coord], [timesteps]
@@ -490,7 +489,7 @@ class Engine:
             tv = cur_t.to(device=rt.device, dtype=torch.float32).reshape(-1).contiguous()
             if tv.numel() == 1 and B > 1:
                 tv = tv.expand(B).contiguous()     # gimm.py:184 broadcasts a scalar time over the batch
-            ninr = self._motion_inr(latcat, f01, f10, z0, z1, bound, cg, tv, B, H, W)
+            ninr = self._motion_inr(latcat, f01, f10, z0, z1, cg, tv, B, H, W)
             outs.append(rt.nhwc_to_nchw(ninr, 2).unsqueeze(2))   # (B,2,1,H',W')
         return outs[0] if single else outs
 
@@ -546,7 +545,7 @@ class Engine:
             tv = cur_t.to(device=rt.device, dtype=torch.float32).reshape(-1).contiguous()
             assert cg.shape[0] == B and cg.shape[1] == 1 and cg.shape[-1] == 3 and tv.numel() == B
             Hc, Wc = cg.shape[2], cg.shape[3]
-            ninr = self._motion_inr(latcat, f01, f10, z0, z1, scaler, cg, tv, B, H, W, taps, f"t{i}_")
+            ninr = self._motion_inr(latcat, f01, f10, z0, z1, cg, tv, B, H, W, taps, f"t{i}_")
             flow_t = rt.f32(B, Hc, Wc, 2)
             ninr_nchw = rt.f32(B, 2, 1, Hc, Wc)
             rt._chk(lib.flow_unnormalize(ninr.data_ptr(), scaler.data_ptr(), flow_t.data_ptr(), ninr_nchw.data_ptr(),

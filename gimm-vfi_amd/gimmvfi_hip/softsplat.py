@@ -10,7 +10,7 @@ Same public names and contracts:
 * ``softsplat(tenIn, tenFlow, tenMetric, strMode, return_norm=False)`` (softsplat.py:286-352): every mode of the
   reference ("sum", "avg", "linear[-addeps|-zeroeps|-clipeps]", "softmax[-...]"), the same asserts, the same NaN guards.
 
-The GIMM-VFI forward itself does not go through this module (its splat is fused: ``gvfi_softsplat_tile``); this is the
+The GIMM-VFI forward itself does not go through this module (it splats NHWC latents with ``gvfi_softsplat_accum`` / ``_normalize``); this is the
 boundary for callers that use the reference's op directly.
 """
 import torch

@@ -165,12 +165,6 @@ int gvfi_splat_weights(const float* f01, const float* f10, const float* gfilt9, 
 int gvfi_softsplat_accum(const void* lat, int ldl, int C, const float* flow, const float* z, const float* t,
                          int one_minus_t, float* acc, int B, int H, int W, int dtype, void* stream);
 int gvfi_softsplat_normalize(const float* acc, int C, void* dst, int ldd, long long npix, int dtype, void* stream);
-/* The two calls above in one pass for C = 16, no global accumulator (softsplat.py:286-352 "linear-zeroeps" +
- * 371-421): dst[B,H,W,0:16] (activation type, pitch ldd) = splat(lat*Z) / splat(Z) by flow*tscale[b], zero
- * denominators -> 1.  bound[b] >= max |flow| of sample b (the path's flow scaler, fi_utils.py:52-57): every workgroup
- * owns a 32x32 tile of targets, sums in LDS and scans only the sources within ceil(bound*tscale)+1 pixels of it. */
-int gvfi_softsplat_tile(const void* lat, int ldl, const float* flow, const float* z, const float* t, int one_minus_t,
-                        const float* bound, void* dst, int ldd, int B, int H, int W, int dtype, void* stream);
 /* The reference's native op with its own contract -- softsplat_func.forward / CuPy kernel `softsplat_out`
  * (modules/softsplat.py:358-446): tenIn (N,C,H,W) f32, tenFlow (N,2,H,W) f32, tenOut (N,C,H,W) f32 that the CALLER has
  * zero-initialised (softsplat.py:362-364), accumulated with float atomics on `stream`. */

@@ -351,56 +351,6 @@ def splat_case(rt, B=2, H=12, W=20, C=16):
         o = out.float().cpu().permute(0, 3, 1, 2)
         assert torch.isfinite(o).all()
         assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max()))
-        if C == 16:
-            # the path's one-pass kernel (32x32 owner tiles in LDS): same reference, result inside a wider buffer
-            bound = rt.f32(B, zero=True)
-            rt._chk(rt.lib.flow_absmax(fd.data_ptr(), fd.data_ptr(), bound.data_ptr(), B, H * W, rt.stream()), "flow_absmax")
-            wide = rt.act(B, H, W, 48, zero=True)
-            wide[..., :16] = la[..., :16]
-            rt._chk(rt.lib.softsplat_tile(View(wide, 0, 16).ptr, 48, fd.data_ptr(), zd.data_ptr(), td.data_ptr(), omt,
-                                          bound.data_ptr(), View(wide, 32, 16).ptr, 48, B, H, W, rt.dtype, rt.stream()),
-                    "softsplat_tile")
-            o2 = wide[..., 32:48].float().cpu().permute(0, 3, 1, 2)
-            assert torch.isfinite(o2).all()
-            assert float((o2 - ref).abs().max()) <= tol(rt, float(ref.abs().max()))
-            assert float(wide[..., 16:32].float().abs().max()) == 0.0      # nothing outside the destination slice
-            # a bound that is merely >= max|flow| (looser) gives the same sums up to the summation order
-            bound.fill_(float(torch.nan_to_num(flow, nan=0.0, posinf=0.0, neginf=0.0).abs().max()) * 1.7 + 3.0)
-            if not torch.isfinite(flow).all():
-                bound.fill_(float("inf"))
-            rt._chk(rt.lib.softsplat_tile(View(wide, 0, 16).ptr, 48, fd.data_ptr(), zd.data_ptr(), td.data_ptr(), omt,
-                                          bound.data_ptr(), View(wide, 32, 16).ptr, 48, B, H, W, rt.dtype, rt.stream()),
-                    "softsplat_tile")
-            o3 = wide[..., 32:48].float().cpu().permute(0, 3, 1, 2)
-            assert float((o3 - ref).abs().max()) <= tol(rt, float(ref.abs().max()))
-
-
-def splat_tile_case(rt, B=2, H=70, W=100, scale=6.0, seed=11):
-    """Owner-tile splat on a grid of several (partial) 32x32 tiles with smooth + rough motion of a few pixels:
-    every corner must be claimed by exactly one tile."""
-    g = torch.Generator().manual_seed(seed)
-    dev = _dev(rt)
-    C = 16
-    lat = _rounded(rt, torch.randn(B, C, H, W, generator=g))
-    low = torch.randn(B, 2, max(H // 8, 2), max(W // 8, 2), generator=g) * scale
-    flow = F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False) + torch.randn(B, 2, H, W, generator=g)
-    z = torch.rand(B, 1, H, W, generator=g) + 0.5
-    t = torch.rand(B, generator=g)
-    la = _to_act(rt, lat).to(dev)
-    fd = flow.permute(0, 2, 3, 1).contiguous().to(dev)
-    zd = z.reshape(B, H, W).contiguous().to(dev)
-    td = t.to(dev)
-    bound = rt.f32(B, zero=True)
-    rt._chk(rt.lib.flow_absmax(fd.data_ptr(), fd.data_ptr(), bound.data_ptr(), B, H * W, rt.stream()), "flow_absmax")
-    for omt in (0, 1):
-        ts = (1 - t) if omt else t
-        ref = orc.softsplat_linear_zeroeps(lat, flow * ts.view(-1, 1, 1, 1), z)
-        out = rt.act(B, H, W, C)
-        rt._chk(rt.lib.softsplat_tile(la.data_ptr(), la.shape[-1], fd.data_ptr(), zd.data_ptr(), td.data_ptr(), omt,
-                                      bound.data_ptr(), out.data_ptr(), out.shape[-1], B, H, W, rt.dtype, rt.stream()),
-                "softsplat_tile")
-        o = out.float().cpu().permute(0, 3, 1, 2)
-        assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max()))
 
 
 def splat_nchw_case(rt, N=2, C=5, H=13, W=21):

@@ -124,11 +124,6 @@ def test_softsplat_edge_cases(rt):
     kc.splat_case(rt, B=2, H=64, W=96)
 
 
-def test_softsplat_owner_tiles(rt):
-    kc.splat_tile_case(rt)
-    kc.splat_tile_case(rt, B=3, H=256, W=448, scale=12.0, seed=13)     # benchmark-size grid, motion up to ~40 px
-
-
 def test_softsplat_native_op_contract(rt):
     kc.splat_nchw_case(rt)
 

@@ -120,10 +120,6 @@ def test_softsplat_edge_cases(rt):
     kc.splat_case(rt)
 
 
-def test_softsplat_owner_tiles(rt):
-    kc.splat_tile_case(rt)
-
-
 def test_softsplat_native_op_contract(rt):
     kc.splat_nchw_case(rt)
 
