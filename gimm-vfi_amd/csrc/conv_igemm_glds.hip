@@ -30,7 +30,7 @@ struct ConvArgs2 {
     int Mg;          // output pixels per weight group
     int MT, NT;      // tiles
     int per_xcd;     // ceil(MT*NT / 8)
-    int dbg;         // ablation switches for profiling (algo >> 4): 1 = no A DMA, 2 = no B DMA, 4 = no MFMA
+    int dbg;         // profiling switches (algo >> 8): 8 = no epilogue, 16 = no K loop, 128 = s_memtime stamps
     long long Ktot;  // weight row length in elements
     unsigned howo_mul, howo_sh, wo_mul, wo_sh;   // magic numbers: x / d == (umulhi(x, mul) + x) >> sh  for x < 2^31
 };
@@ -41,7 +41,7 @@ struct ConvArgs2 {
 // 8 consecutive output channels of one pixel: bias / activation / residual / GRU gate math on 8 values
 // and ONE 16-byte store (bf16) or two (f32), fully coalesced along the channel axis.  This keeps the
 // register footprint of the epilogue tiny (no spills with 128 accumulators) and replaces 2-byte stores.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE, int PPS = 1>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel(ConvArgs2 a) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int VE = Elem<T>::VE;
@@ -207,8 +207,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     };
     // one LDS-DMA instruction (1 KiB per wave): pieces [0, A_INSTR) are A rows, [A_INSTR, NPIECE) B rows
     auto stage_piece = [&](int pc) {
-        if ((a.dbg & 1) && pc < A_INSTR) return;      // profiling only: no A-tile DMA
-        if ((a.dbg & 2) && pc >= A_INSTR) return;     // profiling only: no B-tile DMA
         if (pc < A_INSTR) {
             const int i = pc;
             if (A_TOTAL % NW != 0 && (i * NW + wave) >= A_TOTAL) return;
@@ -316,23 +314,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         // s_waitcnt lgkmcnt(1) in front of the first MFMA after the barrier -- the round trip was back), and the DMA
         // pieces carry no branches.
         uint4 fa[2][MI], fb[2][NI];
-        const bool no_mma = (a.dbg & 4) != 0, no_frag = (a.dbg & 32) != 0;   // profiling only
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) fa[q][i] = zero4();
-#pragma unroll
-            for (int j = 0; j < NI; ++j) fb[q][j] = zero4();
-        }
         auto load_frags = [&](const unsigned char* sa, int kk, int buf) {
-            if (no_frag) return;
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[buf][i] = *(const uint4*)(sa + a_rd[kk] + i * 32 * RB);
 #pragma unroll
             for (int j = 0; j < NI; ++j) fb[buf][j] = *(const uint4*)(sa + b_rd[kk] + j * 32 * RB);
         };
         auto mma_step = [&](int kk) {
-            if (no_mma) return;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -348,16 +336,20 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                 GVFI_SCHED_BARRIER();
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    if (!no_mma) {
 #pragma unroll
-                        for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
-                    }
-                    if (HAS_NEXT) {   // all DMA pieces of chunk kt+1 go out before the barrier below
+                    for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+                    if (HAS_NEXT) {   // all DMA pieces of chunk kt+1 go out before the barrier below, PPS per MFMA group
+                        // (PPS > 1 front-loads them: the issue -> landed time of a piece, ~1 us under load, is about one
+                        // chunk of MFMAs, so every cycle a piece leaves earlier comes off the wait at the barrier:
+                        // 4 per group measured -5 % on the hot layer against 1 per group, same box.  A 4-deep ring of
+                        // 64-byte chunks with chunk-major weights -- DMA issued two chunks ahead -- measured between the
+                        // two and was removed: with the wait gone the loop still takes ~62 us per tile at any shader
+                        // clock from 1.5 to 1.9 GHz, i.e. it is bound on the L2 -> LDS delivery side)
                         constexpr int NSLOT = (KK - 1) * MI;
                         const int slot_id = kk * MI + i;
 #pragma unroll
                         for (int pc = 0; pc < NPIECE; ++pc)
-                            if (pc % NSLOT == slot_id) stage_piece(pc);
+                            if ((PPS > 1 ? pc / PPS : pc % NSLOT) == slot_id) stage_piece(pc);
                     }
                 }
                 GVFI_SCHED_BARRIER();
@@ -704,7 +696,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE = false, int PPS = 1>
 static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     constexpr int BKE = KB / (int)sizeof(T);
     ConvArgs2 a;
@@ -722,7 +714,7 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     gvfi_magic_div((unsigned)p.Wo, a.wo_mul, a.wo_sh);
     a.dbg = (p.algo >> 8) & 0xff;   // profiling switches: algo bits 8.. (8 = no epilogue, 16 = no K loop)
     dim3 grid(a.per_xcd * 8, 1, groups);
-    GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
+    GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE, PPS>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
     return (int)hipGetLastError();
 }
 
@@ -813,7 +805,8 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
 #define GLDS_DISPATCH(TT)                                                                                     \
     if (tile == 256) {                                                                                        \
         if (k == 64) return launch_glds<TT, 256, 256, 2, 4, 64, 4>(p, st);                                    \
-        return launch_glds<TT, 256, 256, 2, 4, 128, 2, true>(p, st);                                          \
+        if (p.algo & 32) return launch_glds<TT, 256, 256, 2, 4, 128, 2, true, 1>(p, st);                      \
+        return launch_glds<TT, 256, 256, 2, 4, 128, 2, true, 4>(p, st);                                       \
     }                                                                                                         \
     if (tile == 128) {                                                                                        \
         if (k == 64) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \

@@ -87,11 +87,6 @@ static inline void glds_wait() {}
 template <int N> static inline void glds_wait_n() {}
 #endif
 
-__device__ __forceinline__ uint4 zero4() {
-    uint4 z;
-    z.x = z.y = z.z = z.w = 0u;
-    return z;
-}
 // instruction-scheduling fence: nothing is moved across it (keeps hand-written software pipelining in place)
 #ifndef GVFI_HOSTSIM
 #define GVFI_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)

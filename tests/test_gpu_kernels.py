@@ -36,6 +36,9 @@ CONV_SHAPES = [
     (1, 17, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
     (1, 17, 19, 64, 256, 3, 3, dict(tile=256, act1=L.ACT_PRELU)),   # 8-wave tile, bf16-staged activation epilogue
     (1, 9, 19, 64, 256, 1, 1, dict(tile=256, act1=L.ACT_LRELU, out_scale=0.5)),  # 8-wave tile, ragged
+    # the 8-wave tile with its DMA pieces spread over the MFMA groups (algo bit 5; the default issues 4 per group)
+    (1, 17, 19, 64, 256, 3, 3, dict(tile=256, algo=2 + 32, act1=L.ACT_PRELU, bf16_only=True)),
+    (4, 128, 224, 256, 256, 3, 3, dict(algo=2 + 32, split=192, bf16_only=True)),
     (4, 128, 224, 256, 256, 3, 3, dict(act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),   # auto -> 256x256 tile
     (4, 128, 224, 256, 256, 3, 3, dict(split=192, tile=128)),                                # same, 128-wide tile
     (2, 64, 112, 128, 128, 3, 3, dict(algo=1, act1=L.ACT_LRELU)),                             # generic kernel on an aligned shape
@@ -61,6 +64,9 @@ CONV_SHAPES = [
 @pytest.mark.parametrize("shape", CONV_SHAPES)
 def test_conv(rt, shape):
     *a, kw = shape
+    kw = dict(kw)
+    if kw.pop("bf16_only", False) and rt.precision != "bf16":
+        pytest.skip("bf16-only kernel path")
     kc.conv_case(rt, *a, **kw)
     torch.cuda.synchronize()
 

@@ -33,6 +33,8 @@ CONV_SHAPES = [
     # (bf16_only: these paths only exist for bf16; the fp32 emulation of a 256x256 tile costs ~20 s each)
     (1, 17, 19, 64, 256, 3, 3, dict(tile=256, act1=L.ACT_PRELU, bf16_only=True)),   # 8-wave tile, bf16-staged activation epilogue
     (1, 9, 19, 64, 256, 1, 1, dict(tile=256, act1=L.ACT_LRELU, out_scale=0.5, bf16_only=True)),  # 8-wave 256x256 tile
+    # the 8-wave tile with its DMA pieces spread over the MFMA groups (algo bit 5; the default issues 4 per group)
+    (1, 17, 19, 64, 256, 3, 3, dict(tile=256, algo=2 + 32, act1=L.ACT_PRELU, bf16_only=True)),
     (1, 9, 11, 128, 24, 3, 3, dict(out_f32=True)),        # Cout <= 32 on the LDS-DMA kernel (128x32 tile)
     (2, 6, 7, 64, 2, 3, 3, dict(out_f32=True, with_res=True)),
     # selectable LDS-DMA variants: 64-row tiles, 64-byte chunks with the 4-deep ring (counted vmcnt), tall 256-row tiles

@@ -51,13 +51,14 @@ def main():
         flops = 2.0 * N * H * W * Cout * Cin * KH * KW
         res = {}
         outs = {}
-        variants = ((1, 0), (2, 128), (2, 256), (2 + 128, 128), (2 + 128, 256))
+        # (2, 256) = 2 x 128-byte stages, DMA pieces front-loaded; +32 = pieces spread over the MFMA groups; +128 = 4 x 64-byte stages
+        variants = ((2, 0), (2, 256), (2 + 32, 256), (2 + 128, 256))
         if os.environ.get("ABLATE0"):   # prologue / K loop / epilogue split on the auto tile
             variants = tuple((2 + 256 * m, 0) for m in (0, 8, 16, 24, 32))
         if os.environ.get("ONLY256"):     # single variant for PMC passes
             variants = ((2, 256),)
         if os.environ.get("ABLATE"):
-            variants = tuple((2 + 256 * m, 256) for m in (0, 0, 64, 8, 16, 24, 32)) + tuple((2 + 256 * m, 128 | (128 << 10)) for m in (0, 8, 16, 24))
+            variants = tuple((2 + 256 * m, 256) for m in (0, 0, 8, 16, 24))
         for algo, tile in variants:
             if (tile & 1023) == 256 and Cout < 192:
                 continue
