@@ -301,7 +301,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     stamp(1);
     int kt = (a.dbg & 16) ? a.KT : 0;   // profiling only: skip the K loop
     if constexpr (NSTAGE == 2 && KK >= 2 && PIPE) {
-        // ---- two-buffer ring, software-pipelined across chunks: the barrier that publishes chunk kt+1 sits INSIDE the
+        // ---- (8-wave tile only: with 2-3 resident 4-wave workgroups another workgroup fills the bubble and the shorter
+        // DMA slack of this schedule costs 5-10 %, re-measured in round 2 with the peeled loop: 4-wave tiles stay on the
+        // plain loop below)  two-buffer ring, software-pipelined across chunks: the barrier that publishes chunk kt+1 sits INSIDE the
         // MFMA stream of chunk kt -- after it every wave issues the first fragment reads of chunk kt+1 and then still
         // has the last k-step of chunk kt to feed the matrix pipe, so the LDS round trip that used to follow every
         // barrier (all waves idle, ~10 % of a K step) is covered.
@@ -798,10 +800,6 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (p.stats != nullptr && !gvfi_conv2d_stats_ok(pp)) return -6;   // statistics requested but not computable here
     hipStream_t st = (hipStream_t)stream;
     const int bm = plan[1], tile = plan[2], k = plan[3];
-    // algo bit 64 (A/B switch): the chunk-pipelined K loop (barrier inside the MFMA stream) for the 4-wave tiles too
-    const bool pipe = (p.algo & 64) != 0;
-#define GLDS_PIPE_AB(TT, BM_, BN_, WM_, WN_)                                                                  \
-    return pipe ? launch_glds<TT, BM_, BN_, WM_, WN_, 128, 2, true>(p, st) : launch_glds<TT, BM_, BN_, WM_, WN_, 128, 2, false>(p, st);
 #define GLDS_DISPATCH(TT)                                                                                     \
     if (tile == 256) {                                                                                        \
         if (k == 64) return launch_glds<TT, 256, 256, 2, 4, 64, 4>(p, st);                                    \
@@ -810,21 +808,20 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     }                                                                                                         \
     if (tile == 128) {                                                                                        \
         if (k == 64) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
-        if (bm == 64) { GLDS_PIPE_AB(TT, 64, 128, 2, 2) }                                                     \
-        GLDS_PIPE_AB(TT, 128, 128, 2, 2)                                                                      \
+        if (bm == 64) return launch_glds<TT, 64, 128, 2, 2, 128, 2>(p, st);                                   \
+        return launch_glds<TT, 128, 128, 2, 2, 128, 2>(p, st);                                                \
     }                                                                                                         \
     if (tile == 64) {                                                                                         \
         if (k == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                     \
-        GLDS_PIPE_AB(TT, 128, 64, 2, 2)                                                                       \
+        return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                                 \
     }                                                                                                         \
     if (bm == 256) {                                                                                          \
         if (k == 64) return launch_glds<TT, 256, 32, 4, 1, 64, 2>(p, st);                                     \
-        GLDS_PIPE_AB(TT, 256, 32, 4, 1)                                                                       \
+        return launch_glds<TT, 256, 32, 4, 1, 128, 2>(p, st);                                                 \
     }                                                                                                         \
     if (k == 64) return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);                                         \
-    GLDS_PIPE_AB(TT, 128, 32, 4, 1)
+    return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }
     GLDS_DISPATCH(bf16_t)
 #undef GLDS_DISPATCH
-#undef GLDS_PIPE_AB
 }
