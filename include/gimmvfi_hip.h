@@ -82,8 +82,8 @@ typedef struct {
                                          * channel_chunk * KH*KW + tap (the kernel walks the taps innermost)   */
     int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32);   *
-                                         * bit 5 / 7: A/B switches (DMA issue spread out,         *
-                                         * pipelined loop on 4-wave tiles, 64-byte K chunks), 8..: *
+                                         * bit 5 / 7: A/B switches (8-wave tile: DMA issue spread *
+                                         * over the MFMA groups; 64-byte K chunks), bits 8..:      *
                                          * profiling switches (skip phases, s_memtime stamps)     */
 } gvfi_conv_params;
 
