@@ -730,9 +730,10 @@ class Engine:
         rt._chk(lib.combine_warps(i0f.data_ptr(), i1f.data_ptr(), dec.data_ptr(), 24, cw.data_ptr(), cw.shape[-1],
                                   cw.shape[-1], mean4.data_ptr(), B, Hf, Wf, rt.dtype, st()), "combine_warps")
         cb = rt.act(B, Hf, Wf, 18, zero=True)
-        rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU)
+        # (pad16: cb's channels 18..23 and o4's / mean4's channel 3 are padding owned here -> whole 16-byte stores)
+        rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU, pad16=True)
         o4 = rt.f32(B, Hf, Wf, 4)
-        rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3))
+        rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3), pad16=True)
         pred = rt.f32(B, 3, Hf, Wf)
         rt._chk(lib.finalize_image(o4.data_ptr(), 4, pred.data_ptr(), B, Hf, Wf, st()), "finalize_image")
         f01 = rt.nhwc_to_nchw(View(dec, 0, 6), 6).reshape(B, 3, 2, Hf, Wf)

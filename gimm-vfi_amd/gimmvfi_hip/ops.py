@@ -242,7 +242,7 @@ class Runtime:
     # ------------------------------------------------------------------ convolution
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None):
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False):
         """stats: optional zero-initialised f32 [N, cout, 2]; when the library can fuse the InstanceNorm statistics
         into this convolution (gvfi_conv2d_stats_ok) they are accumulated there and True is returned in
         ``self.last_stats_fused``, else the caller computes them with instnorm_stats."""
@@ -307,6 +307,14 @@ class Runtime:
         if aux1 is not None:
             aux1 = V(aux1)
             p.aux1, p.lda1 = aux1.ptr, aux1.ld
+        if pad16:
+            # the caller owns the pad channels of `out` (and `res`) up to the next 16-byte boundary: check that they exist
+            unit = 4 if out.is_f32 else 8
+            assert out.coff % unit == 0 and out.coff + roundup(p.Cout, unit) <= out.ld
+            if res is not None:
+                ru = 4 if res.is_f32 else 8
+                assert res.coff % ru == 0 and res.coff + roundup(p.Cout, ru) <= res.ld
+            algo |= 16
         p.tile_hint = tile
         p.algo = algo
         p.stats = None
@@ -330,7 +338,7 @@ class Runtime:
             self._chk(self.lib.conv2d_plan(C.byref(p), plan), "conv2d_plan")   # the library says which kernel it ran
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
-            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel"}[plan[0]]
+            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel"}[plan[0]]
             tag = f"{kname}<{'float' if self.dtype == L.F32 else 'bf16'},{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"

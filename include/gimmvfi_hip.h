@@ -81,7 +81,12 @@ typedef struct {
                                          * contiguous copy (K chunk = 128 bytes).  Chunk index =               *
                                          * channel_chunk * KH*KW + tap (the kernel walks the taps innermost)   */
     int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
-                                         * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32);   *
+                                         * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32),   *
+                                         * 3 = patch kernel (few channels, see gvfi_conv2d_patch); *
+                                         * bit 4 "pad16": the caller owns the channel padding of   *
+                                         * y and res up to the next 16-byte boundary -- a ragged   *
+                                         * last channel group may be accessed in whole 16-byte     *
+                                         * units, y's pad channels receive zeros (patch kernel);   *
                                          * bit 5 / 7: A/B switches (8-wave tile: DMA issue spread *
                                          * over the MFMA groups; 64-byte K chunks), bits 8..:      *
                                          * profiling switches (skip phases, s_memtime stamps)     */
@@ -97,6 +102,15 @@ int gvfi_conv2d_stats_ok(const gvfi_conv_params* p);
 /* the two kernels behind gvfi_conv2d (exposed for A/B measurements) */
 int gvfi_conv2d_glds_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
+/* "Patch" convolution (csrc/conv_patch.hip) for few-channel layers at full resolution that the LDS-DMA kernel cannot
+ * take: one source of <= 64 bf16 / 32 f32 channels (multiple of a 16-byte group), <= 64 output channels, filters up to
+ * 7x7, stride 1 or 2, zero or reflect padding, standard epilogue -- the combination block of multi_flow_combine
+ * (gimmvfi_r.py:60-64,305-308), the encoder stems (raft/extractor.py:137), the reflect-padded motion-encoder layers
+ * (gimmvfi_r.py:84-109).  The 8 x 64-pixel output block's input halo and all weights are staged once in LDS.
+ * gvfi_conv2d routes here by itself (gvfi_conv2d_patch_eligible == 1 and the LDS-DMA kernel not eligible) or with
+ * algo = 3. */
+int gvfi_conv2d_patch_eligible(const gvfi_conv_params* p);
+int gvfi_conv2d_patch(const gvfi_conv_params* p, void* stream);
 
 /* ---- input preparation (gimmvfi_r.py:230-231,329-337,349; raft/raft.py:111-112) ------ */
 /* bilinear resize of float planes, align_corners=False, rscale = (float)(1.0/scale_factor)

@@ -34,7 +34,7 @@ def tol(rt, scale):
 
 
 def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.ACT_NONE, with_res=False,
-              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0, pad=None):
+              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0, pad=None, pad16=False):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
@@ -60,9 +60,28 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     if with_res:
         r = _rounded(rt, torch.randn(N, Cout, Ho, Wo, generator=g))
         res = _to_act(rt, r).to(dev)
-    out = (rt.f32(N, Ho, Wo, Cout + 3, zero=True) if out_f32 else rt.act(N, Ho, Wo, Cout + 3, zero=True))
-    rt.conv(lay, x0, View(out, 2, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
-            slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile, algo=algo)
+    if pad16:
+        # the destination is a tensor of its own whose pad channels (up to the next 16-byte unit) belong to this call:
+        # they are pre-filled with garbage and must come back as zeros; nothing beyond them may be touched
+        unit = 4 if out_f32 else rt.VE if rt.precision == "bf16" else 4
+        cpad = (Cout + unit - 1) // unit * unit
+        out = (rt.f32(N, Ho, Wo, cpad + unit) if out_f32 else rt.act(N, Ho, Wo, cpad + unit, zero=False, pitch=cpad + unit))
+        out.fill_(7.0)
+        if res is not None:
+            ru = 4 if res.dtype == torch.float32 else 8
+            rp = torch.full((N, Ho, Wo, (Cout + ru - 1) // ru * ru), float("nan"), dtype=res.dtype, device=res.device)
+            rp[..., :Cout] = res[..., :Cout]
+            res = rp
+        rt.conv(lay, x0, View(out, 0, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
+                slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile, algo=algo, pad16=True)
+        got = out.float().cpu()
+        assert float(got[..., Cout:cpad].abs().max()) == 0.0 if cpad > Cout else True
+        assert float((got[..., cpad:] - 7.0).abs().max()) == 0.0
+        out = torch.cat([torch.zeros(N, Ho, Wo, 2), got[..., :Cout], torch.zeros(N, Ho, Wo, 1)], -1)
+    else:
+        out = (rt.f32(N, Ho, Wo, Cout + 3, zero=True) if out_f32 else rt.act(N, Ho, Wo, Cout + 3, zero=True))
+        rt.conv(lay, x0, View(out, 2, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
+                slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile, algo=algo)
     xi = F.pad(x, (pw, pw, ph, ph), mode="reflect") if reflect else x
     ref = F.conv2d(xi, w, b, stride=stride, padding=0 if reflect else (ph, pw))
 

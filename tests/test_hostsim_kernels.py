@@ -44,6 +44,17 @@ CONV_SHAPES = [
     (1, 9, 12, 96, 40, 3, 3, dict(act1=L.ACT_LRELU)),
     (1, 18, 20, 32, 32, 3, 3, dict(tile=32 | (256 << 10), act1=L.ACT_LRELU, with_res=True)),
     (1, 18, 20, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),
+    # patch kernel (conv_patch.hip): few channels, halo patch + all weights in LDS; 8 x 64-pixel output blocks, ragged
+    # tiles, 16-byte channel groups that are not a power of two per tap, odd step counts, stride 2, reflect padding
+    (1, 10, 70, 9, 18, 7, 7, dict(algo=3, act1=L.ACT_PRELU)),
+    (1, 9, 40, 18, 3, 7, 7, dict(algo=3, out_f32=True, with_res=True, bf16_only=True)),   # (f32: 178 KB of LDS)
+    (2, 20, 70, 3, 64, 7, 7, dict(algo=3, stride=2, act1=L.ACT_RELU)),
+    (1, 12, 66, 32, 16, 3, 3, dict(algo=3, reflect=True, with_res=True, act2=L.ACT_LRELU)),
+    (1, 9, 33, 64, 32, 3, 3, dict(algo=3, reflect=True, bf16_only=True)),
+    (1, 11, 65, 8, 32, 5, 5, dict(algo=3, act1=L.ACT_PRELU)),
+    (1, 9, 64, 2, 16, 3, 3, dict(algo=3)),
+    (1, 10, 70, 9, 18, 7, 7, dict(algo=3, act1=L.ACT_PRELU, pad16=True)),                     # whole 16-byte stores incl. pad channels
+    (1, 9, 40, 18, 3, 7, 7, dict(algo=3, out_f32=True, with_res=True, pad16=True, bf16_only=True)),
     # FlowFormer (GIMM-VFI-F): patch / sub-sampling convolutions with stride == kernel and no padding, the 6x6 stride-2
     # cost-map convolutions, GELU epilogues on both kernels, token-matrix linears ([1,1,rows,C])
     (2, 16, 24, 3, 128, 4, 4, dict(stride=4, pad=0)),

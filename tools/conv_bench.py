@@ -28,6 +28,12 @@ SHAPES = [
     ("final.up 32->64 3x3 @256x448 B16", 16, 256, 448, 32, 64, 3, 3, None),
     ("final.head 256->24 3x3 @256x448 B8", 8, 256, 448, 256, 24, 3, 3, None),
     ("raft fh2 256->2 3x3 @32x56 B16", 16, 32, 56, 256, 2, 3, 3, None),
+    # few-channel layers at full resolution (generic kernel = algo 1, patch kernel = algo 3)
+    ("comb0 9->18 7x7 @4K", 1, 2176, 4096, 9, 18, 7, 7, None),
+    ("comb2 18->3 7x7 @4K", 1, 2176, 4096, 18, 3, 7, 7, None),
+    ("comb0 9->18 7x7 @256x448 B8", 8, 256, 448, 9, 18, 7, 7, None),
+    ("stem 3->64 7x7 s2 @256x448 B16", 16, 256, 448, 3, 64, 7, 7, None),
+    ("dec.up 8->32 5x5 @256x448 B16", 16, 256, 448, 8, 32, 5, 5, None),
 ]
 
 
@@ -39,20 +45,24 @@ def main():
         if only is not None and only not in name:
             continue
         w = torch.randn(Cout, Cin, KH, KW) / (Cin * KH * KW) ** 0.5
-        lay = ConvLayer(rt, w, torch.randn(Cout))
-        x = torch.randn(N, H, W, Cin, device="cuda").to(rt.tdtype)
+        stride = 2 if " s2 " in name else 1
+        lay = ConvLayer(rt, w, torch.randn(Cout), stride=stride)
+        x = torch.zeros(N, H, W, rt.cp(Cin), device="cuda", dtype=rt.tdtype)
+        x[..., :Cin] = torch.randn(N, H, W, Cin, device="cuda").to(rt.tdtype)
         if split is None:
             x0, x1 = View(x, 0, Cin), None
         else:
             xa = x[..., :split].contiguous()
             xb = x[..., split:].contiguous()
             x0, x1 = View(xa, 0, split), View(xb, 0, Cin - split)
-        out = rt.act(N, H, W, Cout)
-        flops = 2.0 * N * H * W * Cout * Cin * KH * KW
+        out = rt.act(N, H // stride, W // stride, Cout)
+        flops = 2.0 * N * (H // stride) * (W // stride) * Cout * Cin * KH * KW
         res = {}
         outs = {}
         # (2, 256) = 2 x 128-byte stages, DMA pieces front-loaded; +32 = pieces spread over the MFMA groups; +128 = 4 x 64-byte stages
         variants = ((2, 0), (2, 256), (2 + 32, 256), (2 + 128, 256))
+        if Cin < 32:
+            variants = ((1, 0), (3, 0))
         if os.environ.get("ABLATE0"):   # prologue / K loop / epilogue split on the auto tile
             variants = tuple((2 + 256 * m, 0) for m in (0, 8, 16, 24, 32))
         if os.environ.get("ONLY256"):     # single variant for PMC passes
@@ -65,8 +75,9 @@ def main():
             if (tile & 1023) == 128 and Cout <= 64:
                 tile = 0
             try:
+                kw = dict(pad16=True) if (algo == 3 and os.environ.get("PAD16")) else {}
                 for _ in range(2):
-                    rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
+                    rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile, **kw)
             except RuntimeError:
                 continue
             torch.cuda.synchronize()
@@ -74,7 +85,7 @@ def main():
             reps = 5
             e0.record()
             for _ in range(reps):
-                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
+                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile, **kw)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
