@@ -96,6 +96,24 @@ __host__ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i;
 }
 
+// torch upsample_bilinear2d source index, align_corners=False (ATen UpSample.h
+// area_pixel_compute_source_index + guard_index_and_lambda)
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp src_index(int d, float rscale, int n) {
+    float s = rscale * (d + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    int i0 = (int)s;
+    if (i0 > n - 1) i0 = n - 1;
+    Lerp r;
+    r.i0 = i0;
+    r.i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    float l1 = s - (float)i0;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    r.w1 = l1;
+    r.w0 = 1.f - l1;
+    return r;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // unsigned division by an invariant divisor d (1 <= d < 2^31) for dividends x < 2^31:
 //   x / d == (umulhi(x, mul) + x) >> sh     (Granlund-Montgomery round-up method, 33-bit magic minus 2^32)

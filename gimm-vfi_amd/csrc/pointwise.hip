@@ -6,24 +6,6 @@
 #define GVFI_BLOCK 256
 static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK - 1) / GVFI_BLOCK)); }
 
-// torch upsample_bilinear2d source index, align_corners=False (ATen UpSample.h
-// area_pixel_compute_source_index + guard_index_and_lambda)
-struct Lerp { int i0, i1; float w0, w1; };
-__device__ __forceinline__ Lerp src_index(int d, float rscale, int n) {
-    float s = rscale * (d + 0.5f) - 0.5f;
-    if (s < 0.f) s = 0.f;
-    int i0 = (int)s;
-    if (i0 > n - 1) i0 = n - 1;
-    Lerp r;
-    r.i0 = i0;
-    r.i1 = i0 + (i0 < n - 1 ? 1 : 0);
-    float l1 = s - (float)i0;
-    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
-    r.w1 = l1;
-    r.w0 = 1.f - l1;
-    return r;
-}
-
 // ------------------------------------------------------------------ resize of float planes
 __global__ void resize_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, long long total, int H,
                                      int W, int Ho, int Wo, float rscale) {

@@ -132,6 +132,98 @@ extern "C" int gvfi_combine_warps(const float* img4_0, const float* img4_1, cons
     return (int)hipGetLastError();
 }
 
+// The same front half reading the decoder output at the WORKING resolution (DS_SCALE < 1, gimmvfi_r.py:294-303): the
+// bilinear up-sampling of the 24 decoder channels (flows additionally x Hf/H), the six warps, the blends, and the
+// planar (B,3,2,Hf,Wf) copies of the up-sampled flows that the reference returns as flowt0_pred / flowt1_pred -- one
+// pass, nothing materialised at full resolution except what leaves the function.  At 4K the separate passes (two
+// resizes writing + combine_warps re-reading an 855 MB tensor, two NHWC -> NCHW transposes re-reading it again) were
+// ~4.6 ms of the 19 ms per timestep.  Per-channel arithmetic is that of resize_nhwc_kernel (mul * (ly.w0*(lx.w0*v00 +
+// lx.w1*v01) + ly.w1*(lx.w0*v10 + lx.w1*v11))) followed by that of combine_warps_kernel, so the results are bit-equal to
+// the separate passes; with H == Hf (rscale = inv = 1) the interpolation weights are exactly (1, 0).
+template <typename T>
+__global__ void combine_warps_up_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
+                                        const float* __restrict__ dec, int ldd, int H, int W, float rscale, float inv,
+                                        T* __restrict__ act, int lda, int pad, float* __restrict__ mean4,
+                                        float* __restrict__ f0p, float* __restrict__ f1p, long long total, int Hf, int Wf) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long HWf = (long long)Hf * Wf;
+    const long long pix = idx % HWf, b = idx / HWf;
+    const int x = (int)(pix % Wf), y = (int)(pix / Wf);
+    const Lerp ly = src_index(y, rscale, H), lx = src_index(x, rscale, W);
+    const float* p00 = dec + ((b * H + ly.i0) * (long long)W + lx.i0) * ldd;
+    const float* p01 = dec + ((b * H + ly.i0) * (long long)W + lx.i1) * ldd;
+    const float* p10 = dec + ((b * H + ly.i1) * (long long)W + lx.i0) * ldd;
+    const float* p11 = dec + ((b * H + ly.i1) * (long long)W + lx.i1) * ldd;
+    float d[24];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float4 a00 = *(const float4*)(p00 + 4 * q), a01 = *(const float4*)(p01 + 4 * q);
+        const float4 a10 = *(const float4*)(p10 + 4 * q), a11 = *(const float4*)(p11 + 4 * q);
+        const float m = q < 3 ? inv : 1.0f;
+        d[4 * q + 0] = m * (ly.w0 * (lx.w0 * a00.x + lx.w1 * a01.x) + ly.w1 * (lx.w0 * a10.x + lx.w1 * a11.x));
+        d[4 * q + 1] = m * (ly.w0 * (lx.w0 * a00.y + lx.w1 * a01.y) + ly.w1 * (lx.w0 * a10.y + lx.w1 * a11.y));
+        d[4 * q + 2] = m * (ly.w0 * (lx.w0 * a00.z + lx.w1 * a01.z) + ly.w1 * (lx.w0 * a10.z + lx.w1 * a11.z));
+        d[4 * q + 3] = m * (ly.w0 * (lx.w0 * a00.w + lx.w1 * a01.w) + ly.w1 * (lx.w0 * a10.w + lx.w1 * a11.w));
+    }
+    float mean[3] = {0.f, 0.f, 0.f};
+    float v9[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float w0[3], w1[3];
+        sample_border_rgb(i0 + b * HWf * 4, Hf, Wf, (float)x + d[2 * k], (float)y + d[2 * k + 1], w0);
+        sample_border_rgb(i1 + b * HWf * 4, Hf, Wf, (float)x + d[6 + 2 * k], (float)y + d[6 + 2 * k + 1], w1);
+        const float m = d[12 + k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = m * w0[c] + (1.f - m) * w1[c] + d[15 + 3 * k + c];
+            mean[c] += v;
+            v9[3 * k + c] = v;
+        }
+    }
+    T* a = act + idx * lda;
+    if (sizeof(T) == 2 && pad == 16 && ((((uintptr_t)act) | (uintptr_t)(lda * 2)) & 15) == 0) {   // two 16-byte stores
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float lo = 2 * i < 9 ? v9[2 * i < 9 ? 2 * i : 0] : 0.f, hi = 2 * i + 1 < 9 ? v9[2 * i + 1 < 9 ? 2 * i + 1 : 0] : 0.f;
+            w[i] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        }
+        uint4 u0, u1;
+        u0.x = w[0]; u0.y = w[1]; u0.z = w[2]; u0.w = w[3];
+        u1.x = w[4]; u1.y = w[5]; u1.z = w[6]; u1.w = w[7];
+        ((uint4*)a)[0] = u0;
+        ((uint4*)a)[1] = u1;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Elem<T>::st(a + c, v9[c]);
+        for (int c = 9; c < pad; ++c) Elem<T>::st(a + c, 0.f);
+    }
+    *(float4*)(mean4 + idx * 4) = make_float4(mean[0] / 3.0f, mean[1] / 3.0f, mean[2] / 3.0f, 0.f);
+    // planar flows: channel k*2 + c of (B, 3, 2, Hf, Wf)
+    if (f0p != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) f0p[(b * 6 + c) * HWf + pix] = d[c];
+    }
+    if (f1p != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) f1p[(b * 6 + c) * HWf + pix] = d[6 + c];
+    }
+}
+extern "C" int gvfi_combine_warps_up(const float* img4_0, const float* img4_1, const float* dec, int ldd, int H, int W,
+                                     void* act, int lda, int pad, float* mean4, float* flow0_planar, float* flow1_planar,
+                                     int B, int Hf, int Wf, int dtype, void* stream) {
+    if (H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0 || (ldd & 3) || (((uintptr_t)dec | (uintptr_t)mean4) & 15)) return -2;
+    if ((long long)Hf * W != (long long)H * Wf) return -3;       // one isotropic scale
+    const float inv = (float)((double)Hf / (double)H);           // torch: scale_factor = 1 / ds_factor, flows x the same
+    const float rscale = (float)(1.0 / ((double)Hf / (double)H));
+    const long long total = (long long)B * Hf * Wf;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((combine_warps_up_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, img4_0, img4_1, dec, ldd, H, W, rscale, inv, (T*)act,
+                                              lda, pad, mean4, flow0_planar, flow1_planar, total, Hf, Wf));
+    return (int)hipGetLastError();
+}
+
 // decoder head     modules/fi_components.py:331-340
 __global__ void decoder_head_kernel(float* __restrict__ dec, int ldd, const float* __restrict__ flow0,
                                     const float* __restrict__ flow1, const float* __restrict__ mask, long long total) {

@@ -715,20 +715,17 @@ class Engine:
             taps[tag + "final_flow0_1"] = dec[..., 0:6].clone()
             taps[tag + "final_mask"] = dec[..., 12:15].clone()
             taps[tag + "final_res"] = dec[..., 15:24].clone()
-        i0f, i1f = img4[:B], img4[B:]
-        if img4_full is not None:
-            # gimmvfi_r.py:294-303
-            inv = Hf / H
-            decf = rt.f32(B, Hf, Wf, 24)
-            rt.resize(View(dec, 0, 12), 12, inv, mul=inv, out=View(decf, 0, 12))
-            rt.resize(View(dec, 12, 12), 12, inv, out=View(decf, 12, 12))
-            dec = decf
-            i0f, i1f = img4_full[:B], img4_full[B:]
-        # ---- multi_flow_combine + comb_block  fi_components.py:57-94, gimmvfi_r.py:305-308
+        # ---- multi_flow_combine + comb_block  fi_components.py:57-94, gimmvfi_r.py:294-308.  With DS_SCALE < 1 the decoder
+        # output lives at the working resolution: its bilinear up-sampling (flows x Hf/H), the six warps + blends and the
+        # planar copies of the up-sampled flows for the return dict are one pass over the full-resolution pixels
+        i0f, i1f = (img4[:B], img4[B:]) if img4_full is None else (img4_full[:B], img4_full[B:])
         cw = rt.act(B, Hf, Wf, 9, zero=False)
         mean4 = rt.f32(B, Hf, Wf, 4)
-        rt._chk(lib.combine_warps(i0f.data_ptr(), i1f.data_ptr(), dec.data_ptr(), 24, cw.data_ptr(), cw.shape[-1],
-                                  cw.shape[-1], mean4.data_ptr(), B, Hf, Wf, rt.dtype, st()), "combine_warps")
+        f01 = rt.f32(B, 3, 2, Hf, Wf)
+        f11 = rt.f32(B, 3, 2, Hf, Wf)
+        rt._chk(lib.combine_warps_up(i0f.data_ptr(), i1f.data_ptr(), dec.data_ptr(), 24, H, W, cw.data_ptr(), cw.shape[-1],
+                                     cw.shape[-1], mean4.data_ptr(), f01.data_ptr(), f11.data_ptr(), B, Hf, Wf, rt.dtype,
+                                     st()), "combine_warps_up")
         cb = rt.act(B, Hf, Wf, 18, zero=True)
         # (pad16: cb's channels 18..23 and o4's / mean4's channel 3 are padding owned here -> whole 16-byte stores)
         rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU, pad16=True)
@@ -736,8 +733,6 @@ class Engine:
         rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3), pad16=True)
         pred = rt.f32(B, 3, Hf, Wf)
         rt._chk(lib.finalize_image(o4.data_ptr(), 4, pred.data_ptr(), B, Hf, Wf, st()), "finalize_image")
-        f01 = rt.nhwc_to_nchw(View(dec, 0, 6), 6).reshape(B, 3, 2, Hf, Wf)
-        f11 = rt.nhwc_to_nchw(View(dec, 6, 6), 6).reshape(B, 3, 2, Hf, Wf)
         f04 = rt.nhwc_to_nchw(View(st4, 0, 2), 2)
         f14 = rt.nhwc_to_nchw(View(st4, 2, 2), 2)
         return pred, [f01, f04], [f11, f14], others

@@ -278,6 +278,13 @@ int gvfi_warp_blend(const float* img4_0, const float* img4_1, const float* f0, c
  * dec = final decoder output float [B,H,W,24] = [flow0(6) flow1(6) mask(3, post-sigmoid) res(9)] */
 int gvfi_combine_warps(const float* img4_0, const float* img4_1, const float* dec, int ldd, void* act, int lda,
                        int pad, float* mean4, int B, int H, int W, int dtype, void* stream);
+/* the same with the decoder output given at the working resolution [B,H,W,24] (DS_SCALE < 1, gimmvfi_r.py:294-303):
+ * bilinear up-sampling to (Hf,Wf) (align_corners=False; flows x Hf/H) fused in, plus the planar (B,3,2,Hf,Wf) float
+ * copies of the up-sampled flows that forward() returns as flowt0_pred[0] / flowt1_pred[0] (NULL = not wanted).
+ * H == Hf is allowed (plain multi_flow_combine + the planar flows). */
+int gvfi_combine_warps_up(const float* img4_0, const float* img4_1, const float* dec, int ldd, int H, int W, void* act,
+                          int lda, int pad, float* mean4, float* flow0_planar, float* flow1_planar, int B, int Hf,
+                          int Wf, int dtype, void* stream);
 /* final decoder head fix-up (fi_components.py:331-340): dec[.,0:6]+=flow0 x3, [6:12]+=flow1 x3,
  * [12:15] = sigmoid(dec + mask) ; flows float [.,2], mask float [.,1] */
 int gvfi_decoder_head(float* dec, int ldd, const float* flow0, const float* flow1, const float* mask,

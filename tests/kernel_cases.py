@@ -390,6 +390,56 @@ def splat_nchw_case(rt, N=2, C=5, H=13, W=21):
     assert float((out.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
 
 
+def combine_warps_up_case(rt, B=2, H=12, W=20, scale=2):
+    """gvfi_combine_warps_up (up-sampling of the decoder output + multi_flow_combine front half + planar flows in one
+    pass) against the separate passes it replaces, bit for bit, and those against torch (fi_components.py:57-88,
+    gimmvfi_r.py:294-303)."""
+    g = torch.Generator().manual_seed(21 + scale)
+    dev = _dev(rt)
+    Hf, Wf = H * scale, W * scale
+    dec = torch.randn(B, H, W, 24, generator=g)
+    dec[..., :12] *= 3.0
+    dec[..., 12:15] = torch.sigmoid(dec[..., 12:15])
+    i0 = torch.zeros(B, Hf, Wf, 4)
+    i1 = torch.zeros(B, Hf, Wf, 4)
+    i0[..., :3] = torch.rand(B, Hf, Wf, 3, generator=g) * 2 - 1
+    i1[..., :3] = torch.rand(B, Hf, Wf, 3, generator=g) * 2 - 1
+    dec_d, i0d, i1d = dec.to(dev), i0.to(dev), i1.to(dev)
+    # separate passes
+    if scale != 1:
+        decf = rt.f32(B, Hf, Wf, 24)
+        rt.resize(View(dec_d, 0, 12), 12, float(scale), mul=float(scale), out=View(decf, 0, 12))
+        rt.resize(View(dec_d, 12, 12), 12, float(scale), out=View(decf, 12, 12))
+    else:
+        decf = dec_d
+    cw = rt.act(B, Hf, Wf, 9, zero=False)
+    mean4 = rt.f32(B, Hf, Wf, 4)
+    rt._chk(rt.lib.combine_warps(i0d.data_ptr(), i1d.data_ptr(), decf.data_ptr(), 24, cw.data_ptr(), cw.shape[-1],
+                                 cw.shape[-1], mean4.data_ptr(), B, Hf, Wf, rt.dtype, rt.stream()), "combine_warps")
+    f0 = rt.nhwc_to_nchw(View(decf, 0, 6), 6)
+    f1 = rt.nhwc_to_nchw(View(decf, 6, 6), 6)
+    # fused
+    cw2 = rt.act(B, Hf, Wf, 9, zero=False)
+    cw2.fill_(3.0)
+    mean42 = rt.f32(B, Hf, Wf, 4)
+    f02, f12 = rt.f32(B, 3, 2, Hf, Wf), rt.f32(B, 3, 2, Hf, Wf)
+    rt._chk(rt.lib.combine_warps_up(i0d.data_ptr(), i1d.data_ptr(), dec_d.data_ptr(), 24, H, W, cw2.data_ptr(),
+                                    cw2.shape[-1], cw2.shape[-1], mean42.data_ptr(), f02.data_ptr(), f12.data_ptr(), B,
+                                    Hf, Wf, rt.dtype, rt.stream()), "combine_warps_up")
+    assert torch.equal(cw2.cpu(), cw.cpu())
+    assert torch.equal(mean42.cpu(), mean4.cpu())
+    assert torch.equal(f02.cpu().reshape(B, 6, Hf, Wf), f0.cpu())
+    assert torch.equal(f12.cpu().reshape(B, 6, Hf, Wf), f1.cpu())
+    # torch statement of the up-sampled flows (the warps are covered by the end-to-end goldens)
+    d = dec.permute(0, 3, 1, 2)
+    if scale != 1:
+        up = F.interpolate(d[:, :12], scale_factor=float(scale), mode="bilinear", align_corners=False) * scale
+    else:
+        up = d[:, :12]
+    assert float((f02.cpu().reshape(B, 6, Hf, Wf) - up[:, :6]).abs().max()) <= 1e-4
+    assert float((f12.cpu().reshape(B, 6, Hf, Wf) - up[:, 6:12]).abs().max()) <= 1e-4
+
+
 def splat_weights_and_norm_case(rt, sd, B=2, H=16, W=20):
     g = torch.Generator().manual_seed(6)
     dev = _dev(rt)

@@ -146,6 +146,11 @@ def test_softsplat_edge_cases(rt):
     kc.splat_case(rt, B=2, H=64, W=96)
 
 
+def test_combine_warps_up_equals_separate_passes(rt):
+    for scale in (1, 2, 4):
+        kc.combine_warps_up_case(rt, scale=scale)
+
+
 def test_softsplat_native_op_contract(rt):
     kc.splat_nchw_case(rt)
 
