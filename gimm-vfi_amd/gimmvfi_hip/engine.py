@@ -262,15 +262,33 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ RAFT (both directions batched)
-    def _raft(self, imgA, B, iters, taps):
+    @staticmethod
+    def _seq_index(B, device):
+        """Image i of the [frame0 of pair 0..B-1 | frame1 of pair 0..B-1] layout as an index into the B+1 distinct frames
+        of B consecutive pairs (pair b = frames b, b+1)."""
+        return torch.cat([torch.arange(B, device=device), torch.arange(1, B + 1, device=device)])
+
+    def _raft(self, imgA, B, iters, taps, seq=False):
         rt, Ls = self.rt, self.layers
         n = 2 * B
         H, W = imgA.shape[1:3]
         fe = "flow_estimator"
-        f128, _, (h8, w8) = self._enc(imgA, fe + ".fnet", "instance", n)
-        fmap = rt.act(n, h8, w8, 256)
-        rt.conv(Ls[fe + ".fnet.conv2"], f128, fmap)
-        c128, cfeats, _ = self._enc(imgA, fe + ".cnet", "batch", n)
+        if seq and B > 1:
+            # consecutive pairs share frames (SURVEY 8e): both encoders are per image (InstanceNorm / folded BatchNorm),
+            # so they run on the B+1 distinct frames and the 2B-image layout is an index gather of their outputs
+            imgU = torch.cat([imgA[:B], imgA[n - 1:n]], 0)
+            idx = self._seq_index(B, imgA.device)
+            f128, _, (h8, w8) = self._enc(imgU, fe + ".fnet", "instance", B + 1)
+            fmapU = rt.act(B + 1, h8, w8, 256)
+            rt.conv(Ls[fe + ".fnet.conv2"], f128, fmapU)
+            fmap = fmapU[idx]
+            c128, cfeats, _ = self._enc(imgU, fe + ".cnet", "batch", B + 1)
+            c128, cfeats = c128[idx], [f[idx] for f in cfeats]
+        else:
+            f128, _, (h8, w8) = self._enc(imgA, fe + ".fnet", "instance", n)
+            fmap = rt.act(n, h8, w8, 256)
+            rt.conv(Ls[fe + ".fnet.conv2"], f128, fmap)
+            c128, cfeats, _ = self._enc(imgA, fe + ".cnet", "batch", n)
         hA = rt.act(n, h8, w8, 128)
         hB = rt.act(n, h8, w8, 128)
         xbuf = rt.act(n, h8, w8, 256)     # [inp(128) | motion(126) | flow(2)]  raft/update.py:143-144
@@ -496,7 +514,9 @@ class Engine:
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     @_on_device
-    def forward(self, img_xs, coord, t, iters=20, ds_factor=None, taps=None, want_aux=True):
+    def forward(self, img_xs, coord, t, iters=20, ds_factor=None, taps=None, want_aux=True, seq=False):
+        """seq: the B pairs of img_xs are consecutive pairs of one frame sequence (img_xs[b, :, 1] IS img_xs[b+1, :, 0]):
+        per-frame encoder work is done once per distinct frame.  Same outputs."""
         rt, Ls, lib = self.rt, self.layers, self.rt.lib
         st = rt.stream
         assert isinstance(t, list) and isinstance(coord, list) and len(t) == len(coord)
@@ -514,7 +534,7 @@ class Engine:
         HW = H * W
 
         # ---- cal_bidirection_flow (gimmvfi_r.py:126-156)
-        f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps)
+        f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps, seq)
         h4, w4 = H // 4, W // 4
         scaler = rt.f32(B, zero=True)
         rt._chk(lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), B, HW, st()), "flow_absmax")
@@ -564,14 +584,14 @@ class Engine:
         out["nflow"] = nflow
         return out
 
-    def _flow(self, imgA, B, iters, taps):
+    def _flow(self, imgA, B, iters, taps, seq=False):
         """Bidirectional flow + what frame synthesis needs from the flow estimator (gimmvfi_r.py:126-141): flows
         [B,H,W,2] f32 of both directions, the two correlation pyramids of BidirCorrBlock, context features at 1/4
         (128 ch) and 1/8 (256 ch) for both frames."""
         rt, Ls = self.rt, self.layers
         n = 2 * B
         H, W = imgA.shape[1:3]
-        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps)
+        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps, seq)
         f01, f10 = flow_up[:B], flow_up[B:]
         h4, w4 = H // 4, W // 4
         g = rt.act(n, h8, w8, 256)

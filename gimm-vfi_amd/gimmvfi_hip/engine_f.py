@@ -396,7 +396,7 @@ class EngineF(Engine):
         return mem
 
     # ------------------------------------------------------------------ FlowFormer (both directions batched)
-    def _flowformer(self, imgA, B, iters, taps):
+    def _flowformer(self, imgA, B, iters, taps, seq=False):
         rt, Ls = self.rt, self.layers
         self._grids = {}
         n = 2 * B
@@ -405,10 +405,17 @@ class EngineF(Engine):
         P8 = h8 * w8
         fe = "flow_estimator"
         md = fe + ".memory_decoder"
-        cfeat = self._twins(imgA, fe + ".context_encoder")
+        if seq and B > 1:
+            # consecutive pairs: both Twins encoders are per image, so they run on the B+1 distinct frames (Engine._raft)
+            imgU = torch.cat([imgA[:B], imgA[n - 1:n]], 0)
+            idx = self._seq_index(B, imgA.device)
+            cfeat = [f[idx] for f in self._twins(imgU, fe + ".context_encoder")]
+            ff = self._twins(imgU, fe + ".memory_encoder.feat_encoder")[1][idx]
+        else:
+            cfeat = self._twins(imgA, fe + ".context_encoder")
+            ff = self._twins(imgA, fe + ".memory_encoder.feat_encoder")[1]
         context = cfeat[1]                                          # [n,h8,w8,256]
         ctx_rows = context.view(n * P8, 256)
-        ff = self._twins(imgA, fe + ".memory_encoder.feat_encoder")[1]
         fmap = rt.act(n, h8, w8, 256)
         rt.conv(Ls[fe + ".memory_encoder.channel_convertor"], ff, fmap)
         # all-pairs cost volume of both directions (encoder.py:489-506; no 1/sqrt(d)): image i against its partner
@@ -535,9 +542,9 @@ class EngineF(Engine):
         flow_up = rt.convex_upsample(coords, mask)
         return flow_up, fmap, cfeat, (h8, w8)
 
-    def _flow(self, imgA, B, iters, taps):
+    def _flow(self, imgA, B, iters, taps, seq=False):
         """gimmvfi_f.py:114-139: FlowFormer both ways, BidirCorrBlock on its (converted) features, context features
         of the Twins context encoder at 1/4 and 1/8 -- no projections in this model."""
-        flow_up, fmap, cfeat, (h8, w8) = self._flowformer(imgA, B, iters, taps)
+        flow_up, fmap, cfeat, (h8, w8) = self._flowformer(imgA, B, iters, taps, seq)
         pyr, pyrT = self._bidir_pyramids(fmap, B, h8, w8)
         return flow_up[:B], flow_up[B:], pyr, pyrT, cfeat[0], cfeat[1], (h8, w8)

@@ -142,16 +142,16 @@ class GIMMVFI_R(nn.Module):
         return self._engine
 
     # ---- reference API -------------------------------------------------------------------
-    def forward(self, img_xs, coord=None, t=None, iters=None, ds_factor=None):
+    def forward(self, img_xs, coord=None, t=None, iters=None, ds_factor=None, _seq=False):
         assert isinstance(t, list)
         assert isinstance(coord, list)
         assert len(t) == len(coord)
         iters = self._iters()
         eng = self.engine(img_xs.device)
         if not (self.use_graph and img_xs.is_cuda and eng.rt.ev_log is None):
-            return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
+            return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor, seq=_seq)
         try:
-            return self._forward_graph(eng, img_xs, coord, t, iters, ds_factor)
+            return self._forward_graph(eng, img_xs, coord, t, iters, ds_factor, _seq)
         except RuntimeError as e:
             # capture can fail for reasons outside this package (another capture in progress, allocator limits);
             # the eager launch list is the same kernels -- never a different arithmetic path
@@ -163,17 +163,26 @@ class GIMMVFI_R(nn.Module):
             self.use_graph = False
             self._graphs = {}
             torch.cuda.synchronize(img_xs.device)
-            return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor)
+            return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor, seq=_seq)
+
+    def forward_sequence(self, frames, coord=None, t=None, ds_factor=None):
+        """Addition to the reference API for video: `frames` (B+1, 3, H, W) are consecutive frames; returns what
+        forward() returns for the B adjacent pairs (frames[b], frames[b+1]) as one batch, with the per-frame encoder work
+        (RAFT fnet / cnet, Twins) done once per frame instead of once per pair end (src/video_Nx.py feeds every interior
+        frame to the reference twice)."""
+        assert frames.dim() == 4 and frames.shape[0] >= 2
+        img_xs = torch.stack([frames[:-1], frames[1:]], dim=2)
+        return GIMMVFI_R.forward(self, img_xs, coord=coord, t=t, ds_factor=ds_factor, _seq=True)
 
     def _iters(self):
         return self.raft_iter  # gimmvfi_r.py:127-132 hard-codes 20
 
-    def _forward_graph(self, eng, img_xs, coord, t, iters, ds_factor):
+    def _forward_graph(self, eng, img_xs, coord, t, iters, ds_factor, seq=False):
         """Capture once per input signature, then replay; inputs are copied into the graph's static buffers and
         the outputs are returned as fresh tensors (clones), like the eager path."""
         for c in coord:
             assert isinstance(c, tuple) and c[1] is None, "sub-sampled coordinates are a training feature"
-        key = (tuple(img_xs.shape), str(img_xs.device), tuple(tuple(c[0].shape) for c in coord), len(t), ds_factor)
+        key = (tuple(img_xs.shape), str(img_xs.device), tuple(tuple(c[0].shape) for c in coord), len(t), ds_factor, seq)
         ent = self._graphs.get(key)
         if ent is None and len(self._graphs) >= self.max_graphs:
             self._graphs.pop(next(iter(self._graphs)))     # oldest signature: its private memory pool is released
@@ -187,12 +196,12 @@ class GIMMVFI_R(nn.Module):
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(cur)
             with torch.cuda.stream(side):   # warm-up outside capture (one-time attribute / allocator work)
-                eng.forward(sx, coords, st, iters=iters, ds_factor=ds_factor)
+                eng.forward(sx, coords, st, iters=iters, ds_factor=ds_factor, seq=seq)
             cur.wait_stream(side)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = eng.forward(sx, coords, st, iters=iters, ds_factor=ds_factor)
+                out = eng.forward(sx, coords, st, iters=iters, ds_factor=ds_factor, seq=seq)
             ent = (g, sx, sc, st, out)
             self._graphs[key] = ent
         g, sx, sc, st, out = ent
@@ -259,8 +268,8 @@ class GIMMVFI_F(GIMMVFI_R):
     def _iters(self):
         return None   # decoder_depth = 32 (flowformer/configs/submission.py:52, decoder.py:289-290)
 
-    def forward(self, img_xs, coord=None, t=None, ds_factor=None):
-        return super().forward(img_xs, coord=coord, t=t, iters=None, ds_factor=ds_factor)
+    def forward(self, img_xs, coord=None, t=None, ds_factor=None, _seq=False):
+        return super().forward(img_xs, coord=coord, t=t, iters=None, ds_factor=ds_factor, _seq=_seq)
 
 
 class GIMM(nn.Module):

@@ -5,8 +5,10 @@
 writes OUT/output.mp4 (side-by-side [original | interpolated], fps 2N) and OUT/flow.mp4 (colour-coded
 flow_t).  Differences: runs on the MI355X HIP kernels (no CuPy / CUDA), and under
 ``python -m torch.distributed.run --nproc-per-node G`` the frame pairs are sharded over G GPUs with one
-RCCL gather of the uint8 result frames to rank 0; frame decode / upload and result download / colour-coding run in a
-host pipeline beside the GPU (gimmvfi_hip/io_pipeline.py).  Without OpenCV the frames are written as PNGs
+RCCL gather of the device-resident uint8 result frames to rank 0 (flow pictures are written by the rank that computed
+them); every rank runs `--batch` consecutive pairs per forward and encodes each frame once (model.forward_sequence);
+frame decode / upload and result download / colour-coding run in a host pipeline beside the GPU
+(gimmvfi_hip/io_pipeline.py).  Without OpenCV the frames are written as PNGs
 (OUT/output_frames, OUT/flow_frames) and encoded with ffmpeg when it is on PATH.
 ``--random-init`` (addition) runs with seeded random weights when no checkpoint is available."""
 import argparse
@@ -14,6 +16,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 import numpy as np
 import torch
@@ -53,6 +56,7 @@ def default_parser():
     parser.add_argument("--eval", action="store_true")
     parser.add_argument("--random-init", action="store_true", help="seeded random weights instead of a checkpoint")
     parser.add_argument("--precision", type=str, default=None, choices=[None, "bf16", "fp32"])
+    parser.add_argument("--batch", type=int, default=0, help="consecutive frame pairs per forward (0 = by frame size)")
     return parser
 
 
@@ -132,62 +136,87 @@ def main(argv=None):
     # uploaded on a side stream; results come back asynchronously and are colour-coded in a consumer thread
     first = load_image(os.path.join(args.source_path, img_list[0]))
     padder = InputPadder(first.shape, 32)
+    H0, W0 = first.shape[-2:]
     paths = [os.path.join(args.source_path, f) for f in img_list]
-    frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image)
+    # pairs per forward: consecutive pairs of this rank's contiguous range run as ONE batch whose per-frame encoder work
+    # is shared (model.forward_sequence); the default keeps ~1 Mpixel of frames per forward
+    bsz = args.batch if args.batch > 0 else max(1, min(8, (1 << 20) // max(1, H0 * W0)))
+    frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image, lookahead=bsz + 3)
     drain = ResultDrain(device)
+    rt = model.engine(device).rt
+    flow_dir = os.path.join(args.output_path, "flow_parts")     # per-rank flow pictures, assembled by rank 0
+    os.makedirs(flow_dir, exist_ok=True)
 
-    def post(pred_u8, flow_f):
-        # pred_u8: [N-1, H, W, 3] uint8 RGB (truncated x255, reference video_Nx.py:140-148); flow_f: [N-1, 2, h, w]
-        fr = []
-        for i in range(pred_u8.shape[0]):
-            fimg = flow_to_image(flow_f[i].permute(1, 2, 0).numpy(), convert_to_bgr=True)
-            if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
-                fimg = np.array(Image.fromarray(fimg).resize((pred_u8.shape[2], pred_u8.shape[1]), Image.BILINEAR))
-            fr.append(np.stack([pred_u8[i].numpy()[:, :, ::-1], fimg], 0))
-        return np.stack(fr, 0)
+    def post(j0, keep_frames):
+        def fn(pred_u8, flow_f):
+            # pred_u8: [b, N-1, H, W, 3] uint8 RGB ; flow_f: [b, N-1, 2, h, w].  Flow pictures are written by the rank
+            # that computed them (no collective for them); frames only come back to the host on a single-GPU run
+            for bi in range(flow_f.shape[0]):
+                for i in range(flow_f.shape[1]):
+                    fimg = flow_to_image(flow_f[bi, i].permute(1, 2, 0).numpy(), convert_to_bgr=True)
+                    if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
+                        fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
+                    Image.fromarray(np.ascontiguousarray(fimg[:, :, ::-1])).save(
+                        os.path.join(flow_dir, f"{(j0 + bi) * (N - 1) + i:06d}.png"))
+            return pred_u8.numpy() if keep_frames else None
+        return fn
 
     coord_cache = {}
-    for j in tqdm(range(p0, p1)):
-        I0p, I2p = frames_in.get(j), frames_in.get(j + 1)
-        xs = torch.stack((I0p, I2p), dim=2)
-        batch_size, s_shape = xs.shape[0], xs.shape[-2:]
+    local_dev = []     # device-resident uint8 result frames of this rank (gathered once at the end when world > 1)
+    t_warm, pairs_warm = None, 0
+    for j0 in tqdm(range(p0, p1, bsz)):
+        if j0 == p0 + bsz:           # the first batch pays model packing + graph capture: steady state starts here
+            torch.cuda.synchronize(device)
+            t_warm, pairs_warm = time.perf_counter(), j0 - p0
+        b = min(bsz, p1 - j0)
+        frames = torch.cat([frames_in.get(j) for j in range(j0, j0 + b + 1)], 0)      # (b+1, 3, Hp, Wp), each decoded once
+        s_shape = frames.shape[-2:]
         with torch.no_grad():
-            key = (batch_size, tuple(s_shape))
-            if key not in coord_cache:     # the coordinate grids only depend on the frame size
+            key = (b, tuple(s_shape))
+            if key not in coord_cache:     # the coordinate grids only depend on the batch and frame size
                 coord_cache[key] = (
-                    [(model.sample_coord_input(batch_size, s_shape, [1 / N * i], device=xs.device,
-                                               upsample_ratio=ds_factor), None) for i in range(1, N)],
-                    [i * 1 / N * torch.ones(batch_size, device=xs.device, dtype=torch.float) for i in range(1, N)])
+                    [(model.sample_coord_input(b, s_shape, [1 / N * i], device=device, upsample_ratio=ds_factor), None)
+                     for i in range(1, N)],
+                    [i * 1 / N * torch.ones(b, device=device, dtype=torch.float) for i in range(1, N)])
             coord_inputs, timesteps = coord_cache[key]
-            out = model(xs, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
-            preds = torch.stack([padder.unpad(out["imgt_pred"][i])[0] for i in range(N - 1)], 0)     # [N-1,3,H,W]
-            pred_u8 = model.engine(device).rt.frames_to_u8(preds.contiguous())                       # [N-1,H,W,3] RGB
+            out = model.forward_sequence(frames, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
+            preds = torch.stack([padder.unpad(out["imgt_pred"][i]) for i in range(N - 1)], 1)       # [b, N-1, 3, H, W]
+            pred_u8 = rt.frames_to_u8(preds.reshape(-1, *preds.shape[2:]).contiguous()).reshape(b, N - 1, H0, W0, 3)
             flows = []
             for i in range(N - 1):
                 u = padder.unpad(out["flowt"][i])
-                flows.append(u.reshape(2, *u.shape[-2:]))
-            flows = torch.stack(flows, 0).contiguous()
-        drain.submit(j, [pred_u8, flows], post)
+                flows.append(u.reshape(b, 2, *u.shape[-2:]))
+            flows = torch.stack(flows, 1).contiguous()                                              # [b, N-1, 2, h, w]
+        if world > 1:
+            local_dev.append(pred_u8)
+        drain.submit(j0, [pred_u8, flows], post(j0, keep_frames=(world == 1)))
     results = drain.finish()
     frames_in.close()
-    local_frames = [results[j] for j in range(p0, p1)]   # per pair: uint8 [N-1, 2, H, W, 3] (frame, flow image), BGR
-    if local_frames:
-        lf = torch.from_numpy(np.stack(local_frames, 0)).to(device)
+    if t_warm is not None and rank == 0:
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t_warm
+        nfr = (p1 - p0 - pairs_warm) * (N - 1)
+        print(f"[video_Nx] steady state: {nfr} interpolated frames ({W0}x{H0}, {N}x, {bsz} pairs/forward) in {dt:.3f} s = "
+              f"{nfr / dt:.1f} frames/s on rank 0 incl. PNG decode, H2D, D2H and flow colour-coding")
+    if world > 1:
+        lf = torch.cat(local_dev, 0) if local_dev else torch.zeros((0, N - 1, H0, W0, 3), dtype=torch.uint8, device=device)
+        allf = shard.gather_frames_chunked(lf, num_pairs, rank, world)   # the path's only collective: uint8 frames, RCCL
+        torch.distributed.barrier()                                      # every rank's flow pictures are on disk
+        if rank == 0:
+            allf = allf.cpu().numpy()
     else:
-        h, w = Image.open(os.path.join(args.source_path, img_list[0])).size[::-1]
-        lf = torch.zeros((0, N - 1, 2, h, w, 3), dtype=torch.uint8, device=device)
-    allf = shard.gather_frames(lf, num_pairs, rank, world)   # RCCL gather of the result frames
+        allf = np.concatenate([results[j0] for j0 in range(p0, p1, bsz)], 0) if num_pairs > 0 else None
     if rank == 0:
-        allf = allf.cpu().numpy()
         originals = [to_bgr_u8(load_image(os.path.join(args.source_path, f))[0]) for f in img_list]
-        images, flows = [np.concatenate([originals[0], originals[0]], 1)], []
+        images = [np.concatenate([originals[0], originals[0]], 1)]
         for j in range(num_pairs):
             for i in range(N - 1):
-                images.append(np.concatenate([originals[j], allf[j, i, 0]], 1))   # cv2.hconcat([orig, interp])
-                flows.append(allf[j, i, 1])
+                images.append(np.concatenate([originals[j], allf[j, i][:, :, ::-1]], 1))   # cv2.hconcat([orig, interp])
             images.append(np.concatenate([originals[j + 1], originals[j + 1]], 1))
+        flows = [np.array(Image.open(os.path.join(flow_dir, f)))[:, :, ::-1] for f in sorted(os.listdir(flow_dir))]
         o1 = images_to_video(images[:-1], os.path.join(args.output_path, "output.mp4"), fps=N * 2)
         o2 = images_to_video(flows, os.path.join(args.output_path, "flow.mp4"), fps=N * 2)
+        shutil.rmtree(flow_dir, ignore_errors=True)
         print("=========================Interpolation Finished=========================")
         print(len(images), o1, o2)
     if world > 1:

@@ -41,3 +41,34 @@ def test_engine_bf16_batch2_two_timesteps(sd):
         # splat holes (0/0 -> 1, softsplat.py:333-334) are discontinuous: judge flow by mean / p99, not max
         d = (out["flowt"][i].float() - gold[f"flowt_{i}"]).abs().flatten()
         assert float(d.mean()) < 0.03 and float(d.kthvalue(int(d.numel() * 0.99))[0]) < 0.1
+
+
+def test_sequence_mode_shares_encoder_work_and_changes_nothing(sd):
+    """Engine.forward(seq=True): B consecutive pairs of one frame sequence -- the per-frame encoders run on the B+1
+    distinct frames; the flow estimator's outputs equal the pair-by-pair batch bit for bit, everything
+    behind the softmax splat up to the order of its float atomics."""
+    import torch
+
+    from gimmvfi_hip.engine import Engine
+    from gimmvfi_hip.synth import synthetic_pairs
+    from sim_runtime import SimRuntime
+
+    p = synthetic_pairs(2, 128, 128, seed=31)
+    frames = torch.stack([p[0, :, 0], p[0, :, 1], p[1, :, 1]], 0)          # 3 consecutive frames
+    x = torch.stack([frames[:-1], frames[1:]], dim=2)                       # (2,3,2,H,W): pairs (0,1), (1,2)
+    coords = [(orc.sample_coord_input(2, (128, 128), [t], 1.0), None) for t in (0.25, 0.5)]
+    ts = [t * torch.ones(2) for t in (0.25, 0.5)]
+    eng = Engine(SimRuntime("fp32"), sd)
+    calls = []
+    enc = eng._enc
+    eng._enc = lambda x_, *a, **k: (calls.append(x_.shape[0]), enc(x_, *a, **k))[1]
+    a = eng.forward(x, coords, ts)
+    assert calls == [4, 4]                                                  # fnet, cnet on 2B images
+    calls.clear()
+    b = eng.forward(x, coords, ts, seq=True)
+    assert calls == [3, 3]                                                  # ... on the 3 distinct frames
+    for k in ("raft_flow", "nflow"):
+        assert torch.equal(a[k], b[k])
+    for i in range(2):
+        assert maxabs(a["imgt_pred"][i], b["imgt_pred"][i]) < 1e-5
+        assert maxabs(a["flowt"][i], b["flowt"][i]) < 1e-4

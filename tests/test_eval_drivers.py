@@ -100,6 +100,89 @@ def test_vsf_driver_runs_the_septuplet_protocol(tmp_path):
     assert n == 5 and np.isfinite(psnr) and np.isfinite(epe)
 
 
+class OracleModel:
+    """The CPU oracle behind the model API the evaluators call (test infrastructure): the SAME protocol code of the
+    drivers then scores the oracle, and the HIP model must reproduce those scores."""
+
+    def __init__(self, sd):
+        import gimmvfi_r_oracle as orc
+
+        self.orc, self.sd = orc, sd
+
+    def sample_coord_input(self, b, s_shape, t_ids, device=None, upsample_ratio=1.0):
+        return self.orc.sample_coord_input(b, s_shape, t_ids, upsample_ratio)
+
+    def __call__(self, xs, coords, t=None, ds_factor=None):
+        with torch.no_grad():
+            return self.orc.forward(self.sd, xs.cpu(), coords, [ti.cpu() for ti in t], ds_factor)
+
+
+def _hip_model(sd, precision="fp32"):
+    from gimmvfi_hip.model import GIMMVFI_R
+
+    m = GIMMVFI_R(precision=precision)
+    m.load_state_dict(sd, strict=True)
+    return m.to("cuda:0").eval()
+
+
+@pytest.mark.gpu
+def test_snu_film_scores_match_the_oracle_protocol(tmp_path, sd):
+    """reference src/SNU_FILM_arb.py:78-170 (4x split): the driver's evaluate_split run on the HIP model (fp32 mode and
+    bf16) against the same function run on the CPU oracle -- PSNR of every in-between frame through the same padder,
+    coordinate grids and scoring code."""
+    from PIL import Image
+
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    sys.path.insert(0, SRC)
+    import SNU_FILM_arb as snu
+
+    root = tmp_path / "SNU-FILM"
+    seq = root / "test" / "clip_a"
+    os.makedirs(seq)
+    x = synthetic_pairs(1, 150, 200, seed=9)[0]          # not a multiple of 32: the padder is part of the protocol
+    a, b = x[:, 0], x[:, 1]
+    for k in range(5):
+        img = ((1 - k / 4) * a + k / 4 * b).permute(1, 2, 0).numpy()
+        Image.fromarray((img * 255).astype(np.uint8)).save(str(seq / f"{10 + k:05d}.png"))
+    (root / "test-medium.txt").write_text("test/clip_a/00010.png test/clip_a/00012.png test/clip_a/00014.png\n")
+    want, n0 = snu.evaluate_split(OracleModel(sd), str(root), "medium", "cpu")
+    got32, n1 = snu.evaluate_split(_hip_model(sd, "fp32"), str(root), "medium", torch.device("cuda:0"))
+    got16, n2 = snu.evaluate_split(_hip_model(sd, "bf16"), str(root), "medium", torch.device("cuda:0"))
+    print(f"SNU-FILM medium (synthetic): oracle {want:.4f} dB, HIP fp32 {got32:.4f} dB, HIP bf16 {got16:.4f} dB")
+    assert n0 == n1 == n2 == 3
+    assert abs(got32 - want) < 1e-3
+    assert abs(got16 - want) < 0.05
+
+
+@pytest.mark.gpu
+def test_x4k_scores_match_the_oracle_protocol(tmp_path, sd):
+    """reference src/X4K.py:87-197: evaluate_mode (2k = area-resampled + DS 0.5, 4k = native + DS 0.25, prediction
+    quantised to 8 bits before scoring) on the HIP model against the same function on the CPU oracle."""
+    from PIL import Image
+
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    sys.path.insert(0, SRC)
+    import X4K as x4k
+
+    scene = tmp_path / "x4k" / "Type1" / "TEST01"
+    os.makedirs(scene)
+    x = synthetic_pairs(1, 512, 640, seed=4)[0]
+    a, b = x[:, 0], x[:, 1]
+    for k in range(5):
+        img = ((1 - k / 4) * a + k / 4 * b).permute(1, 2, 0).numpy()
+        Image.fromarray((img * 255).astype(np.uint8)).save(str(scene / f"{k:04d}.png"))
+    samples = x4k.getXVFI(str(tmp_path / "x4k"), multiple=2, t_step_size=4)
+    om, hm = OracleModel(sd), _hip_model(sd, "fp32")
+    for mode in ("XTEST-2k", "XTEST-4k"):
+        want, n0 = x4k.evaluate_mode(om, samples, mode, "cpu", (320, 256))
+        got, n1 = x4k.evaluate_mode(hm, samples, mode, torch.device("cuda:0"), (320, 256))
+        print(f"{mode} (synthetic): oracle {want:.4f} dB, HIP fp32 {got:.4f} dB")
+        assert n0 == n1 == 1
+        assert abs(got - want) < 1e-2          # 8-bit quantisation before scoring: a flipped LSB moves the score by ~1e-4
+
+
 @pytest.mark.gpu
 def test_snu_film_arb_driver_on_a_synthetic_split(tmp_path):
     """reference src/SNU_FILM_arb.py protocol (medium split = 4x): PSNR of the three in-between frames, files written."""

@@ -35,15 +35,17 @@ def _worker(rank, world, port, num_pairs, q):
     local = torch.stack([torch.full((3, 4, 5, 3), j, dtype=torch.uint8) for j in range(a, b)]) if b > a else \
         torch.zeros((0, 3, 4, 5, 3), dtype=torch.uint8)
     out = shard.gather_frames(local, num_pairs, rank, world)
+    out2 = shard.gather_frames_chunked(local, num_pairs, rank, world, chunk_pairs=2)     # several rounds, ragged last one
     if rank == 0:
+        assert torch.equal(out, out2)
         q.put(out.numpy())
     else:
-        assert out is None
+        assert out is None and out2 is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_pairs", [5, 2, 1])
+@pytest.mark.parametrize("num_pairs", [7, 5, 2, 1])
 def test_gather_frames_gloo_world2(num_pairs):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -33,7 +33,7 @@ def main():
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True)
         dt = time.perf_counter() - t0
-        print(r.stdout[-300:], r.stderr[-300:] if r.returncode else "")
+        print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("[video_Nx]")), r.stderr[-300:] if r.returncode else "")
         print(f"CLI: {n} frames {W}x{H}, {N}x -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
               f"(incl. process start, model build, graph capture, PNG/video writing)")
 
