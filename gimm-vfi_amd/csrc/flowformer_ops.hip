@@ -18,51 +18,66 @@ static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + GVFI_BLOCK 
 // Input: the residual stream (float when x_f32, else the activation type); output: activation type (the operand
 // of the next contraction).  A row is shared by C/VE lanes (one 16-byte output vector each, 64/(C/VE) rows per
 // wave); mean and variance are two shuffle reductions over registers.
-template <typename T>
+// Every lane group normalises R rows; the R loads are issued back to back before the first reduction (one row per
+// lane group left ~1 KB in flight per wave: 0.5 TB/s on the 229 k-row launches of the cost encoder).
+template <typename T, int R>
 __global__ void layernorm_vec_kernel(const void* __restrict__ x, int ldx, int x_f32, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float eps, T* __restrict__ y, int ldy,
                                      long long rows, int C, int lpr) {
     constexpr int VE = Elem<T>::VE;
     const int lane = threadIdx.x & 63;
     const int sub = lane % lpr;
+    const int rpw = 64 / lpr;                                   // rows per wave and pass
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long r = wave * (64 / lpr) + lane / lpr;
-    const bool live = r < rows;
-    float v[VE];
-    if (live) {
-        if (x_f32) {
-            const float* xr = (const float*)x + r * ldx + sub * VE;
+    const long long r0 = wave * (rpw * R) + lane / lpr;
+    float v[R][VE];
 #pragma unroll
-            for (int e = 0; e < VE; e += 4) {
-                const float4 f = *(const float4*)(xr + e);
-                v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+    for (int i = 0; i < R; ++i) {
+        const long long r = r0 + (long long)i * rpw;
+        if (r < rows) {
+            if (x_f32) {
+                const float* xr = (const float*)x + r * ldx + sub * VE;
+#pragma unroll
+                for (int e = 0; e < VE; e += 4) {
+                    const float4 f = *(const float4*)(xr + e);
+                    v[i][e] = f.x; v[i][e + 1] = f.y; v[i][e + 2] = f.z; v[i][e + 3] = f.w;
+                }
+            } else {
+                struct alignas(16) Vec { T e[VE]; };
+                const Vec q = *(const Vec*)((const T*)x + r * ldx + sub * VE);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) v[i][e] = Elem<T>::ld(&q.e[e]);
             }
         } else {
-            struct alignas(16) Vec { T e[VE]; };
-            const Vec q = *(const Vec*)((const T*)x + r * ldx + sub * VE);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] = Elem<T>::ld(&q.e[e]);
+            for (int e = 0; e < VE; ++e) v[i][e] = 0.f;
         }
-    } else {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) v[e] = 0.f;
     }
-    float s = 0.f;
+    float g[VE], bt[VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) s += v[e];
-    for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    const float mean = s / (float)C;
-    float q2 = 0.f;
+    for (int e = 0; e < VE; ++e) {
+        g[e] = gamma[sub * VE + e];
+        bt[e] = beta[sub * VE + e];
+    }
 #pragma unroll
-    for (int e = 0; e < VE; ++e) q2 += (v[e] - mean) * (v[e] - mean);
-    for (int off = lpr >> 1; off > 0; off >>= 1) q2 += __shfl_xor(q2, off);
-    if (!live) return;
-    const float rstd = 1.0f / sqrtf(q2 / (float)C + eps);
-    struct alignas(16) VecO { T e[VE]; } o;
+    for (int i = 0; i < R; ++i) {
+        const long long r = r0 + (long long)i * rpw;
+        float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < VE; ++e)
-        Elem<T>::st(&o.e[e], (v[e] - mean) * rstd * gamma[sub * VE + e] + beta[sub * VE + e]);
-    *(VecO*)(y + r * ldy + sub * VE) = o;
+        for (int e = 0; e < VE; ++e) s += v[i][e];
+        for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        const float mean = s / (float)C;
+        float q2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) q2 += (v[i][e] - mean) * (v[i][e] - mean);
+        for (int off = lpr >> 1; off > 0; off >>= 1) q2 += __shfl_xor(q2, off);
+        if (r >= rows) continue;     // (after the shuffles: every lane of the wave takes part in them)
+        const float rstd = 1.0f / sqrtf(q2 / (float)C + eps);
+        struct alignas(16) VecO { T e[VE]; } o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) Elem<T>::st(&o.e[e], (v[i][e] - mean) * rstd * g[e] + bt[e]);
+        *(VecO*)(y + r * ldy + sub * VE) = o;
+    }
 }
 template <typename T>
 __global__ void layernorm_kernel(const void* __restrict__ x, int ldx, int x_f32, const float* __restrict__ gamma,
@@ -94,14 +109,23 @@ extern "C" int gvfi_layernorm(const void* x, int ldx, int x_f32, const float* ga
     // the emulator runs cooperative launches with one OS thread per lane: keep the CPU suite fast, the vector kernel
     // is exercised by the unit tests at small row counts
     const bool vec_ok_rows = rows <= 256;
+    const long long r4_min = 65;       // ... and let those unit tests reach the four-row variant too
 #else
     const bool vec_ok_rows = true;
+    const long long r4_min = 4096;
 #endif
     if (vec && vec_ok_rows) {
-        const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
-        GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((layernorm_vec_kernel<T>), grid1d(waves * 64), dim3(GVFI_BLOCK),
-                                                (hipStream_t)stream, x, ldx, x_f32, gamma, beta, eps, (T*)y, ldy, rows, C,
-                                                lpr));
+        if (rows >= r4_min) {      // four rows per lane group
+            const long long waves = (rows + 4 * (64 / lpr) - 1) / (4 * (64 / lpr));
+            GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((layernorm_vec_kernel<T, 4>), grid1d(waves * 64), dim3(GVFI_BLOCK),
+                                                    (hipStream_t)stream, x, ldx, x_f32, gamma, beta, eps, (T*)y, ldy, rows,
+                                                    C, lpr));
+        } else {
+            const long long waves = (rows + (64 / lpr) - 1) / (64 / lpr);
+            GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((layernorm_vec_kernel<T, 1>), grid1d(waves * 64), dim3(GVFI_BLOCK),
+                                                    (hipStream_t)stream, x, ldx, x_f32, gamma, beta, eps, (T*)y, ldy, rows,
+                                                    C, lpr));
+        }
     } else {
         GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((layernorm_kernel<T>), grid1d(rows), dim3(GVFI_BLOCK),
                                                   (hipStream_t)stream, x, ldx, x_f32, gamma, beta, eps, (T*)y, ldy, rows, C));
@@ -174,13 +198,12 @@ extern "C" int gvfi_pos_embed(const float* coords, long long period, float scale
 // ------------------------------------------------------------------ first cost-map convolution   encoder.py:39-41
 // Conv2d(1, 16, 6, stride 2, padding 2) + ReLU over the cost maps [maps][H][W] (float, the all-pairs volume itself),
 // zero-extended to a multiple of the patch size on the right / bottom (encoder.py:70-75): out [maps][Ho][Wo][16].
-// s2d: the output is written space-to-depth(2): pixel (oy, ox) -> pixel (oy/2, ox/2), channel block (oy&1)*2 + (ox&1)
-// of a [maps][Ho/2][Wo/2][4*16] tensor, the layout in which the following 6x6 stride-2 convolution is a 3x3 stride-1
-// convolution over 64 channels (LDS-DMA kernel); Ho, Wo even.
+// (A space-to-depth output layout that turns the two following 6x6 stride-2 convolutions into 3x3 stride-1 ones on
+// the LDS-DMA kernel was measured in round 2: 130.6 frames/s either way, removed.)
 template <typename T>
 __global__ void cost_embed1_kernel(const float* __restrict__ vol, const float* __restrict__ w /*[36][16]*/,
                                    const float* __restrict__ bias, T* __restrict__ out, int ldo, long long total, int H,
-                                   int W, int Ho, int Wo, int s2d) {
+                                   int W, int Ho, int Wo) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over output pixels
     if (idx >= total) return;
     const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho);
@@ -201,38 +224,16 @@ __global__ void cost_embed1_kernel(const float* __restrict__ vol, const float* _
             for (int c = 0; c < 16; ++c) acc[c] += v * wk[c];
         }
     }
-    T* o = s2d ? out + ((m * (Ho / 2) + oy / 2) * (long long)(Wo / 2) + ox / 2) * ldo + ((oy & 1) * 2 + (ox & 1)) * 16
-               : out + idx * ldo;
+    T* o = out + idx * ldo;
 #pragma unroll
     for (int c = 0; c < 16; ++c) Elem<T>::st(o + c, acc[c] > 0.f ? acc[c] : 0.f);
 }
 extern "C" int gvfi_cost_embed1(const float* vol, const float* w, const float* bias, void* out, int ldo, long long maps,
-                                int H, int W, int Ho, int Wo, int s2d, int dtype, void* stream) {
-    if (ldo < (s2d ? 64 : 16) || (s2d && ((Ho | Wo) & 1))) return -2;
+                                int H, int W, int Ho, int Wo, int dtype, void* stream) {
+    if (ldo < 16) return -2;
     const long long total = maps * Ho * Wo;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((cost_embed1_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
-                                              vol, w, bias, (T*)out, ldo, total, H, W, Ho, Wo, s2d));
-    return (int)hipGetLastError();
-}
-
-// space-to-depth(2) of an NHWC tensor: dst[n, y/2, x/2, ((y&1)*2 + (x&1))*C + c] = src[n, y, x, c]   (H, W even)
-template <typename T>
-__global__ void space_to_depth2_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, long long total,
-                                       int H, int W, int C) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (pixel, channel)
-    if (idx >= total) return;
-    const int c = (int)(idx % C);
-    const long long pix = idx / C;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H);
-    const long long n = pix / ((long long)W * H);
-    dst[((n * (H / 2) + y / 2) * (long long)(W / 2) + x / 2) * ldd + ((y & 1) * 2 + (x & 1)) * C + c] = src[pix * lds + c];
-}
-extern "C" int gvfi_space_to_depth2(const void* src, int lds, void* dst, int ldd, int C, int N, int H, int W, int dtype,
-                                    void* stream) {
-    if (((H | W) & 1) || ldd < 4 * C) return -2;
-    const long long total = (long long)N * H * W * C;
-    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((space_to_depth2_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
-                                              (hipStream_t)stream, (const T*)src, lds, (T*)dst, ldd, total, H, W, C));
+                                              vol, w, bias, (T*)out, ldo, total, H, W, Ho, Wo));
     return (int)hipGetLastError();
 }
 
@@ -339,71 +340,13 @@ __global__ void attn_window_kernel(const T* __restrict__ q, int ldq, const T* __
         }
     acc.store(out + row * ldo + hd * HD);
 }
-// LDS-staged variant (A/B switch GVFI_ATTN_LDS=1, not yet measured): one workgroup per window stages its ws*ws key and
-// value rows (padded positions from kpad / vpad, rounded to the activation type) once; a lane owns one (query, head)
-// and reads the keys from LDS -- lanes of a wave are (8 queries x 8 heads): same-head lanes broadcast, different heads
-// are HD elements apart (no bank conflict for HD*sizeof(T) >= 16 bytes).
-template <typename T, int HD>
-__global__ void attn_window_lds_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
-                                       const T* __restrict__ v, int ldv, const float* __restrict__ kpad,
-                                       const float* __restrict__ vpad, T* __restrict__ out, int ldo, int H, int W, int ws,
-                                       int heads, float scale) {
-    GVFI_DYN_SMEM(smem);
-    const int C = heads * HD, nk = ws * ws;
-    T* Ks = (T*)smem;
-    T* Vs = Ks + nk * C;
-    const int nwx = (W + ws - 1) / ws, nwy = (H + ws - 1) / ws;
-    int b = blockIdx.x;
-    const int wx = (b % nwx) * ws;
-    b /= nwx;
-    const int wy = (b % nwy) * ws;
-    const long long img0 = (long long)(b / nwy) * H * W;
-    for (int i = threadIdx.x; i < nk * C; i += blockDim.x) {
-        const int pos = i / C, c = i - pos * C;
-        const int yy = wy + pos / ws, xx = wx + pos % ws;
-        if (yy < H && xx < W) {
-            const long long row = img0 + (long long)yy * W + xx;
-            Ks[i] = k[row * ldk + c];
-            Vs[i] = v[row * ldv + c];
-        } else {
-            Elem<T>::st(&Ks[i], kpad[pos * C + c]);
-            Elem<T>::st(&Vs[i], vpad[pos * C + c]);
-        }
-    }
-    __syncthreads();
-    for (int item = threadIdx.x; item < nk * heads; item += blockDim.x) {
-        const int hd = item % heads, pos = item / heads;
-        const int yy = wy + pos / ws, xx = wx + pos % ws;
-        if (yy >= H || xx >= W) continue;
-        const long long row = img0 + (long long)yy * W + xx;
-        AttnAcc<T, HD> acc;
-        acc.init(q + row * ldq + hd * HD);
-        for (int j = 0; j < nk; ++j) acc.key(Ks + j * C + hd * HD, Vs + j * C + hd * HD, scale);
-        acc.store(out + row * ldo + hd * HD);
-    }
-}
-static inline bool gvfi_attn_lds() {
-    const char* e = getenv("GVFI_ATTN_LDS");
-    return e && e[0] == '1';
-}
+// (LDS-staged variants of this kernel and of attn_global_kernel -- a workgroup staging its window's / group's key and
+// value rows once -- were measured in round 2: 130.3 vs 130.6 frames/s, i.e. the per-key global loads are served by
+// L1/L2 as fast as LDS serves them; removed.)
 extern "C" int gvfi_attn_window(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
                                 const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
                                 int head_dim, float scale, int dtype, void* stream) {
     const long long total = (long long)n_img * H * W * heads;
-    const size_t shm = (size_t)2 * ws * ws * heads * head_dim * (dtype == GVFI_F32 ? 4 : 2);
-    if (gvfi_attn_lds() && shm <= 150 * 1024) {
-        dim3 grid((unsigned)((long long)n_img * ((H + ws - 1) / ws) * ((W + ws - 1) / ws)));
-#define GVFI_AWL(HD_)                                                                                                 \
-    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP_SHM((attn_window_lds_kernel<T, HD_>), grid, dim3(GVFI_BLOCK), shm,         \
-                                                (hipStream_t)stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v,   \
-                                                ldv, kpad, vpad, (T*)out, ldo, H, W, ws, heads, scale))
-        if (head_dim == 8) GVFI_AWL(8);
-        else if (head_dim == 16) GVFI_AWL(16);
-        else if (head_dim == 32) GVFI_AWL(32);
-        else return -2;
-#undef GVFI_AWL
-        return (int)hipGetLastError();
-    }
 #define GVFI_AW(HD_)                                                                                                 \
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_window_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),          \
                                               (hipStream_t)stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
@@ -443,57 +386,12 @@ __global__ void attn_global_kernel(const T* __restrict__ q, int ldq, long long q
     }
     acc.store(out + (g1 * ob1 + g0 * ob0 + i * os) * ldo + hd * HD);
 }
-// LDS-staged variant of the batched case (G0 == 1, unit strides: sub-sampled global attention): a workgroup stages
-// the M key / value rows of its group once and serves QB consecutive queries x all heads (GVFI_ATTN_LDS=1).
-template <typename T, int HD>
-__global__ void attn_global_lds_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
-                                       const T* __restrict__ v, int ldv, T* __restrict__ out, int ldo, int NQ, int M,
-                                       int heads, float scale, int QB) {
-    GVFI_DYN_SMEM(smem);
-    const int C = heads * HD;
-    T* Ks = (T*)smem;
-    T* Vs = Ks + M * C;
-    const int chunks = (NQ + QB - 1) / QB;
-    const long long g1 = blockIdx.x / chunks;
-    const int q0 = (int)(blockIdx.x % chunks) * QB;
-    for (int i = threadIdx.x; i < M * C; i += blockDim.x) {
-        const int j = i / C, c = i - j * C;
-        Ks[i] = k[(g1 * M + j) * ldk + c];
-        Vs[i] = v[(g1 * M + j) * ldv + c];
-    }
-    __syncthreads();
-    for (int item = threadIdx.x; item < QB * heads; item += blockDim.x) {
-        const int hd = item % heads, qi = q0 + item / heads;
-        if (qi >= NQ) continue;
-        const long long row = g1 * NQ + qi;
-        AttnAcc<T, HD> acc;
-        acc.init(q + row * ldq + hd * HD);
-        for (int j = 0; j < M; ++j) acc.key(Ks + j * C + hd * HD, Vs + j * C + hd * HD, scale);
-        acc.store(out + row * ldo + hd * HD);
-    }
-}
 extern "C" int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
                                 const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
                                 long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
                                 int head_dim, float scale, int dtype, void* stream) {
     if (G0 <= 0 || NQ <= 0 || M <= 0) return -2;
     const long long total = G1 * G0 * NQ * heads;
-    const size_t shm = (size_t)2 * M * heads * head_dim * (dtype == GVFI_F32 ? 4 : 2);
-    if (gvfi_attn_lds() && G0 == 1 && qs == 1 && ks == 1 && os == 1 && qb1 == NQ && ob1 == NQ && kb1 == M && NQ >= 64 &&
-        shm <= 150 * 1024) {
-        const int QB = GVFI_BLOCK / heads;
-        dim3 grid((unsigned)(G1 * ((NQ + QB - 1) / QB)));
-#define GVFI_AGL(HD_)                                                                                                  \
-    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP_SHM((attn_global_lds_kernel<T, HD_>), grid, dim3(GVFI_BLOCK), shm,          \
-                                                (hipStream_t)stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v,    \
-                                                ldv, (T*)out, ldo, NQ, M, heads, scale, QB))
-        if (head_dim == 8) GVFI_AGL(8);
-        else if (head_dim == 16) GVFI_AGL(16);
-        else if (head_dim == 32) GVFI_AGL(32);
-        else return -2;
-#undef GVFI_AGL
-        return (int)hipGetLastError();
-    }
 #define GVFI_AG(HD_)                                                                                                   \
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_global_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),            \
                                               (hipStream_t)stream, (const T*)q, ldq, qb1, qb0, qs, (const T*)k, ldk,     \
@@ -539,9 +437,68 @@ __global__ void xqk_kernel(const T* __restrict__ x, int ldx, int Cx, const T* __
     }
     Elem<T>::st(out + r * ldo + c, val);
 }
+// table[pos][c] = enc(x, y)[c] for the positions xqk adds (enc_mode 1: the ws*ws window positions, 2: the H*W grid
+// positions), Ct channels -- the same per-channel expression as the inline evaluation above, computed once per forward
+// instead of once per (row, channel): the sin / cos of 229 k rows x 192 channels were 1.6 ms of a GIMM-VFI-F step
+__global__ void pos_table_kernel(float* __restrict__ table, int npos, int Ct, int W, int enc_mode, int ws) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npos * Ct) return;
+    const int c = idx % Ct, pos = idx / Ct;
+    const int px = enc_mode == 1 ? pos % ws : pos % W, py = enc_mode == 1 ? pos / ws : pos / W;
+    table[idx] = pos_enc_channel((float)px, (float)py, c, Ct);
+}
+extern "C" int gvfi_ff_pos_table(float* table, int H, int W, int Ct, int enc_mode, int ws, void* stream) {
+    if ((enc_mode != 1 && enc_mode != 2) || (Ct & 3) || (enc_mode == 1 && ws <= 0)) return -2;
+    const int npos = enc_mode == 1 ? ws * ws : H * W;
+    GVFI_LAUNCH_SIMPLE(pos_table_kernel, grid1d((long long)npos * Ct), dim3(GVFI_BLOCK), (hipStream_t)stream, table, npos, Ct,
+                       W, enc_mode, ws);
+    return (int)hipGetLastError();
+}
+// vector form: one 16-byte group of channels per thread, positional code from the table
+template <typename T>
+__global__ void xqk_vec_kernel(const T* __restrict__ x, int ldx, int Cx, const T* __restrict__ ctx, int ldc, int Cc,
+                               T* __restrict__ out, int ldo, long long total, int P, int W, int K, int nb, int enc_mode,
+                               int ws, const float* __restrict__ table) {
+    constexpr int VE = Elem<T>::VE;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (row, channel group)
+    if (idx >= total) return;
+    const int Ct = Cx + Cc, G = Ct / VE;
+    const int c = (int)(idx % G) * VE;
+    const long long r = idx / G;
+    const int p = (int)(r % P);
+    const long long im = r / P;
+    struct alignas(16) Vec { T e[VE]; };
+    Vec v;
+    if (c < Cx) {
+        v = *(const Vec*)(x + r * ldx + c);
+    } else {
+        const long long per = (long long)nb * K;
+        const long long cimg = (im / per) * nb + (im % per) % nb;
+        v = *(const Vec*)(ctx + (cimg * P + p) * ldc + (c - Cx));
+    }
+    if (enc_mode) {
+        const int px = p % W, py = p / W;
+        const int pos = enc_mode == 1 ? (py % ws) * ws + (px % ws) : p;
+        const float* tr = table + (long long)pos * Ct + c;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) Elem<T>::st(&v.e[e], Elem<T>::ld(&v.e[e]) + tr[e]);
+    }
+    *(Vec*)(out + r * ldo + c) = v;
+}
 extern "C" int gvfi_ff_xqk(const void* x, int ldx, int Cx, const void* ctx, int ldc, int Cc, void* out, int ldo, int n_img,
-                           int H, int W, int K, int nb, int enc_mode, int ws, int dtype, void* stream) {
+                           int H, int W, int K, int nb, int enc_mode, int ws, const float* enc_table, int dtype,
+                           void* stream) {
     if (((Cx + Cc) & 3) || nb <= 0 || K <= 0 || (enc_mode == 1 && ws <= 0)) return -2;
+    const int ve = dtype == GVFI_F32 ? 4 : 8;
+    const bool vec = (enc_mode == 0 || enc_table != nullptr) && Cx % ve == 0 && Cc % ve == 0 && ldx % ve == 0 &&
+                     ldc % ve == 0 && ldo % ve == 0 && ((((uintptr_t)x) | ((uintptr_t)ctx) | ((uintptr_t)out)) & 15) == 0;
+    if (vec) {
+        const long long totv = (long long)n_img * H * W * ((Cx + Cc) / ve);
+        GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((xqk_vec_kernel<T>), grid1d(totv), dim3(GVFI_BLOCK), (hipStream_t)stream,
+                                                  (const T*)x, ldx, Cx, (const T*)ctx, ldc, Cc, (T*)out, ldo, totv, H * W,
+                                                  W, K, nb, enc_mode, ws, enc_table));
+        return (int)hipGetLastError();
+    }
     const long long total = (long long)n_img * H * W * (Cx + Cc);
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((xqk_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
                                               (const T*)x, ldx, Cx, (const T*)ctx, ldc, Cc, (T*)out, ldo, total, H * W, W,

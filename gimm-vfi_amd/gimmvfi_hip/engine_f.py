@@ -139,17 +139,8 @@ class EngineF(Engine):
         k = ce + ".patch_embed.proj.0"
         self.consts[k + ".w"] = self._f32(sd[k + ".weight"].reshape(16, 36).t())    # [36][16]
         self.consts[k + ".b"] = self._f32(sd[k + ".bias"])
-        # GVFI_F_S2D=1 (A/B switch, not yet measured): the two 6x6 stride-2 convolutions as 3x3 stride-1 convolutions
-        # over space-to-depth(2) inputs (64 / 128 channels -> LDS-DMA kernel instead of the generic one)
-        self.s2d = os.environ.get("GVFI_F_S2D", "0") == "1"
         for k in (ce + ".patch_embed.proj.2", ce + ".patch_embed.proj.4"):
-            w = sd[k + ".weight"]
-            if self.s2d:
-                co, ci = w.shape[:2]
-                w2 = w.reshape(co, ci, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * ci, 3, 3)   # [(dy,dx,c)][a][b]
-                self._add(k, w2, sd[k + ".bias"], stride=1, pad=(1, 1))
-            else:
-                self._add(k, w, sd[k + ".bias"], stride=2, pad=(2, 2))
+            self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=2, pad=(2, 2))
         self._conv(sd, ce + ".patch_embed.ffn_with_coord.0")
         self._conv(sd, ce + ".patch_embed.ffn_with_coord.2")
         self._ln(sd, ce + ".patch_embed.norm")
@@ -295,14 +286,14 @@ class EngineF(Engine):
         att = self._tok(rows, 128)
         if local:
             xqk = self._tok(rows, 192)
-            rt.ff_xqk(y, ctxp, xqk, n_img, h8, w8, K_LAT, B, 1)
+            rt.ff_xqk(y, ctxp, xqk, n_img, h8, w8, K_LAT, B, 1, table=self._enc_table(1, h8, w8))
             qk = self._linear(a_ + ".qk", xqk)
             v = self._linear(a_ + ".v", y)
             rt.attn_window(View(qk, 0, 128), View(qk, 128, 128), v, C_[a_ + ".kpad"], C_[a_ + ".vpad"], att, n_img, h8, w8,
                            7, 8, 16)
         else:
             xq = self._tok(rows, 192)
-            rt.ff_xqk(y, ctxp, xq, n_img, h8, w8, K_LAT, B, 2)
+            rt.ff_xqk(y, ctxp, xq, n_img, h8, w8, K_LAT, B, 2, table=self._enc_table(2, h8, w8))
             q = self._linear(a_ + ".q", xq)
             xk = self._tok(rows, 192)
             rt.ff_xqk(y, ctxp, xk, n_img, h8, w8, K_LAT, B, 0)
@@ -328,6 +319,13 @@ class EngineF(Engine):
         x = self._linear(a_ + ".proj", att, res=x, f32=True)
         return self._mlp_res(p, x, p + ".norm2", 1e-5, p + ".mlp.fc1", p + ".mlp.fc2")
 
+    def _enc_table(self, mode, h, w):
+        """positional code of the window (mode 1) / grid (mode 2) positions, evaluated once per forward"""
+        key = ("enc", mode, h, w)
+        if key not in self._grids:
+            self._grids[key] = self.rt.ff_pos_table(h, w, 192, mode)
+        return self._grids[key]
+
     def _grid(self, h, w):
         key = ("grid", h, w)
         if key not in self._grids:
@@ -342,11 +340,9 @@ class EngineF(Engine):
         pe = ce + ".patch_embed"
         # ---- PatchEmbed of the cost maps   encoder.py:30-96
         hp, wp = (h8 + 7) // 8 * 8, (w8 + 7) // 8 * 8
-        e1 = rt.cost_embed1(vol, C_[pe + ".proj.0.w"], C_[pe + ".proj.0.b"], maps, h8, w8, hp // 2, wp // 2, s2d=self.s2d)
+        e1 = rt.cost_embed1(vol, C_[pe + ".proj.0.w"], C_[pe + ".proj.0.b"], maps, h8, w8, hp // 2, wp // 2)
         e2 = rt.act(maps, hp // 4, wp // 4, 32)
         rt.conv(Ls[pe + ".proj.2"], e1, e2, act1=A.ACT_RELU)
-        if self.s2d:
-            e2 = rt.space_to_depth2(e2, 32)
         h3, w3 = hp // 8, wp // 8
         T = h3 * w3
         tok = rt.act(maps, h3, w3, 128)

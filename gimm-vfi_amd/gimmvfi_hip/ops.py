@@ -517,18 +517,10 @@ class Runtime:
         self._chk(self.lib.pos_embed(coords.data_ptr(), period, float(scale), float(offset), dim, o.ptr, o.ld, rows,
                                      1 if accumulate else 0, self.dtype, self.stream()), "pos_embed")
 
-    def cost_embed1(self, vol, w, b, maps, h, w_, ho, wo, s2d=False):
-        out = self.act(maps, ho // 2, wo // 2, 64) if s2d else self.act(maps, ho, wo, 16)
+    def cost_embed1(self, vol, w, b, maps, h, w_, ho, wo):
+        out = self.act(maps, ho, wo, 16)
         self._chk(self.lib.cost_embed1(vol.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), out.shape[-1], maps,
-                                       h, w_, ho, wo, 1 if s2d else 0, self.dtype, self.stream()), "cost_embed1")
-        return out
-
-    def space_to_depth2(self, src, c):
-        src = V(src)
-        n, h, w = src.t.shape[:3]
-        out = self.act(n, h // 2, w // 2, 4 * c)
-        self._chk(self.lib.space_to_depth2(src.ptr, src.ld, out.data_ptr(), out.shape[-1], c, n, h, w, self.dtype,
-                                           self.stream()), "space_to_depth2")
+                                       h, w_, ho, wo, self.dtype, self.stream()), "cost_embed1")
         return out
 
     def cost_lookup(self, vol, coords, out, q, h, w, radius=4):
@@ -550,11 +542,16 @@ class Runtime:
                                        m, heads, hd, float(hd ** -0.5), self.dtype, self.stream()), "attn_global")
         return out
 
-    def ff_xqk(self, x, ctx, out, n_img, h, w, k, nb, enc_mode, ws=7):
+    def ff_xqk(self, x, ctx, out, n_img, h, w, k, nb, enc_mode, ws=7, table=None):
         x, c, o = V(x), V(ctx), V(out)
         self._chk(self.lib.ff_xqk(x.ptr, x.ld, x.c, c.ptr, c.ld, c.c, o.ptr, o.ld, n_img, h, w, k, nb, enc_mode, ws,
-                                  self.dtype, self.stream()), "ff_xqk")
+                                  None if table is None else table.data_ptr(), self.dtype, self.stream()), "ff_xqk")
         return out
+
+    def ff_pos_table(self, h, w, ct, enc_mode, ws=7):
+        t = self.f32(ws * ws if enc_mode == 1 else h * w, ct)
+        self._chk(self.lib.ff_pos_table(t.data_ptr(), h, w, ct, enc_mode, ws, self.stream()), "ff_pos_table")
+        return t
 
     def tile_rows(self, table, out, rows, p, k, c):
         o = V(out)

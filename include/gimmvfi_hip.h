@@ -235,15 +235,9 @@ int gvfi_dwconv3x3_res(const void* x, int ldx, const float* w, const float* bias
 int gvfi_pos_embed(const float* coords, long long period, float scale, float offset, int dim, void* out, int ldo,
                    long long rows, int accumulate, int dtype, void* stream);
 /* first cost-map convolution (encoder.py:39-41,70-75): Conv2d(1,16,6,s2,p2)+ReLU over float maps [maps][H][W]
- * (zero-extended right/bottom to Ho*2 x Wo*2) -> out [maps][Ho][Wo][ldo >= 16]; w float [36][16].
- * s2d = 1: written space-to-depth(2) as [maps][Ho/2][Wo/2][ldo >= 64] (see gvfi_space_to_depth2) */
+ * (zero-extended right/bottom to Ho*2 x Wo*2) -> out [maps][Ho][Wo][ldo >= 16]; w float [36][16] */
 int gvfi_cost_embed1(const float* vol, const float* w, const float* bias, void* out, int ldo, long long maps,
-                     int H, int W, int Ho, int Wo, int s2d, int dtype, void* stream);
-/* dst[n, y/2, x/2, ((y&1)*2 + (x&1))*C + c] = src[n, y, x, c]: in this layout the 6x6 stride-2 padding-2 cost-map
- * convolutions (encoder.py:42-49) are 3x3 stride-1 padding-1 convolutions over 4*C channels, i.e. shapes of the
- * LDS-DMA MFMA kernel (w'[co][(dy,dx,c)][a][b] = w[co][c][2a+dy][2b+dx]) */
-int gvfi_space_to_depth2(const void* src, int lds, void* dst, int ldd, int C, int N, int H, int W, int dtype,
-                         void* stream);
+                     int H, int W, int Ho, int Wo, int dtype, void* stream);
 /* MemoryDecoder.encode_flow_token (decoder.py:237-255): (2r+1)^2 bilinear taps of cost map q around coords[q] */
 int gvfi_cost_lookup(const float* maps, const float* coords, void* out, int ldo, long long Q, int h, int w,
                      int radius, int dtype, void* stream);
@@ -263,7 +257,10 @@ int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long 
  * context-aware attention of the cost encoder (twins.py:366-395, 465-493); cimg reproduces the reference's
  * context.repeat() tiling over (batch, latent token): nb = pairs per direction, K = latent tokens */
 int gvfi_ff_xqk(const void* x, int ldx, int Cx, const void* ctx, int ldc, int Cc, void* out, int ldo, int n_img,
-                int H, int W, int K, int nb, int enc_mode, int ws, int dtype, void* stream);
+                int H, int W, int K, int nb, int enc_mode, int ws, const float* enc_table, int dtype, void* stream);
+/* enc_table of gvfi_ff_xqk (optional, NULL = evaluate the code per element): float [ws*ws (enc_mode 1) or H*W (2)][Ct]
+ * = LinearPositionEmbeddingSine (attention.py:170-182) of the positions gvfi_ff_xqk adds, once per forward */
+int gvfi_ff_pos_table(float* table, int H, int W, int Ct, int enc_mode, int ws, void* stream);
 /* out[row, 0:C] = table[(row / P) % K]  (the learned latent tokens broadcast over the cost maps, encoder.py:420) */
 int gvfi_tile_rows(const float* table, void* out, int ldo, int out_f32, long long rows, int P, int K, int C,
                    int dtype, void* stream);

@@ -137,10 +137,12 @@ def xqk_case(rt, nb=2, K=3, H=5, W=6):
     P = H * W
     x = _r(rt, torch.randn(n * K, P, 128, generator=g))
     ctx = _r(rt, torch.randn(n, P, 64, generator=g))
-    for mode in (0, 1, 2):
+    for mode, use_table in ((0, False), (1, False), (2, False), (1, True), (2, True)):
         out = torch.zeros(n * K * P, 192, dtype=rt.tdtype, device=rt.device)
+        # with the table: the vector kernel + gvfi_ff_pos_table (what the engine runs); without: per-element evaluation
+        table = rt.ff_pos_table(H, W, 192, mode) if use_table else None
         rt.ff_xqk(x.reshape(-1, 128).to(rt.tdtype).to(rt.device), ctx.reshape(-1, 64).to(rt.tdtype).to(rt.device), out,
-                  n * K, H, W, K, nb, mode, 7)
+                  n * K, H, W, K, nb, mode, 7, table=table)
         refs = []
         for d in range(2):           # per direction: x batch (nb*K), context batch nb tiled by repeat
             xd = x[d * nb * K:(d + 1) * nb * K]
@@ -171,56 +173,3 @@ def tile_softmax_case(rt):
     got = y.float().cpu()
     assert float((got[:, :ncol] - x.softmax(-1)).abs().max()) <= tol(rt, 1.0)
     assert float(got[:, ncol:].abs().max()) == 0.0
-
-
-def s2d_conv_case(rt, maps=3, h=9, w=11):
-    """6x6 stride-2 padding-2 cost-map convolutions as 3x3 convolutions over space-to-depth(2) inputs
-    (GVFI_F_S2D path of engine_f): first convolution written space-to-depth, second through gvfi_space_to_depth2."""
-    from gimmvfi_hip import lib as L
-    from gimmvfi_hip.ops import ConvLayer
-
-    g = _g(9)
-    vol = torch.randn(maps, h, w, generator=g) * 2
-    w0, b0 = torch.randn(16, 1, 6, 6, generator=g) * 0.2, torch.randn(16, generator=g) * 0.1
-    w1, b1 = _r(rt, torch.randn(32, 16, 6, 6, generator=g) / 24), torch.randn(32, generator=g) * 0.1
-    w2, b2 = _r(rt, torch.randn(64, 32, 6, 6, generator=g) / 34), torch.randn(64, generator=g) * 0.1
-    hp, wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
-    e1 = rt.cost_embed1(vol.to(rt.device), w0.reshape(16, 36).t().contiguous().to(rt.device), b0.to(rt.device), maps, h, w,
-                        hp // 2, wp // 2, s2d=True)
-
-    def s2d_w(wt):
-        co, ci = wt.shape[:2]
-        return wt.reshape(co, ci, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * ci, 3, 3)
-
-    e2 = rt.act(maps, hp // 4, wp // 4, 32)
-    rt.conv(ConvLayer(rt, s2d_w(w1), b1, stride=1, pad=(1, 1)), e1, e2, act1=L.ACT_RELU)
-    e3 = rt.act(maps, hp // 8, wp // 8, 64)
-    rt.conv(ConvLayer(rt, s2d_w(w2), b2, stride=1, pad=(1, 1)), rt.space_to_depth2(e2, 32), e3)
-    x = F.pad(vol[:, None], (0, wp - w, 0, hp - h))
-    r1 = _r(rt, F.relu(F.conv2d(x, w0, b0, stride=2, padding=2)))
-    r2 = _r(rt, F.relu(F.conv2d(r1, w1, b1, stride=2, padding=2)))
-    r3 = F.conv2d(r2, w2, b2, stride=2, padding=2)
-    got = e3.float().cpu().permute(0, 3, 1, 2)
-    assert float((got - r3).abs().max()) <= 3 * tol(rt, float(r3.abs().max()) + 1.0)
-
-
-def attn_lds_case(rt):
-    """GVFI_ATTN_LDS=1: the LDS-staged window / batched-global attention variants against the same oracle functions."""
-    import os
-
-    os.environ["GVFI_ATTN_LDS"] = "1"
-    try:
-        attn_window_case(rt)                                   # ragged grid: padded window positions from kpad / vpad
-        attn_window_case(rt, B=1, H=7, W=14, C=128, heads=4)   # head_dim 32
-        g = _g(11)
-        heads, hd = 8, 16
-        C = heads * hd
-        B, N, M = 2, 70, 12                                   # N >= 64 -> LDS variant, ragged last query chunk
-        q, k, v = (_r(rt, torch.randn(B, n_, C, generator=g)) for n_ in (N, M, M))
-        ref = forc._mha(q, k, v, heads)
-        dev = lambda t: t.reshape(-1, C).to(rt.tdtype).to(rt.device)
-        out = torch.empty(B * N, C, dtype=rt.tdtype, device=rt.device)
-        rt.attn_global(dev(q), (N, 0, 1), dev(k), dev(v), (M, 0, 1), out, (N, 0, 1), B, 1, N, M, heads, hd)
-        assert float((out.float().cpu().reshape(B, N, C) - ref).abs().max()) <= 2 * tol(rt, float(ref.abs().max()) + 1.0)
-    finally:
-        del os.environ["GVFI_ATTN_LDS"]

@@ -6,7 +6,7 @@ stage, the oracle -- batch 2, so the reference's context.repeat() tiling over (b
 GPU (`-m gpu`): libgimmvfi_hip.so through the drop-in model API against the same goldens.
 
 Tolerances: fp32 mode PSNR >= 80 dB, flows within 5e-3 px (32 recurrent iterations of lookup -> GRU; measured on
-MI355X: 139 dB, 3e-5 px); bf16 mode PSNR >= 35 dB and mean flow error < 0.5 px on flows of up to 30 px (measured:
+MI355X: 139 dB, 3e-5 px); bf16 mode PSNR >= 42 dB and mean flow error < 0.25 px on flows of up to 30 px (measured:
 43.7-49.0 dB, 0.15-0.21 px with the seeded random weights -- bf16 operands through two Twins encoders, 6 context-aware
 blocks and 32 decoder iterations; flows / cost volume / coordinates / residual streams stay fp32)."""
 import os
@@ -77,22 +77,6 @@ def test_engine_f_sim_bf16(sd_f):
     assert float(d.mean()) < 0.5
 
 
-def test_engine_f_sim_s2d_switch(sd_f, monkeypatch):
-    """GVFI_F_S2D=1 (A/B switch): the 6x6 stride-2 cost-map convolutions as 3x3 convolutions over space-to-depth
-    inputs give the same result."""
-    from gimmvfi_hip.engine_f import EngineF
-    from sim_runtime import SimRuntime
-
-    monkeypatch.setenv("GVFI_F_S2D", "1")
-    meta, gold = load_golden("f_136x152_t040")
-    x, coords, ts = golden_inputs(meta)
-    eng = EngineF(SimRuntime("fp32"), sd_f)
-    assert eng.s2d
-    out = eng.forward(x, coords, ts, iters=None)
-    assert maxabs(out["raft_flow"], gold["raft_flow"]) < 2e-3
-    assert psnr(out["imgt_pred"][0], gold["imgt_pred_0"]) > 100.0
-
-
 def test_engine_f_sim_ragged_grid(sd_f):
     """136 x 152 frames -> 17 x 19 grid at 1/8: ragged 7x7 windows (bias / positional-code keys), zero-extended
     sub-sampling convolutions and cost-map patches, odd P8 (padded pitch of the GMA attention matrix)."""
@@ -158,25 +142,6 @@ def test_gpu_f_fp32_matches_reference_golden(name, sd_f):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("GVFI_TEST_UNMEASURED") != "1",
-                    reason="A/B switches are emulator-verified but not yet run on an MI355X; opt in with "
-                           "GVFI_TEST_UNMEASURED=1 (tools/f_profile.sh does)")
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("switch", ["GVFI_F_S2D", "GVFI_ATTN_LDS"])
-def test_gpu_f_ab_switches(sd_f, monkeypatch, precision, switch):
-    """A/B switches prepared for the next measurement round (off by default): GVFI_F_S2D=1 = cost-map convolutions on
-    the LDS-DMA kernel through the space-to-depth layout; GVFI_ATTN_LDS=1 = LDS-staged window / sub-sampled attention."""
-    monkeypatch.setenv(switch, "1")
-    meta, gold = load_golden("f_136x152_t040")
-    x, coords, ts = golden_inputs(meta)
-    m = _model(sd_f, precision)
-    out = _run(m, x, coords, ts)
-    assert m.engine(DEV).s2d == (switch == "GVFI_F_S2D")
-    p = psnr(out["imgt_pred"][0], gold["imgt_pred_0"])
-    assert p >= (80.0 if precision == "fp32" else 35.0), p
-
-
-@pytest.mark.gpu
 def test_gpu_f_fp32_stage_taps_vs_oracle(sd_f):
     meta, _ = load_golden("f_b2_128x128_t025_075")
     x, coords, ts = golden_inputs(meta)
@@ -202,8 +167,8 @@ def test_gpu_f_bf16_matches_reference_golden(name, sd_f):
         p = psnr(out["imgt_pred"][i], gold[f"imgt_pred_{i}"])
         d = (out["flowt"][i].cpu().float() - gold[f"flowt_{i}"]).abs().flatten()
         print(f"\n[gimmvfi_f bf16 {name} t{i}] PSNR {p:.2f} dB, mean |flow err| {float(d.mean()):.3f} px")
-        assert p >= 35.0, p
-        assert float(d.mean()) < 0.5
+        assert p >= 42.0, p
+        assert float(d.mean()) < 0.25
 
 
 @pytest.mark.gpu
