@@ -22,10 +22,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _model(sd, precision):
-    from gimmvfi_hip.model import GIMMVFI_R
+def _model(sd, precision, kind="r"):
+    from gimmvfi_hip.model import GIMMVFI_F, GIMMVFI_R
 
-    m = GIMMVFI_R(precision=precision)
+    m = (GIMMVFI_F if kind == "f" else GIMMVFI_R)(precision=precision)
     m.load_state_dict(sd, strict=True)
     return m.to(DEV).eval()
 
@@ -133,7 +133,7 @@ def run_hr(m, meta, x):
     return out
 
 
-def check_hr(out, meta, z, prec, tag):
+def check_hr(out, meta, z, prec, tag, kind="r"):
     T = meta["N"] - 1
     assert len(out["imgt_pred"]) == T
     cyx = z["crop_yx"]
@@ -163,11 +163,16 @@ def check_hr(out, meta, z, prec, tag):
         assert worst_lsb <= 1, worst_lsb                    # +-1 LSB of the 8-bit frame
         assert worst_psnr >= 60.0, worst_psnr
         assert worst_bm <= 2e-4, worst_bm
-        assert worst_flow <= 2e-3, worst_flow
-    else:
+        assert worst_flow <= (2e-3 if kind == "r" else 5e-3), worst_flow
+    elif kind == "r":
         assert worst_psnr >= 40.0, worst_psnr
         assert worst_bm <= 1e-1, worst_bm      # one 16x16 block; sub-pixel flow differences at occlusion edges
         assert worst_flow <= 0.25, worst_flow
+    else:
+        # GIMM-VFI-F bf16 with the seeded random weights: flows of up to 50 px from two Twins encoders, six context-aware
+        # blocks and 32 recurrent iterations on bf16 operands (tests/test_gimmvfi_f.py: 43.7-49 dB at <= 192 px)
+        assert worst_psnr >= 38.0, worst_psnr
+        assert worst_flow <= 1.5, worst_flow
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -178,5 +183,20 @@ def test_hires_matches_reference_fixture(sd, name, prec):
     m = _model(sd, prec)
     out = run_hr(m, meta, x)
     check_hr(out, meta, z, prec, name)
+    del out, m
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["demo_864x736", "2k_ds050", "demo2k_ds050", "4k_ds025"])
+def test_hires_f_matches_reference_fixture(sd_f, name, prec):
+    """GIMM-VFI-F (FlowFormer flow estimator, BASELINE.json configs[3]/[4]) on the same hi-res cases, against fixtures of
+    the reference's GIMMVFI_F (oracle/make_golden_hires.py --model f; Twins from the reference's vendored class, see
+    README 'timm')."""
+    meta, z = load_hr(name, "f")
+    x = hr_inputs(meta, z)
+    m = _model(sd_f, prec, "f")
+    out = run_hr(m, meta, x)
+    check_hr(out, meta, z, prec, "F " + name, "f")
     del out, m
     torch.cuda.empty_cache()
