@@ -148,16 +148,18 @@ def main():
         # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
         # figure is the committed measurement of tools/pmc_hotconv.sh (FETCH_SIZE doubled per the gfx950 note of
         # MI355X_MICROARCH.md + WRITE_SIZE), valid for the default workload's 256->256 3x3 layer only
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r1_hotconv_pmc_hbm.json")
+        traffic, pmc = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r2_hotconv_pmc.json")
         if (os.path.isfile(pmc_path) and args.model == "r" and tag.startswith("conv_igemm_glds_kernel<bf16,256,256")
                 and (B, H, W, NI, ds) == (8, 256, 448, 2, None)):
-            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]
+            pmc = json.load(open(pmc_path))
+            traffic = pmc["hbm_bytes_per_launch"]
         roofline = {
             "bound": "mfma", "kernel": tag, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": ("HBM bytes/launch from profiles/r1_hotconv_pmc_hbm.json (PMC, separate run); algorithmic 0.94 GB"
-                             if traffic is not None else "no PMC pass for this workload"),
+            "traffic_note": ("HBM bytes/launch from profiles/r2_hotconv_pmc.json (rocprofv3 PMC passes of tools/r2_call6.sh, "
+                             "FETCH_SIZE x2 + WRITE_SIZE); algorithmic 0.94 GB" if traffic is not None
+                             else "no PMC pass for this workload"),
             "launches_per_step": cnt // ev_steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
             "avg_launch_gflop": round(fl / cnt / 1e9, 3),
             "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / ev_steps * 1e3, 3),
@@ -172,6 +174,14 @@ def main():
         # volume GEMM (1.6) = 2 604 GF
         gf = {("r", 256, 448, 2, None): 2065, ("f", 256, 448, 2, None): 2604,
               ("r", 1088, 2048, 8, 0.5): 7917, ("r", 2176, 4096, 8, 0.25): 8059}.get((args.model, H, W, NI, ds))
+        if pmc is not None:
+            # MFMA pipe utilisation and effective clock of the same kernel from the PMC pass (SQ_VALU_MFMA_BUSY_CYCLES over
+            # 1024 SIMDs x GRBM_GUI_ACTIVE/8): achieved/peak ~= mfma_busy x clock/2.4 GHz -- the chip runs this kernel at its
+            # power budget, not at the 2.4 GHz the peak is quoted for
+            cyc = pmc["gui_active_cycles_per_xcd"]
+            roofline["pmc"] = {"mfma_busy_frac": round(pmc["mfma_busy_frac"], 4),
+                               "effective_clock_ghz": round(cyc / (sec / cnt) / 1e9, 3),
+                               "source": "profiles/r2_hotconv_pmc.json (separate profiled run of the same layer)"}
         if gf is not None:
             path_tf = gf * 1e9 * value / world / 1e12
             roofline["path"] = {"minimal_gflop_per_frame": gf, "achieved": round(path_tf, 1), "unit": "TFLOP/s per GPU",

@@ -128,7 +128,7 @@ class EngineF(Engine):
     def _build_flow(self, sd):
         """FlowFormer (flowformer/__init__.py:6-18, transformer.py:29-42)."""
         self.ln, self.consts = {}, {}
-        self.raft_lanes = int(os.environ.get("GVFI_F_LANES", "1"))   # parallel decoder sequences (see Engine._raft)
+        self.raft_lanes = int(os.environ.get("GVFI_F_LANES", "2"))   # parallel decoder sequences (see Engine._raft)
         fe = "flow_estimator"
         self._build_twins(sd, fe + ".context_encoder")
         me = fe + ".memory_encoder"
