@@ -175,12 +175,10 @@ def main():
         gf = {("r", 256, 448, 2, None): 2065, ("f", 256, 448, 2, None): 2604,
               ("r", 1088, 2048, 8, 0.5): 7917, ("r", 2176, 4096, 8, 0.25): 8059}.get((args.model, H, W, NI, ds))
         if pmc is not None:
-            # MFMA pipe utilisation and effective clock of the same kernel from the PMC pass (SQ_VALU_MFMA_BUSY_CYCLES over
-            # 1024 SIMDs x GRBM_GUI_ACTIVE/8): achieved/peak ~= mfma_busy x clock/2.4 GHz -- the chip runs this kernel at its
-            # power budget, not at the 2.4 GHz the peak is quoted for
-            cyc = pmc["gui_active_cycles_per_xcd"]
+            # MFMA pipe utilisation of the same kernel from the PMC pass: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+            # GRBM_GUI_ACTIVE / 8 XCDs).  achieved / peak ~= mfma_busy x effective clock / 2.4 GHz: the chip runs this kernel at
+            # its power budget (1.5-1.9 GHz by the in-kernel cycle counter), not at the clock the peak is quoted for
             roofline["pmc"] = {"mfma_busy_frac": round(pmc["mfma_busy_frac"], 4),
-                               "effective_clock_ghz": round(cyc / (sec / cnt) / 1e9, 3),
                                "source": "profiles/r2_hotconv_pmc.json (separate profiled run of the same layer)"}
         if gf is not None:
             path_tf = gf * 1e9 * value / world / 1e12

@@ -98,13 +98,17 @@ class ResultDrain:
     work already enqueued on the current stream; ``post(*host_tensors)`` runs in the consumer thread once the copy has
     landed.  ``results()`` returns {key: post result} after ``finish()``."""
 
-    def __init__(self, device, depth=8):
+    def __init__(self, device, depth=8, workers=4):
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.q = queue.Queue(maxsize=depth)
         self.out = {}
         self.err = None
+        # the copies are awaited in order by one thread; the CPU post-processing of different items (colour-coding,
+        # image encoding: numpy / PIL release the GIL) runs in a small pool so that it keeps up with the GPU
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.pending = []
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
@@ -134,13 +138,19 @@ class ResultDrain:
             try:
                 if ev is not None:
                     ev.synchronize()
-                self.out[key] = post(*hosts)
+                self.pending.append((key, self.pool.submit(post, *hosts)))
             except Exception as e:      # surfaced by finish()
                 self.err = e
 
     def finish(self):
         self.q.put(None)
         self.thread.join()
+        for key, fut in self.pending:
+            try:
+                self.out[key] = fut.result()
+            except Exception as e:
+                self.err = self.err or e
+        self.pool.shutdown(wait=True)
         if self.err is not None:
             raise self.err
         return self.out

@@ -147,18 +147,22 @@ def main(argv=None):
     flow_dir = os.path.join(args.output_path, "flow_parts")     # per-rank flow pictures, assembled by rank 0
     os.makedirs(flow_dir, exist_ok=True)
 
-    def post(j0, keep_frames):
+    def post(j0, single):
         def fn(pred_u8, flow_f):
-            # pred_u8: [b, N-1, H, W, 3] uint8 RGB ; flow_f: [b, N-1, 2, h, w].  Flow pictures are written by the rank
-            # that computed them (no collective for them); frames only come back to the host on a single-GPU run
+            # pred_u8: [b, N-1, H, W, 3] uint8 RGB ; flow_f: [b, N-1, 2, h, w].  The flow pictures are made by the rank
+            # that computed the flows (they never enter the collective): kept in memory on a single-GPU run, written to
+            # OUT/flow_parts (raw .npy, assembled by rank 0) otherwise
+            pics = []
             for bi in range(flow_f.shape[0]):
                 for i in range(flow_f.shape[1]):
                     fimg = flow_to_image(flow_f[bi, i].permute(1, 2, 0).numpy(), convert_to_bgr=True)
                     if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
                         fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
-                    Image.fromarray(np.ascontiguousarray(fimg[:, :, ::-1])).save(
-                        os.path.join(flow_dir, f"{(j0 + bi) * (N - 1) + i:06d}.png"))
-            return pred_u8.numpy() if keep_frames else None
+                    pics.append(fimg)
+            if single:
+                return pred_u8.numpy(), pics
+            np.save(os.path.join(flow_dir, f"{j0:07d}.npy"), np.stack(pics, 0))
+            return None
         return fn
 
     coord_cache = {}
@@ -189,7 +193,7 @@ def main(argv=None):
             flows = torch.stack(flows, 1).contiguous()                                              # [b, N-1, 2, h, w]
         if world > 1:
             local_dev.append(pred_u8)
-        drain.submit(j0, [pred_u8, flows], post(j0, keep_frames=(world == 1)))
+        drain.submit(j0, [pred_u8, flows], post(j0, single=(world == 1)))
     results = drain.finish()
     frames_in.close()
     if t_warm is not None and rank == 0:
@@ -205,7 +209,7 @@ def main(argv=None):
         if rank == 0:
             allf = allf.cpu().numpy()
     else:
-        allf = np.concatenate([results[j0] for j0 in range(p0, p1, bsz)], 0) if num_pairs > 0 else None
+        allf = np.concatenate([results[j0][0] for j0 in range(p0, p1, bsz)], 0) if num_pairs > 0 else None
     if rank == 0:
         originals = [to_bgr_u8(load_image(os.path.join(args.source_path, f))[0]) for f in img_list]
         images = [np.concatenate([originals[0], originals[0]], 1)]
@@ -213,7 +217,10 @@ def main(argv=None):
             for i in range(N - 1):
                 images.append(np.concatenate([originals[j], allf[j, i][:, :, ::-1]], 1))   # cv2.hconcat([orig, interp])
             images.append(np.concatenate([originals[j + 1], originals[j + 1]], 1))
-        flows = [np.array(Image.open(os.path.join(flow_dir, f)))[:, :, ::-1] for f in sorted(os.listdir(flow_dir))]
+        if world == 1:
+            flows = [pic for j0 in range(p0, p1, bsz) for pic in results[j0][1]]
+        else:
+            flows = [pic for f in sorted(os.listdir(flow_dir)) for pic in np.load(os.path.join(flow_dir, f))]
         o1 = images_to_video(images[:-1], os.path.join(args.output_path, "output.mp4"), fps=N * 2)
         o2 = images_to_video(flows, os.path.join(args.output_path, "flow.mp4"), fps=N * 2)
         shutil.rmtree(flow_dir, ignore_errors=True)
