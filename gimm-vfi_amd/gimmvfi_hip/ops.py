@@ -194,6 +194,7 @@ class Runtime:
         self.on_gpu = self.device.type == "cuda"
         self.n_launch = 0
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
+        self.use_p3x3 = os.environ.get("GVFI_P3X3", "1") != "0"   # A/B switch: 0 keeps the LDS-DMA kernel on the hot 3x3 layers
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
         self._lanes = {}         # stream id -> extra streams for lanes()
         self.last_stats_fused = False
@@ -266,9 +267,9 @@ class Runtime:
             bke_ = 8 * self.VE
             want = algo & 15
             aligned = layer.w_glds is not None and p.c0 % bke_ == 0 and p.c1 % bke_ == 0
-            if want in (0, 2) and aligned and not (algo & 128):
+            if want in (0, 2, 4) and aligned and not (algo & 128):
                 p.w, p.w_layout = layer.w_glds.data_ptr(), 1
-                algo = 2 | (algo & ~15)
+                algo = (4 if want == 4 else 2) | (algo & ~15)
             else:
                 p.w, p.w_layout = layer.w.data_ptr(), 0
             p.bias = None if layer.b is None else layer.b.data_ptr()
@@ -318,6 +319,9 @@ class Runtime:
         p.tile_hint = tile
         p.algo = algo
         p.stats = None
+        if layer is not None and want == 0 and p.w_layout == 1 and stats is None and self.use_p3x3 \
+                and self.lib.conv2d_p3x3_eligible(C.byref(p)) == 1:
+            p.algo = 4 | (algo & ~15)       # halo-staged 3x3 kernel (conv_p3x3.hip) ahead of the LDS-DMA kernel
         self.last_stats_fused = False
         if stats is not None:
             p.stats = stats.data_ptr()
@@ -338,7 +342,7 @@ class Runtime:
             self._chk(self.lib.conv2d_plan(C.byref(p), plan), "conv2d_plan")   # the library says which kernel it ran
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
-            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel"}[plan[0]]
+            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel"}[plan[0]]
             tag = f"{kname}<{'float' if self.dtype == L.F32 else 'bf16'},{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"

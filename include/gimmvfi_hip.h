@@ -83,6 +83,7 @@ typedef struct {
     int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32),   *
                                          * 3 = patch kernel (few channels, see gvfi_conv2d_patch); *
+                                         * 4 = halo-staged 3x3 kernel (gvfi_conv2d_p3x3);           *
                                          * bit 4 "pad16": the caller owns the channel padding of   *
                                          * y and res up to the next 16-byte boundary -- a ragged   *
                                          * last channel group may be accessed in whole 16-byte     *
@@ -111,6 +112,14 @@ int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
  * algo = 3. */
 int gvfi_conv2d_patch_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_patch(const gvfi_conv_params* p, void* stream);
+/* 3x3 stride-1 zero-padded bf16 convolution with Cout % 256 == 0, channel counts % 64 == 0, w_layout 1 and >= 65536
+ * output pixels -- the ResBlocks of NewMultiFlowDecoder (fi_components.py:97-154,279-340), the path's FLOP-dominant
+ * layers (csrc/conv_p3x3.hip): 16 x 16-pixel output tile whose 18 x 18 input halo is staged once per 64-channel chunk
+ * instead of once per tap.  Results are bit-identical to the LDS-DMA kernel's (same K order, same epilogue arithmetic).
+ * gvfi_conv2d routes here by itself when gvfi_conv2d_p3x3_eligible == 1 (algo 0) or with algo = 4 (eligible == 2:
+ * runnable, but fewer than 65536 output pixels); algo = 2 keeps the LDS-DMA kernel. */
+int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* p);
+int gvfi_conv2d_p3x3(const gvfi_conv_params* p, void* stream);
 
 /* ---- input preparation (gimmvfi_r.py:230-231,329-337,349; raft/raft.py:111-112) ------ */
 /* bilinear resize of float planes, align_corners=False, rscale = (float)(1.0/scale_factor)

@@ -114,6 +114,31 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     return err
 
 
+def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, with_res=False, act2=L.ACT_NONE, out_scale=1.0, seed=0, variant=0):
+    """The halo-staged 3x3 kernel (conv_p3x3.hip, algo 4) walks K in the LDS-DMA kernel's order and shares its epilogue
+    arithmetic: the two must agree bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    dev = _dev(rt)
+    w = _rounded(rt, torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    lay = ConvLayer(rt, w, torch.randn(Cout, generator=g), slope=torch.rand(Cout, generator=g) * 0.3 + 0.1)
+    x = torch.randn(N, H, W, Cin, generator=g).to(rt.tdtype).to(dev)
+    if split is None:
+        x0, x1 = View(x, 0, Cin), None
+    else:
+        xa = x[..., :split + 8].contiguous()           # a wider first source: pitch != channel count
+        xb = x[..., split:].contiguous()
+        x0, x1 = View(xa, 0, split), View(xb, 0, Cin - split)
+    res = torch.randn(N, H, W, Cout, generator=g).to(rt.tdtype).to(dev) if with_res else None
+    outs = []
+    for algo in (4 + variant, 2):
+        out = torch.full((N, H, W, Cout + 8), 7.0, dtype=rt.tdtype, device=dev)
+        rt.conv(lay, x0, View(out, 0, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
+                slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, algo=algo, tile=256)
+        outs.append(out.float().cpu())
+    assert float((outs[0][..., Cout:] - 7.0).abs().max()) == 0.0
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
 def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5, ctx_split=False):
     """SepConvGRU half step with the fused epilogues (raft/update.py:58-66)."""
     g = torch.Generator().manual_seed(seed)

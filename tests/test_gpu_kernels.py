@@ -48,6 +48,11 @@ CONV_SHAPES = [
     (2, 64, 112, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),                    # tall 256x32 tile, 128-byte chunks
     (4, 32, 56, 384, 128, 1, 5, dict(split=128, act1=L.ACT_RELU)),                            # auto -> 64-row tiles (224 workgroups)
     (1, 40, 56, 96, 96, 3, 3, dict(act1=L.ACT_RELU)),                                         # 64-byte chunks, 4-deep ring (counted vmcnt)
+    # halo-staged 3x3 kernel (conv_p3x3.hip)
+    (1, 17, 19, 64, 256, 3, 3, dict(algo=4, act1=L.ACT_PRELU, pad16=True, bf16_only=True)),
+    (1, 17, 19, 128, 256, 3, 3, dict(algo=4, split=64, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU, pad16=True, bf16_only=True)),
+    (2, 9, 17, 64, 512, 3, 3, dict(algo=4, act1=L.ACT_LRELU, out_scale=0.5, pad16=True, bf16_only=True)),
+    (4, 128, 224, 256, 256, 3, 3, dict(act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU, pad16=True, bf16_only=True)),   # auto -> p3x3
     # patch kernel (conv_patch.hip): few channels, halo patch + all weights in LDS; 8 x 64-pixel output blocks, ragged
     # tiles, 16-byte channel groups that are not a power of two per tap, odd step counts, stride 2, reflect padding
     (1, 10, 70, 9, 18, 7, 7, dict(algo=3, act1=L.ACT_PRELU)),
@@ -84,6 +89,19 @@ def test_conv(rt, shape):
     if kw.pop("bf16_only", False) and rt.precision != "bf16":
         pytest.skip("bf16-only kernel path")
     kc.conv_case(rt, *a, **kw)
+    torch.cuda.synchronize()
+
+
+def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
+    if rt.precision != "bf16":
+        pytest.skip("bf16-only kernel")
+    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU)
+    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU, variant=32)   # 4 waves of 128 x 128
+    kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1, variant=32)
+    kc.p3x3_equals_glds_case(rt, 2, 250, 443, 256, 256, split=192, seed=1)                       # ragged tiles, conv3 / conv5 geometry
+    kc.p3x3_equals_glds_case(rt, 4, 128, 224, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=2)  # final ResBlock
+    kc.p3x3_equals_glds_case(rt, 4, 128, 224, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=2, variant=32)
+    kc.p3x3_equals_glds_case(rt, 1, 136, 256, 320, 512, split=256, act1=L.ACT_LRELU, out_scale=0.5, seed=3)
     torch.cuda.synchronize()
 
 

@@ -55,6 +55,10 @@ CONV_SHAPES = [
     (1, 9, 64, 2, 16, 3, 3, dict(algo=3)),
     (1, 10, 70, 9, 18, 7, 7, dict(algo=3, act1=L.ACT_PRELU, pad16=True)),                     # whole 16-byte stores incl. pad channels
     (1, 9, 40, 18, 3, 7, 7, dict(algo=3, out_f32=True, with_res=True, pad16=True, bf16_only=True)),
+    # halo-staged 3x3 kernel (conv_p3x3.hip): ragged 16 x 16 tiles, two sources / two channel chunks, both epilogues, two Cout tiles
+    (1, 17, 19, 64, 256, 3, 3, dict(algo=4, act1=L.ACT_PRELU, pad16=True, bf16_only=True)),
+    (1, 17, 19, 128, 256, 3, 3, dict(algo=4, split=64, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU, pad16=True, bf16_only=True)),
+    (2, 9, 17, 64, 512, 3, 3, dict(algo=4, act1=L.ACT_LRELU, out_scale=0.5, pad16=True, bf16_only=True)),
     # FlowFormer (GIMM-VFI-F): patch / sub-sampling convolutions with stride == kernel and no padding, the 6x6 stride-2
     # cost-map convolutions, GELU epilogues on both kernels, token-matrix linears ([1,1,rows,C])
     (2, 16, 24, 3, 128, 4, 4, dict(stride=4, pad=0)),
@@ -75,6 +79,15 @@ def test_conv(rt, shape):
     if kw.pop("bf16_only", False) and rt.precision != "bf16":
         pytest.skip("bf16-only kernel path")
     kc.conv_case(rt, *a, **kw)
+
+
+def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
+    if rt.precision != "bf16":
+        pytest.skip("bf16-only kernel")
+    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU)
+    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU, variant=32)   # 4 waves of 128 x 128
+    kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1, variant=32)
+    kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1)
 
 
 def test_gru_epilogues(rt):

@@ -15,6 +15,8 @@ SHAPES = [
     ("final.resblock 256->256 3x3 @256x448 B8", 8, 256, 448, 256, 256, 3, 3, None),
     ("final.resblock 192+64->256 3x3", 8, 256, 448, 256, 256, 3, 3, 192),
     ("final.side 64->64 3x3", 8, 256, 448, 64, 64, 3, 3, None),
+    ("final.resblock 256->256 3x3 @544x1024 B2 (2K/4K)", 2, 544, 1024, 256, 256, 3, 3, None),
+    ("final.resblock 256->256 3x3 ragged @250x443 B4", 4, 250, 443, 256, 256, 3, 3, None),
     ("raft gru 128+256->256 1x5 @32x56 B16", 16, 32, 56, 384, 256, 1, 5, 128),
     ("raft convc2 256->192 3x3", 16, 32, 56, 256, 192, 3, 3, None),
     ("raft gruq 128+256->128 5x1", 16, 32, 56, 384, 128, 5, 1, 128),
@@ -60,7 +62,10 @@ def main():
         res = {}
         outs = {}
         # (2, 256) = 2 x 128-byte stages, DMA pieces front-loaded; +32 = pieces spread over the MFMA groups; +128 = 4 x 64-byte stages
-        variants = ((2, 0), (2, 256), (2 + 32, 256), (2 + 128, 256))
+        # 4 = halo-staged 3x3 kernel (conv_p3x3.hip); the LDS-DMA default is timed again after it (DVFS drift within the call)
+        variants = ((2, 256), (4, 0), (4 + 32, 0), (2, 256 | (1 << 20)), (4, 1 << 20), (4 + 32, 1 << 20)) if os.environ.get("P3") else ((2, 0), (2, 256), (2 + 32, 256), (2 + 128, 256))
+        with_res = bool(os.environ.get("RES"))
+        resid = rt.act(N, H // stride, W // stride, Cout) if with_res else None
         if Cin < 32:
             variants = ((1, 0), (3, 0))
         if os.environ.get("ABLATE0"):   # prologue / K loop / epilogue split on the auto tile
@@ -76,8 +81,10 @@ def main():
                 tile = 0
             try:
                 kw = dict(pad16=True) if (algo == 3 and os.environ.get("PAD16")) else {}
+                if with_res:
+                    kw.update(res=resid, act2=L.ACT_LRELU)
                 for _ in range(2):
-                    rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile, **kw)
+                    rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile & 0xfffff, **kw)
             except RuntimeError:
                 continue
             torch.cuda.synchronize()
@@ -85,14 +92,14 @@ def main():
             reps = 5
             e0.record()
             for _ in range(reps):
-                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile, **kw)
+                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile & 0xfffff, **kw)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             res[(algo, tile)] = (ms, flops / ms / 1e9)
             outs[(algo, tile)] = out.float().clone()
         ref = outs[(1, 0)] if (1, 0) in outs else next(iter(outs.values()))
-        txt = " | ".join(f"a{k[0]}t{k[1] & 1023}m{k[1] >> 10} {v[0]:7.3f} ms {v[1]:6.1f} TF/s d={float((outs[k]-ref).abs().max()):.1e}" for k, v in res.items())
+        txt = " | ".join(f"a{k[0]}t{k[1] & 1023}m{(k[1] >> 10) & 1023}{chr(39) if k[1] >> 20 else str()} {v[0]:7.3f} ms {v[1]:6.1f} TF/s d={float((outs[k]-ref).abs().max()):.1e}" for k, v in res.items())
         print(f"{name:42s} {txt}")
 
 
