@@ -110,6 +110,14 @@ template <> struct Mma2<float> {
 };
 
 
+// median of three (v_med3_f32)
+__device__ __forceinline__ float med3f(float a, float b, float c) {
+#ifndef GVFI_HOSTSIM
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#endif
+}
 // two floats -> packed bf16x2 (round to nearest even); the native cast lets hipcc emit v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #ifndef GVFI_HOSTSIM

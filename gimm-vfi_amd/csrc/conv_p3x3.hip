@@ -18,6 +18,11 @@
 #include "conv_mma.h"
 #include <type_traits>
 
+#ifndef GVFI_HOSTSIM
+#define P3_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define P3_WAVE_SYNC() emu::wave_sync()
+#endif
 #define P3_TH 16
 #define P3_TW 16
 #define P3_PW (P3_TW + 2)
@@ -34,16 +39,20 @@ struct P3Args {
     int tiles_x, tiles_y, mtiles, ntiles_n, per_xcd;
 };
 
-// WAVES_N = 4: 8 waves of 128 x 64 (2 per SIMD); WAVES_N = 2: 4 waves of 128 x 128 (1 per SIMD, 256 accumulator registers:
-// a third fewer LDS fragment reads per MFMA)
-template <int WAVES_N> __global__ void __launch_bounds__(128 * WAVES_N) conv_p3x3_kernel(P3Args a) {
+// 8 waves of 128 x 64, 2 per SIMD.  (Measured and dropped: 4 waves of 128 x 128 with 256 accumulator registers -- a third
+// fewer LDS fragment reads per MFMA, but one wave per SIMD: 0.965 vs 0.861 ms on the 8 x 256 x 448 256->256 layer.)
+// PROF (algo bit 15): wave 0 adds up shader-clock cycles per phase into aux1[block * 4 + {prologue, K loop, of which waiting
+// for the DMA + barrier, epilogue}] (tools/p3x3_timeline.py)
+template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3Args a) {
     typedef bf16_t T;
+    constexpr int WAVES_N = 4;
     constexpr int NW = 2 * WAVES_N, NT = NW * 64, WM = 128, WN = 256 / WAVES_N, MI = 4, NI = WN / 32, BN = 256, BM = 256, RB = 128, KK = 4;
     constexpr int QP = (P3_PIECES + NW - 1) / NW;      // patch pieces per wave (6 / 12)
     constexpr int PPT = (QP + 5) / 6;                  // ... of the next channel chunk issued per tap (taps 0..5)
     constexpr int B_INSTR = 32 / NW;
     constexpr int RPI = NT / 32;                       // tile rows per store-loop iteration
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P3_PATCH + 2 * P3_BSTAGE];
+    constexpr int PTAB = 2 * P3_PATCH + 2 * P3_BSTAGE;      // per-channel epilogue parameters: bias, slope 1, slope 2 (3 x 256 floats)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PTAB + 3 * 256 * 4];
     const gvfi_conv_params& p = a.p;
     const int bid = blockIdx.x;
     const int v = (bid & 7) * a.per_xcd + (bid >> 3);          // XCD-aware order, as conv_igemm_glds.hip
@@ -118,12 +127,28 @@ template <int WAVES_N> __global__ void __launch_bounds__(128 * WAVES_N) conv_p3x
     auto issue_b = [&](int kt, int i) {
         bufdma16(b_off[i], srd_b, (unsigned)(kt * p.Cout * 128), smem_lds + 2 * P3_PATCH + (kt & 1) * P3_BSTAGE + (i * NW + wave) * 1024);
     };
+    // ---- per-channel epilogue parameters -> LDS (published by the prologue barrier)
+    if (tid < 256) {
+        float* pt = (float*)(smem + PTAB);
+        pt[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+        pt[256 + tid] = p.act1 == GVFI_ACT_PRELU ? p.slope1[n0 + tid] : (p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f));
+        pt[512 + tid] = p.act2 == GVFI_ACT_PRELU ? p.slope2[n0 + tid] : (p.act2 == GVFI_ACT_NONE ? 1.f : (p.act2 == GVFI_ACT_LRELU ? 0.1f : 0.f));
+    }
     // ---- prologue: patch of chunk 0 + weights of (chunk 0, tap 0)
 #pragma unroll
     for (int q = 0; q < QP; ++q) issue_patch(0, q);
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) issue_b(0, i);
 
+    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
+    auto now = [&]() -> unsigned long long {
+#ifndef GVFI_HOSTSIM
+        return __builtin_readcyclecounter();
+#else
+        return 0;
+#endif
+    };
+    if (PROF) tprev = now();
     uint4 fa[2][MI], fb[2][NI];
     // c: channel chunk (runtime), tap / kk compile-time: the tap and k-step offsets are ds_read immediates
     unsigned pa[MI], pb[KK];        // this step's fragment base addresses
@@ -158,7 +183,7 @@ template <int WAVES_N> __global__ void __launch_bounds__(128 * WAVES_N) conv_p3x
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+                for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fb[kk & 1][j], fa[kk & 1][i]);
                 if (HAS_NEXT && kk == 0 && i == 0) {
 #pragma unroll
                     for (int q = 0; q < B_INSTR; ++q) issue_b(kt + 1, q);
@@ -171,8 +196,11 @@ template <int WAVES_N> __global__ void __launch_bounds__(128 * WAVES_N) conv_p3x
             GVFI_SCHED_BARRIER();
         }
         if (HAS_NEXT) {
+            unsigned long long tw = 0;
+            if (PROF) tw = now();
             glds_wait_n<0>();
             __syncthreads();
+            if (PROF) ph[2] += now() - tw;
             set_bases(tap == 8 ? c + 1 : c, ntap);
             load_frags(ntoff, 0, KK & 1);
             GVFI_SCHED_BARRIER();
@@ -180,7 +208,7 @@ template <int WAVES_N> __global__ void __launch_bounds__(128 * WAVES_N) conv_p3x
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[(KK - 1) & 1][i], fb[(KK - 1) & 1][j]);
+            for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fb[(KK - 1) & 1][j], fa[(KK - 1) & 1][i]);
         GVFI_SCHED_BARRIER();
     };
     auto chunk9 = [&](int c, auto last) {
@@ -196,13 +224,31 @@ template <int WAVES_N> __global__ void __launch_bounds__(128 * WAVES_N) conv_p3x
     };
     glds_wait_n<0>();
     __syncthreads();
+    if (PROF) { const unsigned long long t = now(); ph[0] = t - tprev; tprev = t; }
     set_bases(0, 0);
     load_frags(0, 0, 0);
     int c = 0;
     for (; c + 1 < a.chunks; ++c) chunk9(c, std::false_type{});
     chunk9(c, std::true_type{});
+    if (PROF) { const unsigned long long t = now(); ph[1] = t - tprev; tprev = t; }
+    auto prof_out = [&]() {
+        if (PROF && tid == 0) {
+            ph[3] = now() - tprev;
+            unsigned long long* o = (unsigned long long*)p.aux1 + (size_t)bid * 4;
+            for (int k = 0; k < 4; ++k) o[k] = ph[k];
+        }
+    };
 
-    // ---------------------------------------------------------------- epilogue (arithmetic of conv_igemm_glds.hip)
+    // ---------------------------------------------------------------- epilogue
+    // y = act2(act1(acc + bias) + res) * out_scale, the arithmetic of conv_igemm_glds.hip.  The MFMAs ran with the weights
+    // as their row operand: a lane holds ONE pixel (tile row wm*128 + i*32 + lane%32) and, per accumulator block, 4 x 4
+    // consecutive output channels (wn*64 + j*32 + 8*(r/4) + 4*(lane/32) + r%4).  Four channels are one 8-byte unit of the
+    // NHWC line, so bias / activation run as packed pairs and a ds_write_b64 stages them (the column-per-lane layout
+    // of the other kernels needs a 2-byte write and ~8 VALU operations per element: 11 of this kernel's 100 kcycles).
+    // act(t) = max(t,0) + s*min(t,0) == med3(t, s*t, s <= 1 ? +inf : -inf) for every activation this kernel takes
+    // (none: s = 1, ReLU: s = 0, leaky: s = 0.1, PReLU: per channel).
+    // Staging tile: 256 rows x 512 bytes; the 16-byte unit u of row r sits at slot u ^ (r & 15), and rows with bit 4 set
+    // swap the two 8-byte halves of a unit -- 32 lanes writing 8 bytes of 32 different rows cover the 64 banks once.
     // tile row r <-> output pixel (y0 + r/16, x0 + r%16)
     const int frow = lane & 31, fhalf = lane >> 5;
     const int my_cg = tid & 31;                         // 32 groups of 8 channels per row, RPI rows per iteration
@@ -214,116 +260,123 @@ template <int WAVES_N> __global__ void __launch_bounds__(128 * WAVES_N) conv_p3x
         ok = y < p.H && x < p.W;
         return img_pix + (long long)y * p.W + x;
     };
-    const float f1 = p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f);
-    const float f2 = p.act2 == GVFI_ACT_NONE ? 1.f : (p.act2 == GVFI_ACT_LRELU ? 0.1f : 0.f);
-    const bool has_sc = p.out_scale != 1.0f;
+    const bool has_sc = p.out_scale != 1.0f, has_res = p.res != nullptr;
+    const float* ptab = (const float*)(smem + PTAB);
     __syncthreads();   // every wave is done reading the last staged step
-    if (p.res == nullptr && p.act2 == GVFI_ACT_NONE) {
-        // plain activation: bias + activation in the accumulator layout (per-lane scalars), bf16 tile staged once
-        bf16_t* cs16 = (bf16_t*)smem;
+    if (has_res) {
+        // residual tile -> staging area (same layout: the result overwrites it in place), 128 DMA instructions of 2 rows
+        const gvfi_i32x4 srd_r = make_srd((const bf16_t*)p.res + n0);
+#pragma unroll
+        for (int q = 0; q < 128 / NW; ++q) {
+            const int piece = q * NW + wave;
+            const int row = piece * 2 + (lane >> 5);
+            bool ok;
+            const long long pix = pix_of(row, ok);
+            const unsigned off = ok ? (unsigned)(pix * p.ldr * 2 + (((lane & 31) ^ (row & 15)) << 4)) : GVFI_DMA_OOB;
+            bufdma16(off, srd_r, 0u, smem_lds + piece * 1024);
+        }
+        glds_wait_n<0>();
+        __syncthreads();
+    }
+    const float inf = __builtin_inff();
+    auto stage = [&](auto res_tag, auto sc_tag) {
+        constexpr bool RES = decltype(res_tag)::value, SC = decltype(sc_tag)::value;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int col = wn * WN + j * 32 + frow;
-            const float bj = p.bias ? p.bias[n0 + col] : 0.f;
-            const float sj = p.act1 == GVFI_ACT_PRELU ? p.slope1[n0 + col] : f1;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = wn * WN + j * 32 + 8 * g + 4 * fhalf;          // first of this lane's 4 channels (within the tile)
+                const float4 b4 = *(const float4*)(ptab + c0), s4 = *(const float4*)(ptab + 256 + c0);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, s1[4] = {s4.x, s4.y, s4.z, s4.w};
+                float s2[4] = {1.f, 1.f, 1.f, 1.f}, k1[4], k2[4];
+                if (RES) {
+                    const float4 z4 = *(const float4*)(ptab + 512 + c0);
+                    s2[0] = z4.x; s2[1] = z4.y; s2[2] = z4.z; s2[3] = z4.w;
+                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    const float t = acc[i][j][r] + bj;
-                    float vv = fmaxf(t, 0.f) + sj * fminf(t, 0.f);
-                    if (has_sc) vv *= p.out_scale;
-                    cs16[row * BN + col] = (bf16_t)(pack_bf16x2(vv, 0.f) & 0xffffu);
+                for (int e = 0; e < 4; ++e) {
+                    k1[e] = s1[e] <= 1.f ? inf : -inf;
+                    k2[e] = s2[e] <= 1.f ? inf : -inf;
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int row = wm * WM + i * 32 + frow;
+                    const int unit = row * 512 + (((c0 >> 3) ^ (row & 15)) << 4);
+                    float vv[4];
+#ifndef GVFI_HOSTSIM
+                    {   // packed pairs: v_pk_add_f32 / v_pk_mul_f32
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f2 a2 = {acc[i][j][4 * g + 2 * h], acc[i][j][4 * g + 2 * h + 1]};
+                            const f2 t2 = a2 + f2{bb[2 * h], bb[2 * h + 1]};
+                            const f2 st = t2 * f2{s1[2 * h], s1[2 * h + 1]};
+                            vv[2 * h] = med3f(t2.x, st.x, k1[2 * h]);
+                            vv[2 * h + 1] = med3f(t2.y, st.y, k1[2 * h + 1]);
+                        }
+                    }
+#else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = acc[i][j][4 * g + e] + bb[e];
+                        vv[e] = med3f(t, s1[e] * t, k1[e]);
+                    }
+#endif
+                    if (RES) {
+                        const uint2 ru = *(const uint2*)(smem + unit + (((c0 >> 2) & 1) << 3));
+                        vv[0] += __builtin_bit_cast(float, ru.x << 16);
+                        vv[1] += __builtin_bit_cast(float, ru.x & 0xffff0000u);
+                        vv[2] += __builtin_bit_cast(float, ru.y << 16);
+                        vv[3] += __builtin_bit_cast(float, ru.y & 0xffff0000u);
+#ifndef GVFI_HOSTSIM
+                        {
+                            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f2 t2 = {vv[2 * h], vv[2 * h + 1]};
+                                const f2 st = t2 * f2{s2[2 * h], s2[2 * h + 1]};
+                                vv[2 * h] = med3f(t2.x, st.x, k2[2 * h]);
+                                vv[2 * h + 1] = med3f(t2.y, st.y, k2[2 * h + 1]);
+                            }
+                        }
+#else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] = med3f(vv[e], s2[e] * vv[e], k2[e]);
+#endif
+                        P3_WAVE_SYNC();   // rows with bit 4 set: lanes l and l + 32 write the halves the other one has just read
+                    }
+                    if (SC) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] *= p.out_scale;
+                    }
+                    uint2 u;
+                    u.x = pack_bf16x2(vv[0], vv[1]);
+                    u.y = pack_bf16x2(vv[2], vv[3]);
+                    *(uint2*)(smem + unit + ((((c0 >> 2) ^ (row >> 4)) & 1) << 3)) = u;
                 }
             }
         }
-        __syncthreads();
+    };
+    if (has_res) {
+        if (has_sc) stage(std::true_type{}, std::true_type{}); else stage(std::true_type{}, std::false_type{});
+    } else {
+        if (has_sc) stage(std::false_type{}, std::true_type{}); else stage(std::false_type{}, std::false_type{});
+    }
+    __syncthreads();
 #pragma unroll 4
-        for (int it = 0; it < BM / RPI; ++it) {
-            const int row = row_a + it * RPI;
-            bool ok;
-            const long long pix = pix_of(row, ok);
-            if (!ok) continue;
-            *(uint4*)((bf16_t*)p.y + pix * p.ldy + my_cout0) = *(const uint4*)(cs16 + row * BN + my_cg * 8);
+    for (int it = 0; it < BM / RPI; ++it) {
+        const int row = row_a + it * RPI;               // (row >> 4) & 1 == it & 1: the half swap is a compile-time choice
+        bool ok;
+        const long long pix = pix_of(row, ok);
+        if (!ok) continue;
+        uint4 u = *(const uint4*)(smem + row * 512 + ((my_cg ^ (row & 15)) << 4));
+        if (it & 1) {
+            const uint4 t = u;
+            u.x = t.z; u.y = t.w; u.z = t.x; u.w = t.y;
         }
-        return;
+        *(uint4*)((bf16_t*)p.y + pix * p.ldy + my_cout0) = u;
     }
-    // residual / second activation: two fp32 passes of 128 rows (each wave stages half of its accumulator blocks per pass)
-    float gb[8], gs1[8], gs2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        gb[e] = p.bias ? p.bias[my_cout0 + e] : 0.f;
-        gs1[e] = p.act1 == GVFI_ACT_PRELU ? p.slope1[my_cout0 + e] : f1;
-        gs2[e] = p.act2 == GVFI_ACT_PRELU ? p.slope2[my_cout0 + e] : f2;
-    }
-#ifndef GVFI_HOSTSIM
-#pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(gb[e]), "v"(gs1[e]), "v"(gs2[e]));   // wait for them here (see glds)
-#endif
-    float* cs = (float*)smem;
-    const bool has_res = p.res != nullptr, has_a2 = p.act2 != GVFI_ACT_NONE;
-    constexpr int IPP = 2;     // accumulator blocks per wave and pass; staged row lr of pass ps <-> tile row tile_row(ps, lr)
-    auto tile_row = [&](int ps, int lr) { return (lr / (IPP * 32)) * WM + ps * IPP * 32 + (lr % (IPP * 32)); };
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        // all residual lines of the pass are requested before the accumulators are staged (loads and stores share the
-        // in-order vmcnt counter: nothing may be stored before the last load has been issued)
-        uint4 rr[128 / RPI];
-        long long pixs[128 / RPI];
-        bool oks[128 / RPI];
-#pragma unroll
-        for (int it = 0; it < 128 / RPI; ++it) {
-            pixs[it] = pix_of(tile_row(ps, row_a + it * RPI), oks[it]);
-            if (has_res && oks[it]) rr[it] = *(const uint4*)((const bf16_t*)p.res + pixs[it] * p.ldr + my_cout0);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            if (i / IPP != ps) continue;
-            const int lrow0 = wm * (IPP * 32) + (i - ps * IPP) * 32;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int col = wn * WN + j * 32 + frow;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cs[(lrow0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * BN + col] = acc[i][j][r];
-            }
-        }
-        __syncthreads();
-        constexpr int ITERS = 128 / RPI;
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            if (!oks[it]) continue;
-            const float* cp = cs + (row_a + it * RPI) * BN + my_cg * 8;
-            const float4 c0 = *(const float4*)cp, c1 = *(const float4*)(cp + 4);
-            float vv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t = vv[e] + gb[e];
-                vv[e] = fmaxf(t, 0.f) + gs1[e] * fminf(t, 0.f);
-            }
-            if (has_res) {
-                float r[8];
-                unpack_bf16x8(rr[it], r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] += r[e];
-            }
-            if (has_a2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] = fmaxf(vv[e], 0.f) + gs2[e] * fminf(vv[e], 0.f);
-            }
-            if (has_sc) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] *= p.out_scale;
-            }
-            uint4 u;
-            u.x = pack_bf16x2(vv[0], vv[1]);
-            u.y = pack_bf16x2(vv[2], vv[3]);
-            u.z = pack_bf16x2(vv[4], vv[5]);
-            u.w = pack_bf16x2(vv[6], vv[7]);
-            *(uint4*)((bf16_t*)p.y + pixs[it] * p.ldy + my_cout0) = u;
-        }
-        if (ps == 0) __syncthreads();
-    }
+    prof_out();
 }
 
 // 1 = gvfi_conv2d routes this problem here ahead of the LDS-DMA kernel; 2 = runnable on request (algo 4) but too few
@@ -339,6 +392,7 @@ extern "C" int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* pp) {
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15) || (p.ld0 % 8) || (p.c1 > 0 && (p.ld1 % 8))) return 0;
     // per-lane DMA offsets are 32-bit and stay below the descriptor's range: 18 image rows of the widest source
     if ((long long)18 * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) * 2 >= 0x7fffff00ll) return 0;
+    if (p.res && (long long)p.N * p.H * p.W * p.ldr * 2 >= 0x7fffff00ll) return 0;       // ... and the residual image
     return (long long)p.N * p.H * p.W >= 65536 ? 1 : 2;
 }
 
@@ -354,10 +408,10 @@ extern "C" int gvfi_conv2d_p3x3(const gvfi_conv_params* pp, void* stream) {
     a.mtiles = a.tiles_x * a.tiles_y * p.N;
     a.ntiles_n = p.Cout / 256;
     a.per_xcd = cdiv((long long)a.mtiles * a.ntiles_n, 8);
-    if (p.algo & 32) {     // A/B: 4 waves of 128 x 128
-        GVFI_LAUNCH_COOP(conv_p3x3_kernel<2>, dim3(a.per_xcd * 8), dim3(256), (hipStream_t)stream, a);
+    if (((p.algo >> 8) & 128) && p.aux1 != nullptr) {
+        GVFI_LAUNCH_COOP(conv_p3x3_kernel<true>, dim3(a.per_xcd * 8), dim3(512), (hipStream_t)stream, a);
     } else {
-        GVFI_LAUNCH_COOP(conv_p3x3_kernel<4>, dim3(a.per_xcd * 8), dim3(512), (hipStream_t)stream, a);
+        GVFI_LAUNCH_COOP(conv_p3x3_kernel<false>, dim3(a.per_xcd * 8), dim3(512), (hipStream_t)stream, a);
     }
     return (int)hipGetLastError();
 }

@@ -96,11 +96,8 @@ def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
     if rt.precision != "bf16":
         pytest.skip("bf16-only kernel")
     kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU)
-    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU, variant=32)   # 4 waves of 128 x 128
-    kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1, variant=32)
     kc.p3x3_equals_glds_case(rt, 2, 250, 443, 256, 256, split=192, seed=1)                       # ragged tiles, conv3 / conv5 geometry
     kc.p3x3_equals_glds_case(rt, 4, 128, 224, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=2)  # final ResBlock
-    kc.p3x3_equals_glds_case(rt, 4, 128, 224, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=2, variant=32)
     kc.p3x3_equals_glds_case(rt, 1, 136, 256, 320, 512, split=256, act1=L.ACT_LRELU, out_scale=0.5, seed=3)
     torch.cuda.synchronize()
 

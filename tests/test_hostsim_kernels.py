@@ -85,8 +85,6 @@ def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
     if rt.precision != "bf16":
         pytest.skip("bf16-only kernel")
     kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU)
-    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU, variant=32)   # 4 waves of 128 x 128
-    kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1, variant=32)
     kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1)
 
 

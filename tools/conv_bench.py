@@ -63,7 +63,7 @@ def main():
         outs = {}
         # (2, 256) = 2 x 128-byte stages, DMA pieces front-loaded; +32 = pieces spread over the MFMA groups; +128 = 4 x 64-byte stages
         # 4 = halo-staged 3x3 kernel (conv_p3x3.hip); the LDS-DMA default is timed again after it (DVFS drift within the call)
-        variants = ((2, 256), (4, 0), (4 + 32, 0), (2, 256 | (1 << 20)), (4, 1 << 20), (4 + 32, 1 << 20)) if os.environ.get("P3") else ((2, 0), (2, 256), (2 + 32, 256), (2 + 128, 256))
+        variants = ((2, 256), (4, 0), (2, 256 | (1 << 20)), (4, 1 << 20)) if os.environ.get("P3") else ((2, 0), (2, 256), (2 + 32, 256), (2 + 128, 256))
         with_res = bool(os.environ.get("RES"))
         resid = rt.act(N, H // stride, W // stride, Cout) if with_res else None
         if Cin < 32:
