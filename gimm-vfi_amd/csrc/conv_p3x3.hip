@@ -363,18 +363,26 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
         if (has_sc) stage(std::false_type{}, std::true_type{}); else stage(std::false_type{}, std::false_type{});
     }
     __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < BM / RPI; ++it) {
-        const int row = row_a + it * RPI;               // (row >> 4) & 1 == it & 1: the half swap is a compile-time choice
-        bool ok;
-        const long long pix = pix_of(row, ok);
-        if (!ok) continue;
-        uint4 u = *(const uint4*)(smem + row * 512 + ((my_cg ^ (row & 15)) << 4));
-        if (it & 1) {
-            const uint4 t = u;
-            u.x = t.z; u.y = t.w; u.z = t.x; u.w = t.y;
+    {   // iteration it of a thread = tile row row_a + 16 * it = pixel (y0 + it, x0 + row_a): one pointer, a constant stride
+        static_assert(RPI == P3_TW, "store loop geometry");
+        const int x = x0 + row_a;
+        bf16_t* yp = (bf16_t*)p.y + (img_pix + (long long)y0 * p.W + x) * p.ldy + my_cout0;
+        const long long ystride = (long long)p.W * p.ldy;
+        const unsigned char* sp = smem + row_a * 512 + ((my_cg ^ row_a) << 4);
+        const int nrow = x < p.W ? min(P3_TH, p.H - y0) : 0;
+        uint4 u[P3_TH];                      // all LDS reads first (the accumulator registers are free by now)
+#pragma unroll
+        for (int it = 0; it < P3_TH; ++it) {
+            const uint4 t = *(const uint4*)(sp + it * (RPI * 512));
+            if (it & 1) {                       // rows with bit 4 set hold the two 8-byte halves swapped
+                u[it].x = t.z; u[it].y = t.w; u[it].z = t.x; u[it].w = t.y;
+            } else {
+                u[it] = t;
+            }
         }
-        *(uint4*)((bf16_t*)p.y + pix * p.ldy + my_cout0) = u;
+#pragma unroll
+        for (int it = 0; it < P3_TH; ++it)
+            if (it < nrow) *(uint4*)(yp + it * ystride) = u[it];
     }
     prof_out();
 }

@@ -68,10 +68,14 @@ def main():
         resid = rt.act(N, H // stride, W // stride, Cout) if with_res else None
         if Cin < 32:
             variants = ((1, 0), (3, 0))
+        if os.environ.get("PATCH64"):    # LDS-DMA kernel against the patch kernel on the <= 64-channel layers
+            variants = ((2, 0), (3, 0), (2, 1 << 20), (3, 1 << 20))
         if os.environ.get("ABLATE0"):   # prologue / K loop / epilogue split on the auto tile
             variants = tuple((2 + 256 * m, 0) for m in (0, 8, 16, 24, 32))
         if os.environ.get("ONLY256"):     # single variant for PMC passes
             variants = ((2, 256),)
+        if os.environ.get("ONLYP3"):
+            variants = ((4, 0),)
         if os.environ.get("ABLATE"):
             variants = tuple((2 + 256 * m, 256) for m in (0, 0, 8, 16, 24))
         for algo, tile in variants:
@@ -98,6 +102,8 @@ def main():
             ms = e0.elapsed_time(e1) / reps
             res[(algo, tile)] = (ms, flops / ms / 1e9)
             outs[(algo, tile)] = out.float().clone()
+        if not outs:
+            continue
         ref = outs[(1, 0)] if (1, 0) in outs else next(iter(outs.values()))
         txt = " | ".join(f"a{k[0]}t{k[1] & 1023}m{(k[1] >> 10) & 1023}{chr(39) if k[1] >> 20 else str()} {v[0]:7.3f} ms {v[1]:6.1f} TF/s d={float((outs[k]-ref).abs().max()):.1e}" for k, v in res.items())
         print(f"{name:42s} {txt}")
