@@ -369,7 +369,7 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
         bf16_t* yp = (bf16_t*)p.y + (img_pix + (long long)y0 * p.W + x) * p.ldy + my_cout0;
         const long long ystride = (long long)p.W * p.ldy;
         const unsigned char* sp = smem + row_a * 512 + ((my_cg ^ row_a) << 4);
-        const int nrow = x < p.W ? min(P3_TH, p.H - y0) : 0;
+        const int nrow = x < p.W ? (p.H - y0 < P3_TH ? p.H - y0 : P3_TH) : 0;
         uint4 u[P3_TH];                      // all LDS reads first (the accumulator registers are free by now)
 #pragma unroll
         for (int it = 0; it < P3_TH; ++it) {
