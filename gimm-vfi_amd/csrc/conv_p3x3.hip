@@ -167,7 +167,12 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
     };
     // one (channel chunk, tap) step: 4 k-steps of 8 MFMAs; the weights of the next step (and one patch piece of the next
     // channel chunk during taps 0..5) are issued right behind the first MFMA group; the barrier that publishes them
-    // sits before the last k-step (see conv_igemm_glds.hip)
+    // sits before the last k-step (see conv_igemm_glds.hip).
+    // Measured alternatives for the issue point (same box, 8 x 256 x 448 256->256, tools/p3x3_timeline.py): right after the
+    // barrier, before the fragment reads: K loop 92.6 instead of 85.0 kcycles; behind the first MFMA group of the LAST
+    // k-step (weights two steps ahead): 91.6 kcycles, yet 0.849 against 0.833 ms -- the shader clock rises as utilisation
+    // falls (1.63 -> 1.70 GHz): the kernel runs at the chip's power limit, not at a latency limit; waves 4-7 two / four /
+    // six MFMA groups later than waves 0-3: 98.6 / 102.7 / 107.6 kcycles.
     auto step = [&](int c, auto tap_tag, auto last_chunk_tag) {
         constexpr int tap = decltype(tap_tag)::value;
         constexpr bool LAST_CHUNK = decltype(last_chunk_tag)::value;
@@ -199,6 +204,7 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
             unsigned long long tw = 0;
             if (PROF) tw = now();
             glds_wait_n<0>();
+            if (PROF) { const unsigned long long t = now(); ph[3] += t - tw; }     // (own DMA pieces landed)
             __syncthreads();
             if (PROF) ph[2] += now() - tw;
             set_bases(tap == 8 ? c + 1 : c, ntap);
@@ -206,9 +212,10 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
             GVFI_SCHED_BARRIER();
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fb[(KK - 1) & 1][j], fa[(KK - 1) & 1][i]);
+        }
         GVFI_SCHED_BARRIER();
     };
     auto chunk9 = [&](int c, auto last) {
@@ -233,7 +240,9 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
     if (PROF) { const unsigned long long t = now(); ph[1] = t - tprev; tprev = t; }
     auto prof_out = [&]() {
         if (PROF && tid == 0) {
+            const unsigned long long own = ph[3];
             ph[3] = now() - tprev;
+            ph[2] |= own << 32;      // low word: vmcnt + barrier wait, high word: the vmcnt part
             unsigned long long* o = (unsigned long long*)p.aux1 + (size_t)bid * 4;
             for (int k = 0; k < 4; ++k) o[k] = ph[k];
         }

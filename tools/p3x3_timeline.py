@@ -33,11 +33,15 @@ for name, N, H, W, Cin, Cout, KH, KW, split in SHAPES:
         rt.conv(lay, View(x, 0, Cin), out, act1=L.ACT_RELU, algo=4 + 256 * 128 + abl, aux1=st, **kw)
         e1.record()
         torch.cuda.synchronize()
-        s = st.cpu().view(-1, 4).double()
+        raw = st.cpu().view(-1, 4)
+        own = (raw[:, 2] >> 32).double()
+        raw[:, 2] &= 0xffffffff
+        s = raw.double()
+        own = own[s[:, 1] > 0]
         s = s[s[:, 1] > 0]
         us = e0.elapsed_time(e1) * 1e3
         tot = (s[:, 0] + s[:, 1] + s[:, 3]).mean()
         waves = s.shape[0] / 256.0
         print(f"{name}{' +res' if with_res else ''}: {s.shape[0]} workgroups ({waves:.1f} per CU), {us:.0f} us; cycles per workgroup "
               f"{tot:.0f} (=> {tot * waves / us:.0f} MHz if back to back): prologue {s[:, 0].mean():.0f}, K loop {s[:, 1].mean():.0f} "
-              f"(of which DMA wait + barrier {s[:, 2].mean():.0f}; 36 steps x 32 MFMA x 2 waves x 32 cycles = 73728 busy), epilogue {s[:, 3].mean():.0f}")
+              f"(of which wave 0 waits {s[:, 2].mean():.0f} for DMA + barrier, {own.mean():.0f} of that for its own DMA pieces; 36 steps x 32 MFMA x 2 waves x 32 cycles = 73728 busy), epilogue {s[:, 3].mean():.0f}")
