@@ -6,8 +6,9 @@ value     = interpolated frames / second, whole job (inputs resident in HBM befo
 multi-GPU = frame pairs shard across ranks (weak scaling: 8 pairs per rank), no data-path collective;
             the uint8 result frames are gathered to rank 0 over RCCL inside the timed region.
 
-roofline     : dominant kernel (MFMA implicit-GEMM convolution) -- algorithmic FLOPs of its launches /
-               their HIP-event durations, measured on the launch stream inside the timed steps.
+roofline     : dominant kernel = the convolution kernel with the largest total time per step (since round 2 the
+               halo-staged 3x3 kernel conv_p3x3.hip of the decoder ResBlocks) -- algorithmic FLOPs of its launches /
+               their HIP-event durations, measured on the launch stream in an eager pass right after the timed steps.
 cpu_baseline : the CPU oracle (port of the reference algorithm, oracle/gimmvfi_r_oracle.py) timed on the
                host cores on a bounded sample (B=1 pair of the same workload; thread-count sweep + median), rank 0,
                N=1 only.
@@ -123,11 +124,23 @@ def main():
         frames = world * B * (NI - 1) * args.steps       # N-1 interpolated frames per pair per step
         value = frames / dt
         # ---- roofline of the dominant kernel from the event log of the timed steps
+        # an event pair with nothing between its two records still reads a few microseconds in an eager pass (the second
+        # record is submitted by the host after the first has already executed): measured here and taken off every
+        # launch, otherwise the ~380 RAFT launches of 20 us per step are over-counted by ~10 % (rocprofv3 agrees with the
+        # corrected figures, profiles/r2_kernel_stats_r_448_v3.md)
+        gaps = []
+        for _ in range(64):
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            g1.record()
+            gaps.append((g0, g1))
+        torch.cuda.synchronize()
+        ev_gap_ms = sorted(g0.elapsed_time(g1) for g0, g1 in gaps)[len(gaps) // 2]
         agg = {}
         for tag, fl, e0, e1 in ev:
             a = agg.setdefault(tag, [0.0, 0.0, 0])
             a[0] += fl
-            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[1] += max(e0.elapsed_time(e1) - ev_gap_ms, 0.0) * 1e-3
             a[2] += 1
         if args.shapes:
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
@@ -149,21 +162,23 @@ def main():
         # figure is the committed measurement of tools/pmc_hotconv.sh (FETCH_SIZE doubled per the gfx950 note of
         # MI355X_MICROARCH.md + WRITE_SIZE), valid for the default workload's 256->256 3x3 layer only
         traffic, pmc = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r2_hotconv_pmc.json")
-        if (os.path.isfile(pmc_path) and args.model == "r" and tag.startswith("conv_igemm_glds_kernel<bf16,256,256")
-                and (B, H, W, NI, ds) == (8, 256, 448, 2, None)):
+        pmc_file = {"conv_igemm_glds_kernel<bf16,256,256": "r2_hotconv_pmc.json", "conv_p3x3_kernel<bf16,256,256": "r2_p3x3_pmc.json"}
+        pmc_name = next((v for k_, v in pmc_file.items() if tag.startswith(k_)), "none")
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+        if os.path.isfile(pmc_path) and args.model == "r" and (B, H, W, NI, ds) == (8, 256, 448, 2, None):
             pmc = json.load(open(pmc_path))
             traffic = pmc["hbm_bytes_per_launch"]
         roofline = {
             "bound": "mfma", "kernel": tag, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": ("HBM bytes/launch from profiles/r2_hotconv_pmc.json (rocprofv3 PMC passes of tools/r2_call6.sh, "
-                             "FETCH_SIZE x2 + WRITE_SIZE); algorithmic 0.94 GB" if traffic is not None
+            "traffic_note": (f"HBM bytes/launch of the 256->256 layer from profiles/{pmc_name} (rocprofv3 PMC passes of "
+                             "tools/r2_call10.sh, FETCH_SIZE x2 + WRITE_SIZE); algorithmic 0.94 GB" if traffic is not None
                              else "no PMC pass for this workload"),
             "launches_per_step": cnt // ev_steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
             "avg_launch_gflop": round(fl / cnt / 1e9, 3),
             "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / ev_steps * 1e3, 3),
-            "timing": f"HIP events around each launch, eager pass of {ev_steps} steps after the timed graph-replay region",
+            "timing": f"HIP events around each launch (minus the {ev_gap_ms * 1e3:.1f} us an empty event pair reads), eager pass of "
+                      f"{ev_steps} steps after the timed graph-replay region",
         }
         # whole-path figure SURVEY.md 8(d) asks for: MINIMAL algorithmic FLOPs per interpolated frame (redundant
         # reference work removed) x frames/s against the same dense peak.  R 448x256 T=1: 2 065 GF; R 2K DS 0.5 T=7:
@@ -179,7 +194,7 @@ def main():
             # GRBM_GUI_ACTIVE / 8 XCDs).  achieved / peak ~= mfma_busy x effective clock / 2.4 GHz: the chip runs this kernel at
             # its power budget (1.5-1.9 GHz by the in-kernel cycle counter), not at the clock the peak is quoted for
             roofline["pmc"] = {"mfma_busy_frac": round(pmc["mfma_busy_frac"], 4),
-                               "source": "profiles/r2_hotconv_pmc.json (separate profiled run of the same layer)"}
+                               "source": f"profiles/{pmc_name} (separate profiled run of the same layer)"}
         if gf is not None:
             path_tf = gf * 1e9 * value / world / 1e12
             roofline["path"] = {"minimal_gflop_per_frame": gf, "achieved": round(path_tf, 1), "unit": "TFLOP/s per GPU",

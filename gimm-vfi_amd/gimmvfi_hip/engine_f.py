@@ -151,14 +151,16 @@ class EngineF(Engine):
             self._build_vertical(sd, f"{ce}.vertical_encoder_layers.{i}.local_block", True)
             self._build_vertical(sd, f"{ce}.vertical_encoder_layers.{i}.global_block", False)
         md = fe + ".memory_decoder"
-        self._conv(sd, md + ".flow_token_encoder.0")
+        # (K = 81 cost taps padded to 128 zero-weighted channels: two whole K chunks of the LDS-DMA kernel instead of 88
+        # channels on the generic one -- 61 -> 12 us per decoder iteration)
+        self._conv(sd, md + ".flow_token_encoder.0", cin_pad=128)
         self._conv(sd, md + ".flow_token_encoder.2")
         w, b = sd[md + ".proj.weight"], sd[md + ".proj.bias"]
         self._add("ff.proj_net", w[:128], b[:128])     # tanh half   decoder.py:279-281
         self._add("ff.proj_inp", w[128:], b[128:])     # relu half
         self._build_attn_layer(sd, md + ".decoder_layer.cross_attend", False)
         u = md + ".update_block"
-        self._conv(sd, u + ".encoder.convc1", cin_pad=self.rt.cp64(145))
+        self._conv(sd, u + ".encoder.convc1", cin_pad=max(self.rt.cp64(145), 192))     # = the pitch of the cost tensor
         self.layers[u + ".encoder.convf1"] = PatchConvLayer(self.rt, sd[u + ".encoder.convf1.weight"],
                                                             sd[u + ".encoder.convf1.bias"])
         for k in ("encoder.convc2", "encoder.convf2", "encoder.conv", "flow_head.conv1", "mask.0", "mask.2"):
@@ -448,7 +450,7 @@ class EngineF(Engine):
         ca = md + ".decoder_layer.cross_attend"
         kvm = self._linear(ca + ".kv", mem)                         # [n*K*P8, 128] = [key(64) | value(64)]
         coords = rt.coords_init(n, h8, w8)
-        corr = rt.act(n, h8, w8, 145, zero=True, pitch=rt.cp64(145))    # [cost_global(64) | cost_forward(81) | 0]
+        corr = rt.act(n, h8, w8, 145, zero=True, pitch=max(rt.cp64(145), 192))    # [cost_global(64) | cost_forward(81) | 0 ...]
         corr_rows = corr.view(n * P8, corr.shape[-1])
         flow8 = rt.act(n, h8, w8, 2, zero=True)
         X = rt.act(n, h8, w8, 256)          # [motion(126) flow(2) | aggregated motion(128)]   gru.py:150-152
@@ -488,7 +490,7 @@ class EngineF(Engine):
             for it in range(iters):
                 # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
                 rt.cost_lookup(vol_s, co, View(cr, 64, 81), rows, h8, w8)
-                t1 = self._linear(md + ".flow_token_encoder.0", View(cr_rows, 64, 81), act=A.ACT_GELU)
+                t1 = self._linear(md + ".flow_token_encoder.0", View(cr_rows, 64, 128), act=A.ACT_GELU)   # 81 taps + zeros
                 query = self._linear(md + ".flow_token_encoder.2", t1)
                 # cross-attention of the one query against the map's 8 latent tokens   decoder.py:84-120
                 qn = rt.layernorm(query, self.ln[ca + ".norm1"], 1e-5)
