@@ -283,7 +283,7 @@ template <typename T> static int dispatch_conv(const gvfi_conv_params& p, hipStr
     }
 }
 
-// Which kernel gvfi_conv2d would launch for *pp: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch, 4 halo-staged 3x3), BM, BN, K-chunk bytes, LDS stages}.
+// Which kernel gvfi_conv2d would launch for *pp: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch, 4 halo-staged 3x3, 5 its mid-channel sibling), BM, BN, K-chunk bytes, LDS stages}.
 // the patch kernel (conv_patch.hip) takes what the LDS-DMA kernel cannot: few channels / reflect padding at full resolution
 static bool use_patch(const gvfi_conv_params& p) {
     if ((p.algo & 15) == 3) return true;
@@ -295,8 +295,17 @@ static bool use_p3x3(const gvfi_conv_params& p) {
     return (p.algo & 15) == 0 && gvfi_conv2d_p3x3_eligible(&p) == 1;
 }
 
+static bool use_p3x3s(const gvfi_conv_params& p) {
+    if ((p.algo & 15) == 5) return true;
+    return (p.algo & 15) == 0 && gvfi_conv2d_p3x3s_eligible(&p) == 1;
+}
+
 extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
     const gvfi_conv_params& p = *pp;
+    if (use_p3x3s(p)) {
+        plan[0] = 5; plan[1] = 256; plan[2] = p.Cout > 32 ? 64 : 32; plan[3] = 2 * p.c0; plan[4] = 2;
+        return 0;
+    }
     if (use_p3x3(p)) {
         plan[0] = 4; plan[1] = 256; plan[2] = 256; plan[3] = 128; plan[4] = 2;
         return 0;
@@ -313,6 +322,7 @@ extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
 
 extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {
     const gvfi_conv_params& p = *pp;
+    if (use_p3x3s(p)) return gvfi_conv2d_p3x3s(pp, stream);
     if (use_p3x3(p)) return gvfi_conv2d_p3x3(pp, stream);
     if ((p.algo & 15) == 2 || ((p.algo & 15) == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds(pp, stream);
     if (use_patch(p)) return gvfi_conv2d_patch(pp, stream);

@@ -267,7 +267,13 @@ class Runtime:
             bke_ = 8 * self.VE
             want = algo & 15
             aligned = layer.w_glds is not None and p.c0 % bke_ == 0 and p.c1 % bke_ == 0
-            if want in (0, 2, 4) and aligned and not (algo & 128):
+            # the mid-channel 3x3 kernel (conv_p3x3s.hip) reads the plain weight image; decided below once p is complete
+            small3 = (want in (0, 5) and self.use_p3x3 and x1 is None and layer.kh == 3 and layer.kw == 3 and layer.stride == 1
+                      and layer.cout <= 64 and p.c0 in (32, 64) and p.c0 == layer.cin_pad and self.dtype == L.BF16
+                      and (want == 5 or n * h * w_ >= 65536))
+            if want == 5:
+                p.w, p.w_layout = layer.w.data_ptr(), 0
+            elif want in (0, 2, 4) and aligned and not (algo & 128):
                 p.w, p.w_layout = layer.w_glds.data_ptr(), 1
                 algo = (4 if want == 4 else 2) | (algo & ~15)
             else:
@@ -322,6 +328,13 @@ class Runtime:
         if layer is not None and want == 0 and p.w_layout == 1 and stats is None and self.use_p3x3 \
                 and self.lib.conv2d_p3x3_eligible(C.byref(p)) == 1:
             p.algo = 4 | (algo & ~15)       # halo-staged 3x3 kernel (conv_p3x3.hip) ahead of the LDS-DMA kernel
+        if layer is not None and want == 0 and small3 and stats is None:
+            keep = (p.w, p.w_layout)
+            p.w, p.w_layout = layer.w.data_ptr(), 0
+            if self.lib.conv2d_p3x3s_eligible(C.byref(p)) == 1:
+                p.algo = 5 | (algo & ~15)   # mid-channel sibling (conv_p3x3s.hip)
+            else:
+                p.w, p.w_layout = keep
         self.last_stats_fused = False
         if stats is not None:
             p.stats = stats.data_ptr()
@@ -342,7 +355,7 @@ class Runtime:
             self._chk(self.lib.conv2d_plan(C.byref(p), plan), "conv2d_plan")   # the library says which kernel it ran
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
-            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel"}[plan[0]]
+            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel"}[plan[0]]
             tag = f"{kname}<{'float' if self.dtype == L.F32 else 'bf16'},{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"

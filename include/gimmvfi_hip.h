@@ -84,6 +84,7 @@ typedef struct {
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32),   *
                                          * 3 = patch kernel (few channels, see gvfi_conv2d_patch); *
                                          * 4 = halo-staged 3x3 kernel (gvfi_conv2d_p3x3);           *
+                                         * 5 = its mid-channel sibling (gvfi_conv2d_p3x3s);         *
                                          * bit 4 "pad16": the caller owns the channel padding of   *
                                          * y and res up to the next 16-byte boundary -- a ragged   *
                                          * last channel group may be accessed in whole 16-byte     *
@@ -120,6 +121,13 @@ int gvfi_conv2d_patch(const gvfi_conv_params* p, void* stream);
  * runnable, but fewer than 65536 output pixels); algo = 2 keeps the LDS-DMA kernel. */
 int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_p3x3(const gvfi_conv_params* p, void* stream);
+/* The same scheme for the mid-channel full-resolution layers (csrc/conv_p3x3s.hip): 3x3 stride-1 zero-padded bf16, ONE
+ * source of exactly 32 or 64 channels, Cout <= 64 (multiple of 8), plain weight image (w_layout 0), >= 65536 output
+ * pixels -- conv2 / conv4 of the decoder ResBlocks (fi_components.py:107-133), the CNN encoder's 32 -> 32 layers, the
+ * 32 <-> 64 transitions.  One patch buffer + two small weight stages: 2-5 workgroups per CU.  Bit-identical to the LDS-DMA
+ * kernel.  gvfi_conv2d routes here when gvfi_conv2d_p3x3s_eligible == 1 (algo 0) or with algo = 5. */
+int gvfi_conv2d_p3x3s_eligible(const gvfi_conv_params* p);
+int gvfi_conv2d_p3x3s(const gvfi_conv_params* p, void* stream);
 
 /* ---- input preparation (gimmvfi_r.py:230-231,329-337,349; raft/raft.py:111-112) ------ */
 /* bilinear resize of float planes, align_corners=False, rscale = (float)(1.0/scale_factor)

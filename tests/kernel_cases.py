@@ -114,7 +114,7 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     return err
 
 
-def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, with_res=False, act2=L.ACT_NONE, out_scale=1.0, seed=0, variant=0):
+def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, with_res=False, act2=L.ACT_NONE, out_scale=1.0, seed=0, variant=0, algo_new=4, ld_extra=8):
     """The halo-staged 3x3 kernel (conv_p3x3.hip, algo 4) walks K in the LDS-DMA kernel's order and shares its epilogue
     arithmetic: the two must agree bit for bit."""
     g = torch.Generator().manual_seed(seed)
@@ -130,10 +130,10 @@ def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, 
         x0, x1 = View(xa, 0, split), View(xb, 0, Cin - split)
     res = torch.randn(N, H, W, Cout, generator=g).to(rt.tdtype).to(dev) if with_res else None
     outs = []
-    for algo in (4 + variant, 2):
-        out = torch.full((N, H, W, Cout + 8), 7.0, dtype=rt.tdtype, device=dev)
+    for algo in (algo_new + variant, 2):
+        out = torch.full((N, H, W, Cout + ld_extra), 7.0, dtype=rt.tdtype, device=dev)
         rt.conv(lay, x0, View(out, 0, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
-                slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, algo=algo, tile=256)
+                slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, algo=algo, tile=256 if algo_new == 4 else 0)
         outs.append(out.float().cpu())
     assert float((outs[0][..., Cout:] - 7.0).abs().max()) == 0.0
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())

@@ -88,6 +88,17 @@ def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
     kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1)
 
 
+def test_p3x3s_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
+    """conv_p3x3s.hip (mid-channel sibling, algo 5): all four (Cin, Cout tile) instantiations, ragged tiles, Cout below
+    the tile width, residual + second activation, output scale, output slice of a wider tensor."""
+    if rt.precision != "bf16":
+        pytest.skip("bf16-only kernel")
+    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 64, 64, algo_new=5)
+    kc.p3x3_equals_glds_case(rt, 1, 17, 33, 64, 24, with_res=True, act2=L.ACT_PRELU, algo_new=5, seed=1)
+    kc.p3x3_equals_glds_case(rt, 2, 9, 20, 32, 64, act1=L.ACT_LRELU, out_scale=0.5, algo_new=5, seed=2, ld_extra=24)
+    kc.p3x3_equals_glds_case(rt, 1, 20, 18, 32, 32, with_res=True, act2=L.ACT_LRELU, algo_new=5, seed=3)
+
+
 def test_gru_epilogues(rt):
     kc.gru_case(rt, kh=1, kw=5)
     kc.gru_case(rt, kh=5, kw=1, seed=1)

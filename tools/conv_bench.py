@@ -15,6 +15,8 @@ SHAPES = [
     ("final.resblock 256->256 3x3 @256x448 B8", 8, 256, 448, 256, 256, 3, 3, None),
     ("final.resblock 192+64->256 3x3", 8, 256, 448, 256, 256, 3, 3, 192),
     ("final.side 64->64 3x3", 8, 256, 448, 64, 64, 3, 3, None),
+    ("final.side 64->64 3x3 @544x1024 B1 (4K)", 1, 544, 1024, 64, 64, 3, 3, None),
+    ("side 64->32 3x3 @256x448 B8", 8, 256, 448, 64, 32, 3, 3, None),
     ("final.resblock 256->256 3x3 @544x1024 B2 (2K/4K)", 2, 544, 1024, 256, 256, 3, 3, None),
     ("final.resblock 256->256 3x3 ragged @250x443 B4", 4, 250, 443, 256, 256, 3, 3, None),
     ("raft gru 128+256->256 1x5 @32x56 B16", 16, 32, 56, 384, 256, 1, 5, 128),
@@ -68,6 +70,8 @@ def main():
         resid = rt.act(N, H // stride, W // stride, Cout) if with_res else None
         if Cin < 32:
             variants = ((1, 0), (3, 0))
+        if os.environ.get("P3S"):        # LDS-DMA kernel against the mid-channel halo-staged kernel (conv_p3x3s.hip)
+            variants = ((2, 0), (5, 0), (2, 1 << 20), (5, 1 << 20))
         if os.environ.get("PATCH64"):    # LDS-DMA kernel against the patch kernel on the <= 64-channel layers
             variants = ((2, 0), (3, 0), (2, 1 << 20), (3, 1 << 20))
         if os.environ.get("ABLATE0"):   # prologue / K loop / epilogue split on the auto tile
