@@ -6,7 +6,7 @@
 //   * 16 x 16-pixel output tile, its 18 x 18 halo patch staged ONCE (pixel pitch = channel bytes + 16: conflict-free
 //     ds_read_b128 fragment reads, a tap is a constant address offset), so the K loop DMAs only weights: 9 steps of
 //     BN x (2 CK) bytes from the plain [Cout][3][3][Cin] image, slot-swizzled on the fly;
-//   * one patch buffer + two small weight stages = 30-64 KB of LDS: 2-5 workgroups per CU overlap each other's prologue,
+//   * one patch buffer + a ring of small weight stages = 35-80 KB of LDS: 2-4 workgroups per CU overlap each other's prologue,
 //     barriers and epilogue (the 256 x 256 tile of conv_p3x3.hip owns the CU alone);
 //   * 4 waves, each 64 pixels x all BN output channels (an A fragment feeds BN / 32 MFMAs, a B fragment two);
 //   * pixel-per-lane accumulators (weights are the MFMA row operand) and the packed epilogue of conv_p3x3.hip: bias /
@@ -20,15 +20,22 @@ struct P3sArgs {
     int tiles_x, tiles_y, mtiles, per_xcd;
 };
 
-template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kernel(P3sArgs a) {
+template <int BN, int CK, bool PROF = false> __global__ void __launch_bounds__(256) conv_p3x3s_kernel(P3sArgs a) {
     typedef bf16_t T;
     constexpr int NW = 4, NT = 256, WM = 64, MI = 2, NI = BN / 32, RBK = CK * 2, KK = CK / 16, BM = 256;
     constexpr int PW = 18, PIX = 18 * 18, PITCH = RBK + 16, SPP = RBK / 16 + 1;    // 16-byte slots per patch pixel incl. the pad slot
     constexpr int PIECES = (PIX * SPP + 63) / 64, PATCH = PIECES * 1024, QP = (PIECES + NW - 1) / NW;
     constexpr int BSTAGE = BN * RBK, BP = BSTAGE / 1024, B_INSTR = (BP + NW - 1) / NW;
+    // weight ring: 4 stages for 64 input channels (the DMA of tap t+3 is issued during tap t: a tap is only 16-32 MFMAs per
+    // wave, less than the ~1 us a DMA takes to land; the patch limits these variants to 2 workgroups per CU either way), 2
+    // stages for 32 input channels (3-4 workgroups per CU hide the wait; a deeper ring would cost one of them).
+    // Measured (tools/p3x3s_timeline.py, 64 -> 64 at 8 x 256 x 448): 25 kcycles per workgroup = prologue 10.5 k (the 512
+    // resident workgroups request their 47 KB patches in the same microseconds: an HBM burst) + K loop 8.8 k + epilogue 5.7 k,
+    // two workgroups per CU overlapping: 235 MB in 98 us = 2.4 TB/s, against 0.133 ms on the LDS-DMA kernel.
+    constexpr int NSTB = (CK == 64 && BP % NW == 0) ? 4 : 2, AHEAD = NSTB - 1, CNT = BP / NW;
     constexpr int SP = BN * 2 + 16, STAGING = BM * SP;           // epilogue staging: 256 rows of BN bf16 + 16 bytes
     constexpr int RP = (STAGING + 1023) / 1024, RQ = (RP + NW - 1) / NW;
-    constexpr int MAIN = (PATCH + 2 * BSTAGE > RP * 1024) ? PATCH + 2 * BSTAGE : RP * 1024;
+    constexpr int MAIN = (PATCH + NSTB * BSTAGE > RP * 1024) ? PATCH + NSTB * BSTAGE : RP * 1024;
     constexpr int U = BN / 8, RPI = NT / U;                      // 16-byte units per output row, rows per store iteration
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 3 * BN * 4];
     const gvfi_conv_params& p = a.p;
@@ -44,6 +51,16 @@ template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kern
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const T* __restrict__ xs0 = (const T*)p.x0;
+    // PROF (algo bit 15): wave 0 writes shader-clock cycles of {prologue, K loop, epilogue, start time} to aux1[block * 4 ..]
+    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
+    auto now = [&]() -> unsigned long long {
+#ifndef GVFI_HOSTSIM
+        return __builtin_readcyclecounter();
+#else
+        return 0;
+#endif
+    };
+    if (PROF) { tprev = now(); ph[3] = tprev; }
 
     // ---- patch DMA: per-lane byte offsets relative to the patch origin (image pixel (y0-1, x0-1), may lie in the padding)
     unsigned a_off[QP];
@@ -94,7 +111,7 @@ template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kern
     auto issue_b = [&](int tap) {
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i)
-            if (i * NW + wave < BP) bufdma16(b_off[i], srd_b, (unsigned)(tap * RBK), smem_lds + PATCH + (tap & 1) * BSTAGE + (i * NW + wave) * 1024);
+            if (i * NW + wave < BP) bufdma16(b_off[i], srd_b, (unsigned)(tap * RBK), smem_lds + PATCH + (tap % NSTB) * BSTAGE + (i * NW + wave) * 1024);
     };
     // ---- per-channel epilogue parameters -> LDS (published by the prologue barrier)
     if (tid < BN) {
@@ -108,17 +125,18 @@ template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kern
 #pragma unroll
     for (int q = 0; q < QP; ++q)
         if (q * NW + wave < PIECES) bufdma16(a_off[q], srd_a, 0u, smem_lds + (q * NW + wave) * 1024);
-    issue_b(0);
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) issue_b(t);
 
     uint4 fa[2][MI], fb[2][NI];
     auto load_frags = [&](int tap, int toff, int kk, int buf) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[buf][i] = *(const uint4*)(smem + abase[i] + toff + kk * 32);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) fb[buf][j] = *(const uint4*)(smem + b_rd[kk] + (tap & 1) * BSTAGE + j * 32 * RBK);
+        for (int j = 0; j < NI; ++j) fb[buf][j] = *(const uint4*)(smem + b_rd[kk] + (tap % NSTB) * BSTAGE + j * 32 * RBK);
     };
-    // one tap: KK k-steps of MI x NI MFMAs; the weights of the next tap are issued behind the first MFMA group, the barrier
-    // that publishes them sits before the last k-step (conv_p3x3.hip / conv_igemm_glds.hip)
+    // one tap: KK k-steps of MI x NI MFMAs; the weights of tap + AHEAD are issued behind the first MFMA group, the barrier
+    // that publishes tap + 1 sits before the last k-step (conv_p3x3.hip / conv_igemm_glds.hip)
     auto step = [&](auto tap_tag) {
         constexpr int tap = decltype(tap_tag)::value;
         constexpr bool HAS_NEXT = tap < 8;
@@ -132,12 +150,14 @@ template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kern
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fb[kk & 1][j], fa[kk & 1][i]);
-                if (HAS_NEXT && kk == 0 && i == 0) issue_b(tap + 1);
+                if (tap + AHEAD <= 8 && kk == 0 && i == 0) issue_b(tap + AHEAD);
             }
             GVFI_SCHED_BARRIER();
         }
         if (HAS_NEXT) {
-            glds_wait_n<0>();
+            // the weights of tap + 1 have landed once only the younger stages (tap + 2 .. tap + AHEAD) are outstanding
+            constexpr int later = (tap + AHEAD < 8 ? tap + AHEAD : 8) - (tap + 1);
+            glds_wait_n<later * CNT>();
             __syncthreads();
             load_frags(tap + 1, ntoff, 0, KK & 1);
             GVFI_SCHED_BARRIER();
@@ -148,8 +168,9 @@ template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kern
             for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fb[(KK - 1) & 1][j], fa[(KK - 1) & 1][i]);
         GVFI_SCHED_BARRIER();
     };
-    glds_wait_n<0>();
+    glds_wait_n<(AHEAD - 1) * CNT>();
     __syncthreads();
+    if (PROF) { const unsigned long long t = now(); ph[0] = t - tprev; tprev = t; }
     load_frags(0, 0, 0, 0);
     step(std::integral_constant<int, 0>{});
     step(std::integral_constant<int, 1>{});
@@ -160,6 +181,7 @@ template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kern
     step(std::integral_constant<int, 6>{});
     step(std::integral_constant<int, 7>{});
     step(std::integral_constant<int, 8>{});
+    if (PROF) { const unsigned long long t = now(); ph[1] = t - tprev; tprev = t; }
 
     // ---------------------------------------------------------------- epilogue (conv_p3x3.hip): y = act2(act1(acc + bias) + res) * out_scale
     // a lane holds one pixel (tile row wave*64 + i*32 + lane%32) and per accumulator block 4 x 4 consecutive output channels
@@ -275,6 +297,11 @@ template <int BN, int CK> __global__ void __launch_bounds__(256) conv_p3x3s_kern
             if (ok && cok) *(uint4*)((bf16_t*)p.y + pix * p.ldy + cg * 8) = u[it];
         }
     }
+    if (PROF && tid == 0) {
+        ph[2] = now() - tprev;
+        unsigned long long* o = (unsigned long long*)p.aux1 + (size_t)bid * 4;
+        for (int k = 0; k < 4; ++k) o[k] = ph[k];
+    }
 }
 
 // 1 = gvfi_conv2d routes this problem here ahead of the LDS-DMA kernel; 2 = runnable on request (algo 5) but too few output
@@ -305,7 +332,9 @@ extern "C" int gvfi_conv2d_p3x3s(const gvfi_conv_params* pp, void* stream) {
     a.per_xcd = cdiv((long long)a.mtiles, 8);
     const dim3 grid(a.per_xcd * 8), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (p.c0 == 64) {
+    if (((p.algo >> 8) & 128) && p.aux1 != nullptr && p.c0 == 64 && p.Cout > 32) {
+        GVFI_LAUNCH_COOP((conv_p3x3s_kernel<64, 64, true>), grid, block, st, a);
+    } else if (p.c0 == 64) {
         if (p.Cout > 32) { GVFI_LAUNCH_COOP((conv_p3x3s_kernel<64, 64>), grid, block, st, a); }
         else { GVFI_LAUNCH_COOP((conv_p3x3s_kernel<32, 64>), grid, block, st, a); }
     } else {
