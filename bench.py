@@ -112,6 +112,11 @@ def main():
         rt.ev_shapes = bool(args.shapes)
         ev_steps = max(1, min(args.steps, 3))
         for _ in range(ev_steps):
+            # keep the stream backlogged: the host needs ~15 us per launch in this eager pass, the ~380 RAFT kernels of a step
+            # run ~20 us each -- without a head start the GPU drains the queue there and every event pair also brackets
+            # the host's submit latency (the 20 us kernels read 24 us; rocprofv3 says 21.6).  A 25 ms spin kernel in front of
+            # the step lets the host run ahead of the GPU for the whole step.
+            torch.cuda._sleep(50_000_000)
             model(x, coords, t=ts, ds_factor=ds)
         torch.cuda.synchronize()
         rt.ev_log = None
@@ -124,23 +129,31 @@ def main():
         frames = world * B * (NI - 1) * args.steps       # N-1 interpolated frames per pair per step
         value = frames / dt
         # ---- roofline of the dominant kernel from the event log of the timed steps
-        # an event pair with nothing between its two records still reads a few microseconds in an eager pass (the second
-        # record is submitted by the host after the first has already executed): measured here and taken off every
-        # launch, otherwise the ~380 RAFT launches of 20 us per step are over-counted by ~10 % (rocprofv3 agrees with the
-        # corrected figures, profiles/r2_kernel_stats_r_448_v3.md)
-        gaps = []
-        for _ in range(64):
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record()
-            g1.record()
-            gaps.append((g0, g1))
+        # What an event pair adds to a back-to-back launch (the two timestamp packets), calibrated in-process on a backlogged
+        # stream: 200 small kernels inside ONE pair against the same 200 kernels each inside its own pair.  It is taken off
+        # every launch: ~2.5 us is nothing for the 0.85 ms hot kernel but 12 % of the ~380 RAFT launches per step
+        # (rocprofv3: 21.6 us average; uncorrected pairs read 24.5 us).
+        cal = torch.zeros(1 << 20, device=dev)
+        torch.cuda._sleep(30_000_000)
+        ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ca.record()
+        for _ in range(200):
+            cal.add_(1.0)
+        cb.record()
+        pairs = []
+        for _ in range(200):
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            cal.add_(1.0)
+            c1.record()
+            pairs.append((c0, c1))
         torch.cuda.synchronize()
-        ev_gap_ms = sorted(g0.elapsed_time(g1) for g0, g1 in gaps)[len(gaps) // 2]
+        ev_over_ms = max(sum(c0.elapsed_time(c1) for c0, c1 in pairs) / 200 - ca.elapsed_time(cb) / 200, 0.0)
         agg = {}
         for tag, fl, e0, e1 in ev:
             a = agg.setdefault(tag, [0.0, 0.0, 0])
             a[0] += fl
-            a[1] += max(e0.elapsed_time(e1) - ev_gap_ms, 0.0) * 1e-3
+            a[1] += max(e0.elapsed_time(e1) - ev_over_ms, 1e-3) * 1e-3
             a[2] += 1
         if args.shapes:
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
@@ -177,8 +190,9 @@ def main():
             "launches_per_step": cnt // ev_steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
             "avg_launch_gflop": round(fl / cnt / 1e9, 3),
             "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / ev_steps * 1e3, 3),
-            "timing": f"HIP events around each launch (minus the {ev_gap_ms * 1e3:.1f} us an empty event pair reads), eager pass of "
-                      f"{ev_steps} steps after the timed graph-replay region",
+            "timing": f"HIP events around each launch, eager pass of {ev_steps} steps (each behind a 25 ms spin kernel, so the "
+                      "stream stays backlogged and a pair brackets only its kernel) after the timed graph-replay region; "
+                      f"{ev_over_ms * 1e3:.2f} us per pair (calibrated in-process: what a pair adds to a back-to-back launch) taken off",
         }
         # whole-path figure SURVEY.md 8(d) asks for: MINIMAL algorithmic FLOPs per interpolated frame (redundant
         # reference work removed) x frames/s against the same dense peak.  R 448x256 T=1: 2 065 GF; R 2K DS 0.5 T=7:

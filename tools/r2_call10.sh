@@ -1,6 +1,6 @@
 # Round-2 evidence call after the halo-staged 3x3 kernel (conv_p3x3.hip): whole GPU suite, bench lines, kernel-trace
 # summaries, PMC passes of the new dominant kernel.
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/r2i; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/r2m; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -rP --durations=10 > $O/gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests.log
 grep -E "^(448x256|demo|2k_|4k_|demo2k|F |SNU|XTEST|CLI)|passed|failed|rc " $O/gpu_tests.log
 timeout 300 python bench.py --shapes $O/conv_shapes_r_448.md > $O/bench_r_448.json 2> $O/bench_r_448.err; tail -1 $O/bench_r_448.json | cut -c1-250
