@@ -725,6 +725,8 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
 extern "C" int gvfi_conv2d_stats_ok(const gvfi_conv_params* pp) {
     const gvfi_conv_params& p = *pp;
     int plan[5];
+    // the mid-channel halo-staged kernel (conv_p3x3s.hip) accumulates them in its store loop too
+    if ((p.algo & 15) == 5 || ((p.algo & 15) == 0 && gvfi_conv2d_p3x3s_eligible(pp) == 1)) return gvfi_conv2d_p3x3s_eligible(pp) != 0;
     if (p.dtype != GVFI_BF16 || (p.algo & 15) == 1 || !((p.algo & 15) == 2 || gvfi_conv2d_glds_eligible(pp))) return 0;
     if (gvfi_conv2d_glds_plan(pp, plan) != 0 || plan[2] >= 256) return 0;   // (not in the 8-wave tile)
     if (p.epi_mode != GVFI_EPI_STD || p.y_f32 || (p.res && p.res_f32) || p.act1 > GVFI_ACT_PRELU || p.act2 > GVFI_ACT_PRELU)

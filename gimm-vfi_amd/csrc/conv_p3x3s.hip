@@ -10,7 +10,8 @@
 //     barriers and epilogue (the 256 x 256 tile of conv_p3x3.hip owns the CU alone);
 //   * 4 waves, each 64 pixels x all BN output channels (an A fragment feeds BN / 32 MFMAs, a B fragment two);
 //   * pixel-per-lane accumulators (weights are the MFMA row operand) and the packed epilogue of conv_p3x3.hip: bias /
-//     activation on pairs, v_med3 activation, 8-byte staging writes, residual tile by LDS-DMA, 16-byte stores.
+//     activation on pairs, v_med3 activation, 8-byte staging writes, residual tile by LDS-DMA, 16-byte stores, fused
+//     InstanceNorm statistics (gvfi_conv_params.stats) like the LDS-DMA kernel's.
 // Results are bit-identical to the LDS-DMA kernel's (same K order: tap outer, channel inner; same epilogue arithmetic).
 #include "conv_mma.h"
 #include <type_traits>
@@ -290,11 +291,46 @@ template <int BN, int CK, bool PROF = false> __global__ void __launch_bounds__(2
         uint4 u[BM / RPI];
 #pragma unroll
         for (int it = 0; it < BM / RPI; ++it) u[it] = *(const uint4*)(smem + (row_a + it * RPI) * SP + cg * 16);
+        float st_sum[8], st_sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_sum[e] = st_sq[e] = 0.f;
+        const bool do_stats = p.stats != nullptr;
 #pragma unroll
         for (int it = 0; it < BM / RPI; ++it) {
             bool ok;
             const long long pix = pix_of(row_a + it * RPI, ok);
-            if (ok && cok) *(uint4*)((bf16_t*)p.y + pix * p.ldy + cg * 8) = u[it];
+            if (ok && cok) {
+                *(uint4*)((bf16_t*)p.y + pix * p.ldy + cg * 8) = u[it];
+                if (do_stats) {   // fused InstanceNorm statistics of the values as stored (bf16-rounded), as conv_igemm_glds.hip
+                    float sv[8];
+                    unpack_bf16x8(u[it], sv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        st_sum[e] += sv[e];
+                        st_sq[e] += sv[e] * sv[e];
+                    }
+                }
+            }
+        }
+        if (do_stats) {   // workgroup reduction through the staging area: one atomic pair per (image, channel); a tile lies in one image
+            __syncthreads();
+            float* red = (float*)smem;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[tid * 16 + e] = st_sum[e];
+                red[tid * 16 + 8 + e] = st_sq[e];
+            }
+            __syncthreads();
+            if (tid < BN && tid < p.Cout) {
+                const int cgi = tid >> 3, e = tid & 7;
+                float s0 = 0.f, s1 = 0.f;
+                for (int t = cgi; t < NT; t += U) {
+                    s0 += red[t * 16 + e];
+                    s1 += red[t * 16 + 8 + e];
+                }
+                atomicAdd(p.stats + ((long long)img * p.Cout + tid) * 2 + 0, s0);
+                atomicAdd(p.stats + ((long long)img * p.Cout + tid) * 2 + 1, s1);
+            }
         }
     }
     if (PROF && tid == 0) {
@@ -309,7 +345,7 @@ template <int BN, int CK, bool PROF = false> __global__ void __launch_bounds__(2
 extern "C" int gvfi_conv2d_p3x3s_eligible(const gvfi_conv_params* pp) {
     const gvfi_conv_params& p = *pp;
     if (p.dtype != GVFI_BF16 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return 0;
-    if (p.pad_mode != GVFI_PAD_ZEROS || p.groups > 1 || p.epi_mode != GVFI_EPI_STD || p.w_layout != 0 || p.stats != nullptr) return 0;
+    if (p.pad_mode != GVFI_PAD_ZEROS || p.groups > 1 || p.epi_mode != GVFI_EPI_STD || p.w_layout != 0) return 0;
     if ((p.c0 != 32 && p.c0 != 64) || p.c1 != 0 || p.Cout <= 0 || p.Cout > 64 || (p.Cout % 8)) return 0;
     if (p.Ho != p.H || p.Wo != p.W) return 0;
     if (p.y_f32 || (p.res != nullptr && p.res_f32) || p.act1 > GVFI_ACT_PRELU || p.act2 > GVFI_ACT_PRELU) return 0;

@@ -328,7 +328,7 @@ class Runtime:
         if layer is not None and want == 0 and p.w_layout == 1 and stats is None and self.use_p3x3 \
                 and self.lib.conv2d_p3x3_eligible(C.byref(p)) == 1:
             p.algo = 4 | (algo & ~15)       # halo-staged 3x3 kernel (conv_p3x3.hip) ahead of the LDS-DMA kernel
-        if layer is not None and want == 0 and small3 and stats is None:
+        if layer is not None and want == 0 and small3:
             keep = (p.w, p.w_layout)
             p.w, p.w_layout = layer.w.data_ptr(), 0
             if self.lib.conv2d_p3x3s_eligible(C.byref(p)) == 1:

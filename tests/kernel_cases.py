@@ -224,7 +224,7 @@ def patch_conv_case(rt, N=2, H=10, W=13, Cin=2, Cout=24, KH=7, KW=7):
     assert err <= tol(rt, 4.0), err
 
 
-def conv_stats_case(rt, N=2, H=16, W=16, Cin=64, Cout=64, tile=0):
+def conv_stats_case(rt, N=2, H=16, W=16, Cin=64, Cout=64, tile=0, algo=0):
     """InstanceNorm statistics fused into the convolution's store loop == sums over the stored tensor."""
     assert rt.precision == "bf16"
     g = torch.Generator().manual_seed(14)
@@ -236,7 +236,7 @@ def conv_stats_case(rt, N=2, H=16, W=16, Cin=64, Cout=64, tile=0):
     xa = _to_act(rt, x).to(dev)
     out = rt.act(N, H, W, Cout)
     stats = rt.f32(N, Cout, 2, zero=True)
-    rt.conv(lay, xa, out, stats=stats, tile=tile)
+    rt.conv(lay, xa, out, stats=stats, tile=tile, algo=algo)
     assert rt.last_stats_fused
     o = out.float().cpu()
     ref = torch.stack([o.sum((1, 2)), (o * o).sum((1, 2))], -1)          # [N, Cout, 2] of the stored (rounded) values
@@ -246,6 +246,8 @@ def conv_stats_case(rt, N=2, H=16, W=16, Cin=64, Cout=64, tile=0):
     y = rt.instnorm(out, Cout, relu=False, stats=stats).t.float().cpu()
     n = F.instance_norm(o.permute(0, 3, 1, 2), eps=1e-5).permute(0, 2, 3, 1)
     assert float((y - n).abs().max()) <= tol(rt, 4.0)
+    if algo == 5:      # (the halo-staged kernel's tiles never straddle images)
+        return
     # a shape whose tiles straddle images is refused (caller falls back to gvfi_instnorm_stats)
     out2 = rt.act(N, H - 1, W - 5, Cout)
     rt.conv(lay, _to_act(rt, x[:, :, :H - 1, :W - 5]).to(dev), out2, stats=rt.f32(N, Cout, 2, zero=True))

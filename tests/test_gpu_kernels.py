@@ -137,6 +137,8 @@ def test_conv_fused_instnorm_stats(rt):
         pytest.skip("fused statistics live in the bf16 store loop; fp32 runs gvfi_instnorm_stats")
     kc.conv_stats_case(rt)
     kc.conv_stats_case(rt, N=1, H=8, W=16, Cin=64, Cout=96)
+    kc.conv_stats_case(rt, N=2, H=17, W=19, Cin=64, Cout=64, algo=5)      # mid-channel halo-staged kernel, ragged tiles
+    kc.conv_stats_case(rt, N=1, H=16, W=33, Cin=32, Cout=24, algo=5)
 
 
 def test_tap_split_conv(rt):
