@@ -581,6 +581,15 @@ class Runtime:
         self._chk(self.lib.softmax_rows(x.data_ptr(), n, o.ptr, o.ld, rows, self.dtype, self.stream()), "softmax_rows")
         return out
 
+    def flow_to_image(self, flows, wheel, bgr=True):
+        """flows: [n, 2, h, w] float (contiguous) -> [n, h, w, 3] uint8 pictures (reference flow_viz.flow_to_image per image)."""
+        n, _, h, w = flows.shape
+        out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=self.device)
+        scratch = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.flow_to_image(flows.data_ptr(), 2 * h * w, n, h, w, wheel.data_ptr(), scratch.data_ptr(), out.data_ptr(),
+                                         1 if bgr else 0, self.stream()), "flow_to_image")
+        return out
+
     def frames_to_u8(self, frames_nchw):
         b, _, h, w = frames_nchw.shape
         out = torch.empty((b, h, w, 3), dtype=torch.uint8, device=self.device)

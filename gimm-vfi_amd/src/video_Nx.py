@@ -24,7 +24,7 @@ from PIL import Image
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from models import create_model  # noqa: E402
-from utils.flow_viz import flow_to_image  # noqa: E402
+from utils.flow_viz import make_colorwheel  # noqa: E402
 from utils.setup import single_setup  # noqa: E402
 from utils.utils import InputPadder, set_seed  # noqa: E402
 
@@ -87,8 +87,14 @@ def images_to_video(imgs, output_video_path, fps=15):
         return output_video_path
     frame_dir = os.path.splitext(output_video_path)[0] + "_frames"
     os.makedirs(frame_dir, exist_ok=True)
-    for idx, img in enumerate(imgs):
-        Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(os.path.join(frame_dir, f"{idx:04d}.png"))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def save(item):     # (zlib releases the GIL: the frames compress in parallel; level 1 is ~4x faster than PIL's default 6)
+        idx, img = item
+        Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(os.path.join(frame_dir, f"{idx:04d}.png"), compress_level=1)
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(save, enumerate(imgs)))
     if shutil.which("ffmpeg"):
         subprocess.run(["ffmpeg", "-y", "-framerate", f"{fps}", "-i", f"{frame_dir}/%04d.png", "-c:v", "libx264",
                         "-pix_fmt", "yuv420p", output_video_path])
@@ -147,24 +153,29 @@ def main(argv=None):
     flow_dir = os.path.join(args.output_path, "flow_parts")     # per-rank flow pictures, assembled by rank 0
     os.makedirs(flow_dir, exist_ok=True)
 
+    wheel = torch.from_numpy(make_colorwheel()).float().to(device)
+
     def post(j0, single):
-        def fn(pred_u8, flow_f):
-            # pred_u8: [b, N-1, H, W, 3] uint8 RGB ; flow_f: [b, N-1, 2, h, w].  The flow pictures are made by the rank
-            # that computed the flows (they never enter the collective): kept in memory on a single-GPU run, written to
-            # OUT/flow_parts (raw .npy, assembled by rank 0) otherwise
+        def fn(pred_u8, pics_u8):
+            tq = time.perf_counter()
+            # pred_u8: [b, N-1, H, W, 3] uint8 RGB ; pics_u8: [b*(N-1), h, w, 3] uint8 BGR flow pictures, colour-coded on the
+            # GPU (gvfi_flow_to_image: the numpy coding of seven 2K pictures per pair cost the host 3x the model's time).
+            # They are made by the rank that computed the flows (they never enter the collective): kept in memory on a
+            # single-GPU run, written to OUT/flow_parts (raw .npy, assembled by rank 0) otherwise
             pics = []
-            for bi in range(flow_f.shape[0]):
-                for i in range(flow_f.shape[1]):
-                    fimg = flow_to_image(flow_f[bi, i].permute(1, 2, 0).numpy(), convert_to_bgr=True)
-                    if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
-                        fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
-                    pics.append(fimg)
+            for fimg in pics_u8.numpy():
+                if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
+                    fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
+                pics.append(fimg)
+            if prof is not None:
+                prof["post"] += time.perf_counter() - tq
             if single:
                 return pred_u8.numpy(), pics
             np.save(os.path.join(flow_dir, f"{j0:07d}.npy"), np.stack(pics, 0))
             return None
         return fn
 
+    prof = {"decode_wait": 0.0, "enqueue": 0.0, "submit": 0.0, "post": 0.0} if os.environ.get("GVFI_CLI_TIMING") else None
     coord_cache = {}
     local_dev = []     # device-resident uint8 result frames of this rank (gathered once at the end when world > 1)
     t_warm, pairs_warm = None, 0
@@ -173,7 +184,11 @@ def main(argv=None):
             torch.cuda.synchronize(device)
             t_warm, pairs_warm = time.perf_counter(), j0 - p0
         b = min(bsz, p1 - j0)
+        tp = time.perf_counter()
         frames = torch.cat([frames_in.get(j) for j in range(j0, j0 + b + 1)], 0)      # (b+1, 3, Hp, Wp), each decoded once
+        if prof is not None:
+            prof["decode_wait"] += time.perf_counter() - tp
+            tp = time.perf_counter()
         s_shape = frames.shape[-2:]
         with torch.no_grad():
             key = (b, tuple(s_shape))
@@ -191,11 +206,21 @@ def main(argv=None):
                 u = padder.unpad(out["flowt"][i])
                 flows.append(u.reshape(b, 2, *u.shape[-2:]))
             flows = torch.stack(flows, 1).contiguous()                                              # [b, N-1, 2, h, w]
+            pics_u8 = rt.flow_to_image(flows.reshape(-1, 2, *flows.shape[-2:]), wheel, bgr=True)     # reference :199-207
         if world > 1:
             local_dev.append(pred_u8)
-        drain.submit(j0, [pred_u8, flows], post(j0, single=(world == 1)))
+        if prof is not None:
+            prof["enqueue"] += time.perf_counter() - tp
+            tp = time.perf_counter()
+        drain.submit(j0, [pred_u8, pics_u8], post(j0, single=(world == 1)))
+        if prof is not None:
+            prof["submit"] += time.perf_counter() - tp
+    tp = time.perf_counter()
     results = drain.finish()
     frames_in.close()
+    if prof is not None:
+        print("[video_Nx] host seconds of the main loop: " + ", ".join(f"{k} {v:.3f}" for k, v in prof.items())
+              + f", final drain {time.perf_counter() - tp:.3f}")
     if t_warm is not None and rank == 0:
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t_warm

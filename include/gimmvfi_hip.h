@@ -311,6 +311,11 @@ int gvfi_nhwc_to_nchw_f32(const float* src, int ld, float* dst, int C, int N, in
 /* output frame (B,3,H,W) float in [0,1] -> uint8 [B,H,W,3] (truncation of x*255, src/video_Nx.py:192-196);
  * the unit that is gathered to rank 0 over RCCL in multi-GPU runs */
 int gvfi_frames_to_u8(const float* src_nchw, unsigned char* dst_nhwc, int B, int H, int W, void* stream);
+/* flow colour coding of the CLI's flow.mp4 (reference src/utils/flow_viz.py:20-136 flow_to_image, src/video_Nx.py:199-207):
+ * flow = n_img planar (u, v) float images img_stride floats apart, wheel = the 55 x 3 Middlebury wheel, radmax_zeroed =
+ * n_img zeroed words of scratch (per-image max radius), out = [n_img][h][w][3] uint8 (BGR when bgr != 0) */
+int gvfi_flow_to_image(const float* flow, long long img_stride, int n_img, int h, int w, const float* wheel,
+                       unsigned* radmax_zeroed, unsigned char* out, int bgr, void* stream);
 
 /* library identity / self-check */
 const char* gvfi_version(void);

@@ -500,3 +500,31 @@ def splat_weights_and_norm_case(rt, sd, B=2, H=16, W=20):
             "flow_unnormalize")
     ref = orc.unnormalize_flow(ninr.cpu().permute(0, 3, 1, 2).unsqueeze(2), sref)
     assert float((ft.cpu().permute(0, 3, 1, 2) - ref[:, :, 0]).abs().max()) <= 1e-5
+
+
+def flow_to_image_case(rt, n=3, h=37, w=53):
+    """gvfi_flow_to_image == the CLI's numpy flow_viz.flow_to_image (reference src/utils/flow_viz.py), per image normalisation."""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    spec = importlib.util.spec_from_file_location(
+        "gvfi_cli_flow_viz", os.path.join(os.path.dirname(__file__), "..", "gimm-vfi_amd", "src", "utils", "flow_viz.py"))
+    fv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fv)
+    flow_to_image, make_colorwheel = fv.flow_to_image, fv.make_colorwheel
+    g = torch.Generator().manual_seed(5)
+    flows = torch.randn(n, 2, h, w, generator=g) * torch.tensor([0.3, 4.0, 40.0][:n]).view(n, 1, 1, 1)
+    flows[0, :, 0, 0] = 0.0
+    dev = _dev(rt)
+    wheel = torch.from_numpy(make_colorwheel()).float().to(dev)
+    got = rt.flow_to_image(flows.to(dev).contiguous(), wheel, bgr=True).cpu().numpy().astype(np.int32)
+    bad = 0
+    for i in range(n):
+        ref = flow_to_image(flows[i].permute(1, 2, 0).numpy(), convert_to_bgr=True).astype(np.int32)
+        d = np.abs(got[i] - ref)
+        assert d.max() <= 1, d.max()                      # atan2f may differ by an ulp from numpy's: a floor() can flip
+        bad += int((d > 0).sum())
+    assert bad <= 1e-3 * got.size, bad
+    return bad

@@ -168,3 +168,9 @@ def test_softsplat_native_op_contract(rt):
 
 def test_splat_weights_and_flow_norm(rt, sd):
     kc.splat_weights_and_norm_case(rt, sd)
+
+
+def test_flow_to_image_matches_the_cli_colour_coding(rt):
+    if rt.precision != "fp32":
+        pytest.skip("type-independent kernel: once is enough")
+    kc.flow_to_image_case(rt)

@@ -1,5 +1,5 @@
 """End-to-end throughput of the CLI (PNG decode -> pad -> H2D -> model -> D2H -> colour-coding), synthetic frames.
-usage: python tools/cli_bench.py [n_frames] [W] [H] [N]"""
+usage: python tools/cli_bench.py [n_frames] [W] [H] [N] [DS_SCALE]"""
 import os
 import subprocess
 import sys
@@ -18,6 +18,7 @@ def main():
     W = int(sys.argv[2]) if len(sys.argv) > 2 else 448
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     N = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    ds = sys.argv[5] if len(sys.argv) > 5 else "1.0"
     from gimmvfi_hip.synth import synthetic_pairs
 
     with tempfile.TemporaryDirectory() as d:
@@ -28,13 +29,13 @@ def main():
             f = np.roll((x[:, i % 2].permute(1, 2, 0).numpy() * 255).astype(np.uint8), 3 * i, axis=1)
             Image.fromarray(f).save(os.path.join(src, f"{i:04d}.png"))
         cmd = [sys.executable, os.path.join(ROOT, "gimm-vfi_amd", "src", "video_Nx.py"), "--source-path", src,
-               "--output-path", out, "--N", str(N), "--ds-factor", "1.0", "-m",
+               "--output-path", out, "--N", str(N), "--ds-factor", ds, "-m",
                os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml"), "--random-init", "--eval"]
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True)
         dt = time.perf_counter() - t0
         print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("[video_Nx]")), r.stderr[-300:] if r.returncode else "")
-        print(f"CLI: {n} frames {W}x{H}, {N}x -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
+        print(f"CLI: {n} frames {W}x{H}, {N}x, DS_SCALE {ds} -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
               f"(incl. process start, model build, graph capture, PNG/video writing)")
 
 
