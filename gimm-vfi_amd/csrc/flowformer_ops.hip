@@ -279,6 +279,16 @@ extern "C" int gvfi_cost_lookup(const float* maps, const float* coords, void* ou
     return (int)hipGetLastError();
 }
 
+// A/B switch of the MFMA attention kernels (attn_mfma.hip): GVFI_ATTN_MFMA=0 keeps the scalar kernels below
+static bool attn_mfma_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("GVFI_ATTN_MFMA");
+        on = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
 // ------------------------------------------------------------------ attention over small key sets
 // One thread = one (query row, head): soft-max(q.k_j * scale) over the keys in one pass (running maximum), V accumulated
 // in registers.  HD = head dimension (8, 16, 32).
@@ -346,6 +356,11 @@ __global__ void attn_window_kernel(const T* __restrict__ q, int ldq, const T* __
 extern "C" int gvfi_attn_window(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
                                 const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
                                 int head_dim, float scale, int dtype, void* stream) {
+    // bf16, head dimension 16 / 32, 7x7 windows: one wave per (window, head) on the matrix pipe (attn_mfma.hip)
+    if (attn_mfma_enabled() && gvfi_attn_mfma_ok(1, ws * ws, ws * ws, head_dim, ws, dtype)) {
+        const int rc = gvfi_attn_window_mfma(q, ldq, k, ldk, v, ldv, kpad, vpad, out, ldo, n_img, H, W, ws, heads, head_dim, scale, stream);
+        if (rc != -3) return rc;      // (-3: a pointer / pitch the vector loads cannot take -> scalar kernel)
+    }
     const long long total = (long long)n_img * H * W * heads;
 #define GVFI_AW(HD_)                                                                                                 \
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_window_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),          \
@@ -391,6 +406,11 @@ extern "C" int gvfi_attn_global(const void* q, int ldq, long long qb1, long long
                                 long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
                                 int head_dim, float scale, int dtype, void* stream) {
     if (G0 <= 0 || NQ <= 0 || M <= 0) return -2;
+    if (attn_mfma_enabled() && gvfi_attn_mfma_ok(0, M, NQ, head_dim, 0, dtype)) {
+        const int rc = gvfi_attn_global_mfma(q, ldq, qb1, qb0, qs, k, ldk, v, ldv, kb1, kb0, ks, out, ldo, ob1, ob0, os, G1, G0, NQ, M,
+                                             heads, head_dim, scale, stream);
+        if (rc != -3) return rc;
+    }
     const long long total = G1 * G0 * NQ * heads;
 #define GVFI_AG(HD_)                                                                                                   \
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((attn_global_kernel<T, HD_>), grid1d(total), dim3(GVFI_BLOCK),            \

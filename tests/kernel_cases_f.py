@@ -97,6 +97,27 @@ def attn_window_case(rt, B=2, H=9, W=10, C=64, heads=4):
     assert float((out.float().cpu().reshape(B, H * W, C) - ref).abs().max()) <= 2 * tol(rt, float(ref.abs().max()) + 1.0)
 
 
+def attn_global_mfma_case(rt, hd=16):
+    """Shapes that take the MFMA kernel in bf16 (attn_mfma.hip): M = 37 / 112 / 128 keys, ragged query blocks, strided groups."""
+    g = _g(16)
+    heads = 4
+    C = heads * hd
+    dev = lambda t: t.reshape(-1, t.shape[-1]).to(rt.tdtype).to(rt.device)
+    for (B, N, M) in ((2, 70, 37), (1, 97, 112), (2, 33, 128)):
+        q, k, v = (_r(rt, torch.randn(B, n_, C, generator=g)) for n_ in (N, M, M))
+        ref = forc._mha(q, k, v, heads)
+        # q inside a wider row matrix at a channel offset, k | v in one matrix (as the engine passes them)
+        qw = torch.cat([torch.zeros(B, N, 8), q, torch.zeros(B, N, 8)], -1)
+        kv = torch.cat([k, v], -1)
+        qd, kvd = dev(qw), dev(kv)
+        out = torch.zeros(B * N, C + 8, dtype=rt.tdtype, device=rt.device)
+        rt.attn_global(View(qd, 8, C), (N, 0, 1), View(kvd, 0, C), View(kvd, C, C), (M, 0, 1), View(out, 0, C), (N, 0, 1), B, 1, N, M, heads, hd)
+        got = out.float().cpu()
+        assert float(got[:, C:].abs().max()) == 0.0
+        err = float((got[:, :C].reshape(B, N, C) - ref).abs().max())
+        assert err <= 2 * tol(rt, float(ref.abs().max()) + 1.0), (B, N, M, err)
+
+
 def attn_global_case(rt):
     """(a) batched global attention; (b) one shared query set against per-map keys with the strided image-major
     output; (c) self-attention over the K tokens of a map in the image-major layout."""

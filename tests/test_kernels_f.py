@@ -39,6 +39,8 @@ def _all(rt):
     kf.attn_window_case(rt)
     kf.attn_window_case(rt, B=1, H=7, W=14, C=128, heads=4)          # head_dim 32, no padding
     kf.attn_global_case(rt)
+    kf.attn_global_mfma_case(rt, hd=16)                               # bf16: MFMA attention (attn_mfma.hip); fp32: scalar kernel
+    kf.attn_global_mfma_case(rt, hd=32)
     kf.xqk_case(rt)
     kf.tile_softmax_case(rt)
 
