@@ -410,8 +410,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                          (p.bias == nullptr || true);
     // (8-wave tile) uniform: plain activation epilogue that can be applied in the accumulator layout, see below
     const bool direct16 = NW >= 8 && sizeof(T) == 2 && BM * BN * 2 <= NSTAGE * STAGE && p.epi_mode == GVFI_EPI_STD &&
-                          vec_all && !p.y_f32 && p.res == nullptr && p.act1 <= GVFI_ACT_PRELU &&
+                          vec_all && !p.y_f32 && p.res == nullptr && (p.act1 <= GVFI_ACT_PRELU || p.act1 == GVFI_ACT_GELU) &&
                           p.act2 == GVFI_ACT_NONE && n0 + BN <= p.Cout;
+    // GELU (the transformer MLPs of GIMM-VFI-F: 229 k-row linears) takes the slim store loops too: on the generic loop those
+    // launches spent more in the epilogue than in the contraction
+    const bool gelu1 = p.act1 == GVFI_ACT_GELU;
     if (!GC_EARLY && !direct16) load_gc();
 #ifndef GVFI_HOSTSIM
     if (GC_EARLY || !direct16)
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(gc.bias[e]), "v"(gc.s1[e]), "v"(gc.s2[e]));
 #endif
     const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && my_valid == 8 && !p.y_f32 &&
-                      !(p.res && p.res_f32) && p.act1 <= GVFI_ACT_PRELU && p.act2 <= GVFI_ACT_PRELU;
+                      !(p.res && p.res_f32) && (p.act1 <= GVFI_ACT_PRELU || p.act1 == GVFI_ACT_GELU) && p.act2 <= GVFI_ACT_PRELU;
     // (the 8-wave tile is never used for the GRU convolutions and has no registers for their operands)
     const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8 &&
                           (p.res == nullptr || p.res_f32);
@@ -455,7 +458,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                     for (int r = 0; r < 16; ++r) {
                         const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                         const float t = acc[i][j][r] + bj;
-                        float v = fmaxf(t, 0.f) + sj * fminf(t, 0.f);
+                        float v = gelu1 ? 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)) : fmaxf(t, 0.f) + sj * fminf(t, 0.f);
                         if (has_sc) v *= p.out_scale;
                         cs16[row * BN + col] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
                     }
@@ -530,10 +533,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                     const float4 c0 = *(const float4*)(cp + it * ROWS_PER_IT * BN);
                     const float4 c1 = *(const float4*)(cp + it * ROWS_PER_IT * BN + 4);
                     float vv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    if (gelu1) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float t = vv[e] + gc.bias[e];
-                        vv[e] = fmaxf(t, 0.f) + gc.s1[e] * fminf(t, 0.f);
+                        for (int e = 0; e < 8; ++e) {
+                            const float t = vv[e] + gc.bias[e];
+                            vv[e] = 0.5f * t * (1.0f + erff(t * 0.70710678118654752f));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float t = vv[e] + gc.bias[e];
+                            vv[e] = fmaxf(t, 0.f) + gc.s1[e] * fminf(t, 0.f);
+                        }
                     }
                     if (has_res) {
                         float r[8];

@@ -77,6 +77,8 @@ CONV_SHAPES = [
     (2, 8, 12, 96, 32, 4, 4, dict(stride=4, pad=0)),
     (3, 8, 12, 16, 32, 6, 6, dict(stride=2, pad=2, act1=L.ACT_RELU)),
     (1, 1, 200, 64, 72, 1, 1, dict(act1=L.ACT_GELU)),
+    (1, 1, 300, 128, 256, 1, 1, dict(act1=L.ACT_GELU, tile=256, bf16_only=True)),     # GELU in the 8-wave tile's accumulator-layout epilogue
+    (1, 1, 300, 128, 128, 1, 1, dict(act1=L.ACT_GELU, with_res=True, pad16=True, bf16_only=True)),   # ... and in the slim store loop
     (1, 1, 200, 24, 40, 1, 1, dict(act1=L.ACT_GELU, with_res=True, out_f32=True)),
     (1, 1, 8, 64, 64, 1, 1, {}),
 ]
