@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                     for (int r = 0; r < 16; ++r) {
                         const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                         const float t = acc[i][j][r] + bj;
-                        float v = gelu1 ? 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)) : fmaxf(t, 0.f) + sj * fminf(t, 0.f);
+                        float v = gelu1 ? fast_gelu(t) : fmaxf(t, 0.f) + sj * fminf(t, 0.f);
                         if (has_sc) v *= p.out_scale;
                         cs16[row * BN + col] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
                     }
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float t = vv[e] + gc.bias[e];
-                            vv[e] = 0.5f * t * (1.0f + erff(t * 0.70710678118654752f));
+                            vv[e] = fast_gelu(t);
                         }
                     } else {
 #pragma unroll

@@ -164,9 +164,26 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
 }
+// GELU(t) = t/2 (1 + erf(t/sqrt 2)) with Abramowitz-Stegun 7.1.26 for erf (|error| <= 1.5e-7, one v_exp + one v_rcp, ~14
+// operations; erff costs ~35 and made the 229 k-row transformer MLPs of GIMM-VFI-F VALU-bound in their epilogue).  For negative
+// arguments 1 + erf is evaluated as the complementary term directly, so there is no cancellation.
+__device__ __forceinline__ float fast_gelu(float t) {
+    const float z = fabsf(t) * 0.70710678118654752f;
+    const float k = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = k * (0.254829592f + k * (-0.284496736f + k * (1.421413741f + k * (-1.453152027f + k * 1.061405429f))));
+    const float e = poly * __builtin_amdgcn_exp2f(-1.44269504088896341f * z * z);        // 1 - erf(z)
+    return 0.5f * t * (t >= 0.f ? 2.0f - e : e);
+}
 #else
 static inline float fast_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 static inline float fast_tanh(float x) { return tanhf(x); }
+static inline float fast_gelu(float t) {
+    const float z = fabsf(t) * 0.70710678118654752f;
+    const float k = 1.0f / (1.0f + 0.3275911f * z);
+    const float poly = k * (0.254829592f + k * (-0.284496736f + k * (1.421413741f + k * (-1.453152027f + k * 1.061405429f))));
+    const float e = poly * expf(-z * z);
+    return 0.5f * t * (t >= 0.f ? 2.0f - e : e);
+}
 #endif
 __device__ __forceinline__ void unpack_bf16x8(const uint4& u, float (&o)[8]) {
     o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16));
