@@ -129,8 +129,6 @@ class EngineF(Engine):
         """FlowFormer (flowformer/__init__.py:6-18, transformer.py:29-42)."""
         self.ln, self.consts = {}, {}
         self.raft_lanes = int(os.environ.get("GVFI_F_LANES", "2"))   # parallel decoder sequences (see Engine._raft)
-        # token linears with K in {64, 128} on at most this many rows take the no-LDS kernel (tok_linear.hip); 0 = never
-        self.tok_linear_rows = int(os.environ.get("GVFI_TOK_LINEAR_ROWS", "65536"))
         fe = "flow_estimator"
         self._build_twins(sd, fe + ".context_encoder")
         me = fe + ".memory_encoder"
@@ -219,9 +217,6 @@ class EngineF(Engine):
         x1v = None
         if x1 is not None:
             x1v = mk(x1 if isinstance(x1, View) else View(x1))
-        # short reductions over at most `tok_linear_rows` rows: the no-LDS kernel (tok_linear.hip); else the convolution engine
-        if rows <= self.tok_linear_rows and rt.tok_linear(lay, mk(xv), mk(ov), x1=x1v, act=act, res=rv):
-            return out
         rt.conv(lay, mk(xv), mk(ov), x1=x1v, act1=act, res=rv)
         return out
 

@@ -581,29 +581,6 @@ class Runtime:
         self._chk(self.lib.softmax_rows(x.data_ptr(), n, o.ptr, o.ld, rows, self.dtype, self.stream()), "softmax_rows")
         return out
 
-    def tok_linear(self, layer, x0, out, x1=None, act=L.ACT_NONE, res=None):
-        """Short-reduction linear over token rows (gvfi_tok_linear); returns False when the arguments are not its kind
-        (the caller then uses conv()).  x0 / x1 / out / res: Views of [1, 1, rows, C] row matrices."""
-        if self.dtype != L.BF16 or layer.kh != 1 or layer.kw != 1:
-            return False
-        x0, out = V(x0), V(out)
-        x1 = None if x1 is None else V(x1)
-        res = None if res is None else V(res)
-        k0, k1 = x0.c, 0 if x1 is None else x1.c
-        if x0.is_f32 or (x1 is not None and x1.is_f32) or layer.cin_pad != k0 + k1 or out.c != layer.cout:
-            return False
-        rows = x0.npix
-        a = (x0.ptr, x0.ld, k0, None if x1 is None else x1.ptr, 0 if x1 is None else x1.ld, k1, layer.w.data_ptr(), layer.cin_pad,
-             layer.cout, act, None if res is None else res.ptr, 0 if res is None else int(res.is_f32), 0 if res is None else res.ld,
-             out.ptr, int(out.is_f32), out.ld)
-        if self.lib.tok_linear_ok(*a) != 1:
-            return False
-        self._chk(self.lib.tok_linear(x0.ptr, x0.ld, k0, None if x1 is None else x1.ptr, 0 if x1 is None else x1.ld, k1,
-                                      layer.w.data_ptr(), layer.cin_pad, None if layer.b is None else layer.b.data_ptr(), layer.cout, act,
-                                      None if res is None else res.ptr, 0 if res is None else int(res.is_f32),
-                                      0 if res is None else res.ld, out.ptr, int(out.is_f32), out.ld, rows, self.stream()), "tok_linear")
-        return True
-
     def flow_to_image(self, flows, wheel, bgr=True):
         """flows: [n, 2, h, w] float (contiguous) -> [n, h, w, 3] uint8 pictures (reference flow_viz.flow_to_image per image)."""
         n, _, h, w = flows.shape

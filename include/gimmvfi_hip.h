@@ -270,15 +270,6 @@ int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long 
                      const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
                      long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
                      int head_dim, float scale, int dtype, void* stream);
-/* Linear layer over a token row matrix with a short reduction (csrc/tok_linear.hip; bf16 operands): y[r][0:N] =
- * act([x0[r][0:k0] | x1[r][0:k1]] W^T + bias) (+ res[r]), K = k0 + k1 in {64, 128}, W = plain [N][ldw] image, act in {none,
- * ReLU, GELU}, res / y in bf16 or float.  A wave owns 32 rows, no LDS (FlowFormer's decoder token path, decoder.py:84-120,
- * 237-255; transformer linears).  Same products and summation order as gvfi_conv2d on the same operands. */
-int gvfi_tok_linear_ok(const void* x0, int ld0, int k0, const void* x1, int ld1, int k1, const void* w, int ldw, int N,
-                       int act, const void* res, int res_f32, int ldr, const void* y, int y_f32, int ldy);
-int gvfi_tok_linear(const void* x0, int ld0, int k0, const void* x1, int ld1, int k1, const void* w, int ldw,
-                    const float* bias, int N, int act, const void* res, int res_f32, int ldr, void* y, int y_f32,
-                    int ldy, long long rows, void* stream);
 /* MFMA forms of the two attentions (csrc/attn_mfma.hip; bf16, head_dim 16 or 32): one wave per (group, head) keeps the key
  * fragments and the transposed value fragments in registers and walks blocks of 32 queries -- S^T = K Q^T, soft-max in
  * registers, O^T = V^T P^T, no LDS.  gvfi_attn_global (M in 9..128, NQ >= 16) and gvfi_attn_window (ws == 7) route here by

@@ -5,7 +5,6 @@ import torch
 import torch.nn.functional as F
 
 import gimmvfi_f_oracle as forc
-from gimmvfi_hip import lib as A
 from gimmvfi_hip.ops import View
 from kernel_cases import tol
 
@@ -96,44 +95,6 @@ def attn_window_case(rt, B=2, H=9, W=10, C=64, heads=4):
     vpad = sd["a.qkv.bias"][2 * C:].repeat(49, 1).contiguous().to(rt.device)
     rt.attn_window(View(qd, 0, C), View(qd, C, C), View(qd, 2 * C, C), kpad, vpad, out, B, H, W, 7, heads, C // heads)
     assert float((out.float().cpu().reshape(B, H * W, C) - ref).abs().max()) <= 2 * tol(rt, float(ref.abs().max()) + 1.0)
-
-
-def tok_linear_case(rt):
-    """gvfi_tok_linear (no-LDS short-reduction linear) == the convolution engine on the same operands, bit for bit: K = 64 / 128,
-    two sources, GELU / ReLU, bf16 and float residual / output, N below and above one block, ragged row count."""
-    from gimmvfi_hip.ops import ConvLayer
-    if rt.precision != "bf16":
-        return
-    g = _g(21)
-    dev = rt.device
-    mk = lambda t: View(t.view(1, 1, t.shape[0], t.shape[1]))
-    for (rows, k0, k1, N, act, res_kind, out_f32) in ((100, 64, 0, 64, A.ACT_NONE, None, False), (77, 64, 64, 64, A.ACT_GELU, "bf16", False),
-                                                       (45, 128, 0, 512, A.ACT_GELU, None, False), (33, 128, 0, 72, A.ACT_RELU, "f32", True),
-                                                       (64, 64, 0, 24, A.ACT_NONE, "f32", True)):
-        K = k0 + k1
-        w = _r(rt, torch.randn(N, K, 1, 1, generator=g) / K ** 0.5)
-        lay = ConvLayer(rt, w, torch.randn(N, generator=g))
-        xa = torch.randn(rows, k0 + 8, generator=g).to(rt.tdtype).to(dev)          # source inside a wider matrix
-        xb = torch.randn(rows, k1, generator=g).to(rt.tdtype).to(dev) if k1 else None
-        res = None
-        if res_kind is not None:
-            res = torch.randn(rows, N, generator=g).to(torch.float32 if res_kind == "f32" else rt.tdtype).to(dev)
-        outs = []
-        for use_tok in (True, False):
-            out = torch.full((rows, N + 8), 7.0, dtype=torch.float32 if out_f32 else rt.tdtype, device=dev)
-            xv = View(xa.view(1, 1, rows, k0 + 8), 0, k0)
-            x1v = None if xb is None else mk(xb)
-            ov = View(out.view(1, 1, rows, N + 8), 0, N)
-            rv = None if res is None else mk(res)
-            if use_tok:
-                assert rt.tok_linear(lay, xv, ov, x1=x1v, act=act, res=rv)
-            else:
-                rt.conv(lay, xv, ov, x1=x1v, act1=act, res=rv)
-            outs.append(out.float().cpu())
-        assert float((outs[0][:, N:] - 7.0).abs().max()) == 0.0
-        d = float((outs[0] - outs[1]).abs().max())
-        # float-output layers with GELU do not occur; the bf16 GELU paths share fast_gelu: identical results expected
-        assert d == 0.0, (rows, k0, k1, N, act, res_kind, out_f32, d)
 
 
 def attn_global_mfma_case(rt, hd=16):

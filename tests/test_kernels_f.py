@@ -41,7 +41,6 @@ def _all(rt):
     kf.attn_global_case(rt)
     kf.attn_global_mfma_case(rt, hd=16)                               # bf16: MFMA attention (attn_mfma.hip); fp32: scalar kernel
     kf.attn_global_mfma_case(rt, hd=32)
-    kf.tok_linear_case(rt)
     kf.xqk_case(rt)
     kf.tile_softmax_case(rt)
 
