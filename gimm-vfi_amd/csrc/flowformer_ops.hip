@@ -281,6 +281,12 @@ extern "C" int gvfi_cost_lookup(const float* maps, const float* coords, void* ou
 
 // A/B switch of the MFMA attention kernels (attn_mfma.hip): GVFI_ATTN_MFMA=0 keeps the scalar kernels below
 static bool attn_mfma_enabled() {
+#ifdef GVFI_HOSTSIM
+    // emulator: only on request (a thread per lane makes whole-model emulations with MFMA attention take minutes); read at
+    // every call so that a kernel test can switch it on inside a long-lived test process
+    const char* eh = getenv("GVFI_ATTN_MFMA");
+    return eh != nullptr && eh[0] == '1';
+#endif
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("GVFI_ATTN_MFMA");

@@ -45,7 +45,8 @@ def _all(rt):
     kf.tile_softmax_case(rt)
 
 
-def test_flowformer_kernels_emulated(rt_sim):
+def test_flowformer_kernels_emulated(rt_sim, monkeypatch):
+    monkeypatch.setenv("GVFI_ATTN_MFMA", "1")     # the emulator build takes the MFMA attention kernels only on request
     _all(rt_sim)
 
 
