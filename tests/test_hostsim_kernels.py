@@ -88,6 +88,9 @@ def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
         pytest.skip("bf16-only kernel")
     kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU)
     kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1)
+    kc.p3x3_equals_glds_case(rt, 1, 7, 40, 192, 256, split=128, seed=11)                          # odd chunk count, image lower than a tile
+    kc.p3x3_equals_glds_case(rt, 1, 33, 5, 320, 256, split=256, act1=L.ACT_NONE, with_res=True, act2=L.ACT_PRELU, seed=13)   # image narrower than a tile
+    kc.p3x3_equals_glds_case(rt, 2, 16, 16, 64, 512, with_res=True, act2=L.ACT_LRELU, seed=12)   # two Cout tiles, residual
 
 
 def test_p3x3s_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
@@ -99,6 +102,8 @@ def test_p3x3s_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
     kc.p3x3_equals_glds_case(rt, 1, 17, 33, 64, 24, with_res=True, act2=L.ACT_PRELU, algo_new=5, seed=1)
     kc.p3x3_equals_glds_case(rt, 2, 9, 20, 32, 64, act1=L.ACT_LRELU, out_scale=0.5, algo_new=5, seed=2, ld_extra=24)
     kc.p3x3_equals_glds_case(rt, 1, 20, 18, 32, 32, with_res=True, act2=L.ACT_LRELU, algo_new=5, seed=3)
+    kc.p3x3_equals_glds_case(rt, 3, 16, 3, 32, 8, algo_new=5, with_res=True, act2=L.ACT_PRELU, seed=15)   # narrower than a tile, one channel group
+    kc.p3x3_equals_glds_case(rt, 1, 31, 31, 64, 40, algo_new=5, act1=L.ACT_NONE, out_scale=2.0, seed=16)
 
 
 def test_gru_epilogues(rt):
