@@ -103,7 +103,8 @@ def attn_global_mfma_case(rt, hd=16):
     heads = 4
     C = heads * hd
     dev = lambda t: t.reshape(-1, t.shape[-1]).to(rt.tdtype).to(rt.device)
-    for (B, N, M) in ((2, 70, 37), (1, 97, 112), (2, 33, 128)):
+    # (the smallest sizes the MFMA kernel takes, a partial fourth key block, ragged query blocks)
+    for (B, N, M) in ((2, 70, 37), (1, 97, 112), (2, 33, 128), (1, 16, 9), (3, 200, 65)):
         q, k, v = (_r(rt, torch.randn(B, n_, C, generator=g)) for n_ in (N, M, M))
         ref = forc._mha(q, k, v, heads)
         # q inside a wider row matrix at a channel offset, k | v in one matrix (as the engine passes them)
@@ -116,6 +117,15 @@ def attn_global_mfma_case(rt, hd=16):
         assert float(got[:, C:].abs().max()) == 0.0
         err = float((got[:, :C].reshape(B, N, C) - ref).abs().max())
         assert err <= 2 * tol(rt, float(ref.abs().max()) + 1.0), (B, N, M, err)
+    # strided groups (G0 > 1): one shared query set against per-map keys, image-major output rows
+    n, P, K, T = 2, 5, 20, 12
+    lat = _r(rt, torch.randn(1, K, C, generator=g))
+    kk, vv = (_r(rt, torch.randn(n * P, T, C, generator=g)) for _ in range(2))
+    refb = forc._broad_mha(lat, kk, vv, heads)
+    outb = torch.zeros(n * K * P, C, dtype=rt.tdtype, device=rt.device)
+    rt.attn_global(dev(lat), (0, 0, 1), dev(kk), dev(vv), (P * T, T, 1), outb, (K * P, 1, P), n, P, K, T, heads, hd)
+    gotb = outb.float().cpu().reshape(n, K, P, C).permute(0, 2, 1, 3).reshape(n * P, K, C)
+    assert float((gotb - refb).abs().max()) <= 2 * tol(rt, float(refb.abs().max()) + 1.0)
 
 
 def attn_global_case(rt):

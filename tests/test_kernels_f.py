@@ -38,6 +38,7 @@ def _all(rt):
     kf.cost_embed_lookup_case(rt)
     kf.attn_window_case(rt)
     kf.attn_window_case(rt, B=1, H=7, W=14, C=128, heads=4)          # head_dim 32, no padding
+    kf.attn_window_case(rt, B=1, H=15, W=8, C=128, heads=8)          # head_dim 16, ragged in both directions
     kf.attn_global_case(rt)
     kf.attn_global_mfma_case(rt, hd=16)                               # bf16: MFMA attention (attn_mfma.hip); fp32: scalar kernel
     kf.attn_global_mfma_case(rt, hd=32)
