@@ -5,6 +5,9 @@ workload  = BASELINE.json configs[1]: GIMM-VFI-R, 448x256, batch=8 pairs, t=0.5,
 value     = interpolated frames / second, whole job (inputs resident in HBM before the timed region)
 multi-GPU = frame pairs shard across ranks (weak scaling: 8 pairs per rank), no data-path collective;
             the uint8 result frames are gathered to rank 0 over RCCL inside the timed region.
+            `python bench.py --gpus N` launches itself: without RANK in the environment it re-executes under
+            `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` on a free port (one
+            rank per GPU); started by an external torchrun it uses that world as it is.
 
 roofline     : dominant kernel = the convolution kernel with the largest total time per step (since round 2 the
                halo-staged 3x3 kernel conv_p3x3.hip of the decoder ResBlocks) -- algorithmic FLOPs of its launches /
@@ -16,6 +19,8 @@ cpu_baseline : the CPU oracle (port of the reference algorithm, oracle/gimmvfi_r
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +33,44 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun world: start N ranks of this script on this node and pass
+    rank 0's JSON line through.  Returns the launcher's exit code."""
+    if not args.stub:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_step_factory(world, rank):
+    """Launcher self-test (`--stub`, CPU + gloo): a step with the real step's shape -- some local work and the gather of a
+    uint8 result to rank 0 -- so tests can drive launch / barrier / max-over-ranks / one-line reporting without a GPU."""
+    w = torch.randn(256, 256)
+    buf = [torch.empty(8, 16, 16, 3, dtype=torch.uint8) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        y = (w @ w).abs().clamp(0, 1)
+        frames = (y[:8 * 16 * 16 * 3 // 256].reshape(-1)[:8 * 16 * 16 * 3].reshape(8, 16, 16, 3) * 255).to(torch.uint8)
+        if world > 1:
+            dist.gather(frames, buf, dst=0)
+        return frames
+
+    return step
 
 
 def main():
@@ -46,17 +89,27 @@ def main():
                          "f = GIMM-VFI-F (FlowFormer flow estimator, configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default=None, help="write a per-conv-shape time table (markdown) to this path")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test: CPU + gloo, a stub step (tests/test_host_logic.py); never a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
+    if args.stub:
+        return stub_main(args, world, rank)
+    if torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py: rank {rank} needs GPU {local} but {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
+        assert dist.get_world_size() == world
 
     from gimmvfi_hip.model import GIMMVFI_F, GIMMVFI_R
     from gimmvfi_hip.params import random_state_dict, random_state_dict_f
@@ -90,19 +143,7 @@ def main():
             dist.gather(frames, gather_buf, dst=0)   # the path's only collective: result gather to rank 0
         return frames
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize)
     # Roofline pass: the timed steps above replay a hipGraph (no host work between kernels), and HIP events cannot
     # be recorded per launch inside a graph replay, so the per-launch durations of the dominant kernel come from
     # an instrumented eager pass of the same step right after the timed region (rank 0, same inputs, same stream).
@@ -226,10 +267,50 @@ def main():
             "config": {"workload": f"GIMM-VFI-{args.model.upper()} {W}x{H} batch={B} pairs/GPU, {NI}x interpolation (t=i/{NI}), "
                                    f"DS_SCALE={args.ds:g}, seeded random-init weights",
                        "pairs_per_step_per_gpu": B, "flow_iters": 20 if args.model == "r" else 32,
-                       "parallelism": f"pair-sharded x{world}"},
+                       "parallelism": f"pair-sharded x{world}",
+                       "world_size_rccl": dist.get_world_size() if world > 1 else 1},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def timed_steps(step, steps, warmup, world, sync):
+    """The driver contract's timing: W untimed steps, barrier + sync, exactly K steps, barrier + sync; MAX over ranks."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def stub_main(args, world, rank):
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    step = stub_step_factory(world, rank)
+    dt = timed_steps(step, args.steps, args.warmup, world, lambda: None)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        frames = world * 8 * args.steps
+        print(json.dumps({"metric": "interpolated frames/sec", "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+                          "data": "stub (launcher self-test on CPU/gloo, not a measurement)",
+                          "config": {"workload": "stub", "parallelism": f"pair-sharded x{world}",
+                                     "world_size_rccl": dist.get_world_size() if world > 1 else 1}}))
     if world > 1:
         dist.destroy_process_group()
 

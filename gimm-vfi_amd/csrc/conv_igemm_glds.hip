@@ -773,7 +773,8 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     if (!kb) return -2;
     const int groups = p.groups > 0 ? p.groups : 1;
     const long long M = (long long)p.N * p.Ho * p.Wo / groups;
-    int tile = p.tile_hint & 1023, bm = p.tile_hint >> 10;
+    int tile = p.tile_hint & 1023, bm = (p.tile_hint >> 10) & 1023;
+    const int ns_hint = (p.tile_hint >> 20) & 15;   // ring depth override (0 = auto), 128-byte chunks only
     if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
     tile = tile >= 256 ? 256 : (tile >= 128 ? 128 : (tile >= 64 ? 64 : 32));
     int k = 64, ns = 2;
@@ -795,6 +796,7 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
         if (bm == 0) bm = M >= 65536 ? 256 : 128;
         bm = bm >= 256 ? 256 : 128;
     }
+    if (ns_hint && k == 128 && tile < 256) ns = ns_hint < 2 ? 2 : (ns_hint > 4 ? 4 : ns_hint);
     plan[0] = 2;
     plan[1] = bm;
     plan[2] = tile;
@@ -812,7 +814,7 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (p.groups > 1 && (p.N % p.groups)) return -4;
     if (p.stats != nullptr && !gvfi_conv2d_stats_ok(pp)) return -6;   // statistics requested but not computable here
     hipStream_t st = (hipStream_t)stream;
-    const int bm = plan[1], tile = plan[2], k = plan[3];
+    const int bm = plan[1], tile = plan[2], k = plan[3], ns = plan[4];
 #define GLDS_DISPATCH(TT)                                                                                     \
     if (tile == 256) {                                                                                        \
         if (k == 64) return launch_glds<TT, 256, 256, 2, 4, 64, 4>(p, st);                                    \
@@ -821,11 +823,16 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     }                                                                                                         \
     if (tile == 128) {                                                                                        \
         if (k == 64) return launch_glds<TT, 128, 128, 2, 2, 64, 4>(p, st);                                    \
+        if (bm == 64 && ns == 3) return launch_glds<TT, 64, 128, 2, 2, 128, 3>(p, st);                        \
+        if (bm == 64 && ns == 4) return launch_glds<TT, 64, 128, 2, 2, 128, 4>(p, st);                        \
         if (bm == 64) return launch_glds<TT, 64, 128, 2, 2, 128, 2>(p, st);                                   \
+        if (ns == 3) return launch_glds<TT, 128, 128, 2, 2, 128, 3>(p, st);                                   \
         return launch_glds<TT, 128, 128, 2, 2, 128, 2>(p, st);                                                \
     }                                                                                                         \
     if (tile == 64) {                                                                                         \
         if (k == 64) return launch_glds<TT, 128, 64, 2, 2, 64, 4>(p, st);                                     \
+        if (ns == 3) return launch_glds<TT, 128, 64, 2, 2, 128, 3>(p, st);                                    \
+        if (ns == 4) return launch_glds<TT, 128, 64, 2, 2, 128, 4>(p, st);                                    \
         return launch_glds<TT, 128, 64, 2, 2, 128, 2>(p, st);                                                 \
     }                                                                                                         \
     if (bm == 256) {                                                                                          \
@@ -833,6 +840,8 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
         return launch_glds<TT, 256, 32, 4, 1, 128, 2>(p, st);                                                 \
     }                                                                                                         \
     if (k == 64) return launch_glds<TT, 128, 32, 4, 1, 64, 2>(p, st);                                         \
+    if (ns == 3) return launch_glds<TT, 128, 32, 4, 1, 128, 3>(p, st);                                        \
+    if (ns == 4) return launch_glds<TT, 128, 32, 4, 1, 128, 4>(p, st);                                        \
     return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }
     GLDS_DISPATCH(bf16_t)

@@ -528,6 +528,7 @@ class Engine:
             _, img4_full = rt.prep_images(img_xs)
             img_xs = rt.resize_planes(img_xs, ds_factor)
         imgA, img4 = rt.prep_images(img_xs)
+        self._cur_img_xs = img_xs      # (the float stages of GIMM-VFI-F's precision policy prepare their own copy)
         H, W = img_xs.shape[-2:]
         assert H % 8 == 0 and W % 8 == 0 and H >= 128 and W >= 128, "working resolution must be >=128 and /8"
         n = 2 * B

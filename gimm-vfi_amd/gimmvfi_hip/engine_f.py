@@ -39,7 +39,42 @@ def _enc_host(xs, ys, dim):
                       torch.sin(3.14 * y * fb * (1 / 200)), torch.cos(3.14 * y * fb * (1 / 200))], dim=-1)
 
 
+FLOW_STAGES = ("enc", "cost", "dec")
+
+
+def parse_flow_policy(spec):
+    """'bf16' / None -> no stage in float; 'fp32' -> all three; else a comma list of the stages that run in float:
+    enc (Twins encoders + channel convertor), cost (cost volume + latent cost encoder), dec (32-iteration decoder)."""
+    if spec in (None, "", "bf16"):
+        return ()
+    if spec == "fp32":
+        return FLOW_STAGES
+    st = tuple(x.strip() for x in spec.split(",") if x.strip())
+    for x in st:
+        if x not in FLOW_STAGES:
+            raise ValueError(f"flow_precision: unknown stage {x!r} (stages: {FLOW_STAGES}, or 'bf16' / 'fp32')")
+    return st
+
+
 class EngineF(Engine):
+    def __init__(self, rt, sd, motion_only=False, flow_precision=None, flow_only=False):
+        """flow_precision (bf16 runtime only): which stages of the FLOW ESTIMATOR run in float (exact-f32 MFMA) while
+        everything behind it stays bf16 -- see parse_flow_policy.  The float stages run on a second engine over the same
+        library (`self.hi`, flow-estimator layers only); tensors crossing a stage boundary are converted by
+        gvfi_copy_channels."""
+        self._flow_only = flow_only
+        self.flow_f32 = parse_flow_policy(flow_precision) if rt.precision == "bf16" else ()
+        self.hi = None
+        super().__init__(rt, sd, motion_only=motion_only)
+        if self.flow_f32 and not motion_only:
+            self.hi = EngineF(rt.sibling("fp32"), sd, flow_only=True)
+
+    def _build(self, sd):
+        if self._flow_only:
+            self._build_flow(sd)
+            return
+        super()._build(sd)
+
     # ------------------------------------------------------------------ weight preparation
     def _lin(self, sd, key, name=None, **kw):
         w = sd[key + ".weight"]
@@ -394,15 +429,12 @@ class EngineF(Engine):
         return mem
 
     # ------------------------------------------------------------------ FlowFormer (both directions batched)
-    def _flowformer(self, imgA, B, iters, taps, seq=False):
+    def _ff_encode(self, imgA, B, seq):
+        """Stage "enc": both Twins encoders + channel convertor -> context features (1/4, 1/8) and matching features."""
         rt, Ls = self.rt, self.layers
-        self._grids = {}
         n = 2 * B
-        H, W = imgA.shape[1:3]
-        h8, w8 = H // 8, W // 8
-        P8 = h8 * w8
         fe = "flow_estimator"
-        md = fe + ".memory_decoder"
+        h8, w8 = imgA.shape[1] // 8, imgA.shape[2] // 8
         if seq and B > 1:
             # consecutive pairs: both Twins encoders are per image, so they run on the B+1 distinct frames (Engine._raft)
             imgU = torch.cat([imgA[:B], imgA[n - 1:n]], 0)
@@ -412,10 +444,16 @@ class EngineF(Engine):
         else:
             cfeat = self._twins(imgA, fe + ".context_encoder")
             ff = self._twins(imgA, fe + ".memory_encoder.feat_encoder")[1]
-        context = cfeat[1]                                          # [n,h8,w8,256]
-        ctx_rows = context.view(n * P8, 256)
         fmap = rt.act(n, h8, w8, 256)
         rt.conv(Ls[fe + ".memory_encoder.channel_convertor"], ff, fmap)
+        return cfeat, fmap
+
+    def _ff_cost(self, fmap, context, n, B, h8, w8, taps):
+        """Stage "cost": all-pairs cost volume + latent cost encoder -> volume (float) and cost memory."""
+        rt = self.rt
+        self._grids = {}
+        P8 = h8 * w8
+        ctx_rows = context.view(n * P8, 256)
         # all-pairs cost volume of both directions (encoder.py:489-506; no 1/sqrt(d)): image i against its partner
         fswap = torch.cat([fmap[B:], fmap[:B]], 0)
         vol = rt.f32(n * P8, P8)
@@ -423,11 +461,17 @@ class EngineF(Engine):
                 cout=P8)
         mem = self._cost_encoder(vol, ctx_rows, n, B, h8, w8, taps)
         if taps is not None:
-            taps["f01_context"] = context[:B]
-            taps["f01_cfeat4"] = cfeat[0][:B]
             taps["f01_ffeat"] = fmap[:B]
             taps["f01_cost_memory"] = mem.view(n, K_LAT, P8, 128)[:B]
-        # ---- MemoryDecoder   decoder.py:257-321
+        return vol, mem
+
+    def _ff_decode(self, vol, mem, context, n, B, h8, w8, iters, taps):
+        """Stage "dec": MemoryDecoder (decoder.py:257-321) -> full-resolution flows [n,H,W,2] float."""
+        rt, Ls = self.rt, self.layers
+        if not hasattr(self, "_grids"):
+            self._grids = {}
+        P8 = h8 * w8
+        md = "flow_estimator.memory_decoder"
         hA = rt.act(n, h8, w8, 128)
         hB = rt.act(n, h8, w8, 128)
         inp = rt.act(n, h8, w8, 128)
@@ -537,8 +581,38 @@ class EngineF(Engine):
         rt.conv(Ls[u + ".mask.0"], hA, fh, act1=A.ACT_RELU)
         mask = rt.f32(n, h8, w8, 576)
         rt.conv(Ls[u + ".mask.2"], fh, mask, out_scale=0.25)
-        flow_up = rt.convex_upsample(coords, mask)
+        return rt.convex_upsample(coords, mask)
+
+    def _cvt(self, t, eng):
+        """t in the activation type of engine `eng` (stage boundary of the precision policy; gvfi_copy_channels)."""
+        if t.dtype == eng.rt.tdtype:
+            return t
+        out = torch.empty(t.shape, dtype=eng.rt.tdtype, device=t.device)
+        c = t.shape[-1]
+        v = lambda x: View(x.view(-1, c))
+        self.rt.copy(v(t), v(out), c)
+        return out
+
+    def _flowformer(self, imgA, B, iters, taps, seq=False):
+        n = 2 * B
+        H, W = imgA.shape[1:3]
+        h8, w8 = H // 8, W // 8
+        eng = {st: (self.hi if st in self.flow_f32 else self) for st in FLOW_STAGES}
+        img_e = imgA
+        if eng["enc"] is not self:      # the float stage reads the float image, not its bf16 rounding
+            img_e, _ = self.hi.rt.prep_images(self._cur_img_xs)
+        cfeat, fmap = eng["enc"]._ff_encode(img_e, B, seq)
+        ec = eng["cost"]
+        vol, mem = ec._ff_cost(self._cvt(fmap, ec), self._cvt(cfeat[1], ec), n, B, h8, w8, taps)
+        ed = eng["dec"]
+        flow_up = ed._ff_decode(vol, self._cvt(mem, ed), self._cvt(cfeat[1], ed), n, B, h8, w8, iters, taps)
+        cfeat = [self._cvt(f, self) for f in cfeat]
+        fmap = self._cvt(fmap, self)
+        if taps is not None:
+            taps["f01_context"] = cfeat[1][:B]
+            taps["f01_cfeat4"] = cfeat[0][:B]
         return flow_up, fmap, cfeat, (h8, w8)
+
 
     def _flow(self, imgA, B, iters, taps, seq=False):
         """gimmvfi_f.py:114-139: FlowFormer both ways, BidirCorrBlock on its (converted) features, context features

@@ -127,7 +127,7 @@ class GIMMVFI_R(nn.Module):
 
     def engine(self, device=None, runtime=None):
         device = torch.device(device) if device is not None else next(self.parameters()).device
-        key = (str(device), self.precision, id(runtime))
+        key = (str(device), self.precision, id(runtime), getattr(self, "flow_precision", None))
         if self._engine is None or self._engine_key != key:
             if runtime is None:
                 if device.type != "cuda":
@@ -136,10 +136,13 @@ class GIMMVFI_R(nn.Module):
                         "'cuda' (there is no CPU fallback)"
                     )
                 runtime = Runtime(L.get(), self.precision, device)
-            self._engine = self._engine_cls(runtime, self.state_dict())
+            self._engine = self._make_engine(runtime)
             self._engine_key = key
             self._graphs = {}     # graphs captured on the previous engine replay ITS buffers and packed weights
         return self._engine
+
+    def _make_engine(self, runtime):
+        return self._engine_cls(runtime, self.state_dict())
 
     # ---- reference API -------------------------------------------------------------------
     def forward(self, img_xs, coord=None, t=None, iters=None, ds_factor=None, _seq=False):
@@ -258,6 +261,19 @@ class GIMMVFI_F(GIMMVFI_R):
 
     _spec = staticmethod(param_spec_f)
     _init_sd = staticmethod(random_state_dict_f)
+
+    def __init__(self, config=None, precision=None, flow_precision=None):
+        """flow_precision (with precision "bf16"): precision policy of the FlowFormer flow estimator only --
+        "bf16" (all bf16 MFMA), "fp32" (the whole flow estimator on exact-f32 MFMA, synthesis and motion INR stay
+        bf16), or a comma list of the stages to run in float: enc (Twins encoders), cost (cost volume + latent cost
+        encoder), dec (32-iteration decoder).  Default: config.flow_precision, $GIMMVFI_F_FLOW_PRECISION, else "bf16".
+        See DESIGN.md section 9 for the measured fidelity / speed of each policy."""
+        super().__init__(config, precision)
+        cfg_fp = _cfg_get(config, "flow_precision")
+        self.flow_precision = flow_precision or cfg_fp or os.environ.get("GIMMVFI_F_FLOW_PRECISION", "bf16")
+
+    def _make_engine(self, runtime):
+        return self._engine_cls(runtime, self.state_dict(), flow_precision=self.flow_precision)
 
     @property
     def _engine_cls(self):

@@ -199,6 +199,10 @@ class Runtime:
         self._lanes = {}         # stream id -> extra streams for lanes()
         self.last_stats_fused = False
 
+    def sibling(self, precision):
+        """A runtime of another precision over the same library and device (GIMM-VFI-F's float flow-estimator stages)."""
+        return Runtime(self.lib, precision, self.device)
+
     # ------------------------------------------------------------------ memory
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else 0

@@ -352,10 +352,12 @@ def param_spec_f() -> "OrderedDict[str, tuple]":
     return d
 
 
-def random_state_dict_f(seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+def random_state_dict_f(seed: int = 0, gain: float = 1.0, flow_head_scale: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
     """Seeded random GIMM-VFI-F weights: the shared blocks exactly as random_state_dict(seed) gives them, the
     FlowFormer from an independent generator (Linear/conv ~ U(+-gain/sqrt(fan_in)), LayerNorm gamma/beta and the
-    GMA gamma non-trivial so that every fused/folded path is exercised)."""
+    GMA gamma non-trivial so that every fused/folded path is exercised).  flow_head_scale multiplies the decoder's
+    flow head (update_block.flow_head.conv2): the un-trained recurrence then takes 32 small steps instead of 32 large
+    ones -- flows of a few pixels, the "well-conditioned" parity fixtures (tests/golden/hr_f_*_fh*.npz)."""
     base = random_state_dict(seed, gain)
     g = torch.Generator(device="cpu")
     g.manual_seed(1000 + seed)
@@ -396,7 +398,13 @@ def random_state_dict_f(seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, t
             sd[name] = U(shape, 0.8, 1.2)
         else:
             raise KeyError(name)
+    if flow_head_scale != 1.0:
+        for k in (FLOW_HEAD_F + ".weight", FLOW_HEAD_F + ".bias"):
+            sd[k] = sd[k] * flow_head_scale
     return sd
+
+
+FLOW_HEAD_F = "flow_estimator.memory_decoder.update_block.flow_head.conv2"
 
 
 def random_state_dict_for(model_type: str, seed: int = 0):

@@ -11,7 +11,11 @@ A full 4K x 7 result is 187 MB, so a fixture keeps, per timestep:
 for timesteps `keep` (block means for all of them), plus the un-padded uint8 input frames of the demo cases
 (synthetic inputs are re-generated from the seed; `in_sum` guards that re-generation).
 
-    python oracle/make_golden_hires.py [--model r|f] [case ...]
+    python oracle/make_golden_hires.py [--model r|f] [--flow-head-scale S] [case ...]
+
+--flow-head-scale S (model f): the seeded weights with the FlowFormer decoder's flow head multiplied by S
+(params.random_state_dict_f(0, flow_head_scale=S)) -- flows of a few pixels instead of 40-50 px of folds; the fixture
+is written as hr_f_<case>_fh<100*S>.npz.  Separates conditioning of the un-trained recurrence from arithmetic.
 """
 import json
 import os
@@ -92,10 +96,15 @@ def main():
         i = args.index("--model")
         model_kind = args[i + 1]
         del args[i:i + 2]
+    fh_scale = 1.0
+    if "--flow-head-scale" in args:
+        i = args.index("--flow-head-scale")
+        fh_scale = float(args[i + 1])
+        del args[i:i + 2]
     names = args or list(CASES)
     out_dir = os.path.join(ROOT, "tests", "golden")
     if model_kind == "f":
-        model = rh.build_reference_model_f(random_state_dict_f(0))
+        model = rh.build_reference_model_f(random_state_dict_f(0, flow_head_scale=fh_scale))
     else:
         model = rh.build_reference_model(random_state_dict(0))
     torch.set_num_threads(os.cpu_count())
@@ -120,13 +129,14 @@ def main():
                 arrs[f"flowt_{i}"] = ft[:, ::2, ::2].numpy().astype(np.float16)
         if raw is not None:
             arrs["frames_u8"] = raw
-        meta = {"model": model_kind, "kind": kind, "H": H, "W": W, "Hp": Hp, "Wp": Wp, "pad": pad, "ds": ds, "N": N,
+        meta = {"model": model_kind, "flow_head_scale": fh_scale, "kind": kind, "H": H, "W": W, "Hp": Hp, "Wp": Wp, "pad": pad, "ds": ds, "N": N,
                 "seed": src if kind == "synthetic" else None, "keep": KEEP, "t": tl,
                 "in_sum": int(torch.round(x * 255.0).to(torch.int64).sum()),
                 "flow_absmax": float(max(float(f.abs().max()) for f in o["flowt"])),
                 "ref_cpu_seconds": round(dt, 1), "ref_cpu_threads": torch.get_num_threads()}
         arrs["meta"] = np.array(json.dumps(meta))
-        path = os.path.join(out_dir, f"hr_{model_kind}_{name}.npz")
+        sfx = "" if fh_scale == 1.0 else f"_fh{int(round(fh_scale * 100)):03d}"
+        path = os.path.join(out_dir, f"hr_{model_kind}_{name}{sfx}.npz")
         np.savez_compressed(path, **arrs)
         print(name, f"{dt:.1f}s", os.path.getsize(path) // 1024, "KiB", meta["flow_absmax"], flush=True)
 

@@ -64,6 +64,9 @@ class SimRuntime(Runtime):
         super().__init__(hostsim_lib(), precision, "cpu")
         self.emulate_conv = emulate_conv
 
+    def sibling(self, precision):
+        return SimRuntime(precision, self.emulate_conv)
+
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
              w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False):

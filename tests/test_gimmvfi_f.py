@@ -77,6 +77,29 @@ def test_engine_f_sim_bf16(sd_f):
     assert float(d.mean()) < 0.5
 
 
+def test_engine_f_sim_flow_precision_policy(sd_f):
+    """bf16 engine with the flow estimator's stages in float (GIMMVFI_F(flow_precision=...)): with all three stages in
+    float the flows are those of the fp32 engine, the frames those of bf16 synthesis; a single float stage still runs the
+    whole launch list (stage-boundary conversions)."""
+    from gimmvfi_hip.engine_f import EngineF, parse_flow_policy
+    from sim_runtime import SimRuntime
+
+    assert parse_flow_policy("bf16") == () and parse_flow_policy("fp32") == ("enc", "cost", "dec")
+    assert parse_flow_policy("cost, dec") == ("cost", "dec")
+    with pytest.raises(ValueError):
+        parse_flow_policy("decoder")
+    meta, gold = load_golden("f_128x192_t050")
+    x, coords, ts = golden_inputs(meta)
+    mixed = EngineF(SimRuntime("bf16"), sd_f, flow_precision="fp32").forward(x, coords, ts, iters=None)
+    assert maxabs(mixed["raft_flow"], gold["raft_flow"]) < 2e-3          # the float flow estimator
+    p_mixed = psnr(mixed["imgt_pred"][0], gold["imgt_pred_0"])
+    assert p_mixed > 50.0, p_mixed                                       # bf16 synthesis on exact flows
+    part = EngineF(SimRuntime("bf16"), sd_f, flow_precision="dec").forward(x, coords, ts, iters=None)
+    assert psnr(part["imgt_pred"][0], gold["imgt_pred_0"]) > 40.0
+    # an fp32 engine ignores the policy (everything is float already)
+    assert EngineF(SimRuntime("fp32"), sd_f, flow_precision="fp32").hi is None
+
+
 def test_engine_f_sim_ragged_grid(sd_f):
     """136 x 152 frames -> 17 x 19 grid at 1/8: ragged 7x7 windows (bias / positional-code keys), zero-extended
     sub-sampling convolutions and cost-map patches, odd P8 (padded pitch of the GMA attention matrix)."""

@@ -133,38 +133,51 @@ def run_hr(m, meta, x):
     return out
 
 
-def check_hr(out, meta, z, prec, tag, kind="r"):
+def hr_metrics(out, meta, z):
+    """Worst-case distances of a forward's outputs from a reference fixture (over the kept timesteps / crops)."""
     T = meta["N"] - 1
     assert len(out["imgt_pred"]) == T
     cyx = z["crop_yx"]
-    worst_psnr, worst_lsb, worst_bm, worst_flow, worst_frac, worst_bm999, worst_fmed = 1e9, 0, 0.0, 0.0, 0.0, 0.0, 0.0
+    m = dict(psnr=1e9, lsb=0, bm=0.0, flow999=0.0, frac=0.0, bm999=0.0, fmed=0.0, fmean=0.0)
     for i in range(T):
         img = out["imgt_pred"][i][0].float().cpu()
         assert tuple(img.shape) == (3, meta["Hp"], meta["Wp"]) and torch.isfinite(img).all()
         bm = img.reshape(3, meta["Hp"] // 16, 16, meta["Wp"] // 16, 16).mean(dim=(2, 4))
         dbm = (bm - torch.from_numpy(z[f"bm_{i}"])).abs().flatten()
-        worst_bm = max(worst_bm, float(dbm.max()))
-        worst_bm999 = max(worst_bm999, float(dbm.kthvalue(int(dbm.numel() * 0.999))[0]))
+        m["bm"] = max(m["bm"], float(dbm.max()))
+        m["bm999"] = max(m["bm999"], float(dbm.kthvalue(int(dbm.numel() * 0.999))[0]))
         if i not in meta["keep"]:
             continue
         u8 = torch.round(img.clamp(0, 1) * 255.0)
         ref = torch.from_numpy(z[f"crops_{i}"]).float()
         got = torch.stack([u8[:, y:y + ref.shape[-2], x_:x_ + ref.shape[-1]] for y, x_ in cyx])
         dl = (got - ref).abs()
-        worst_lsb = max(worst_lsb, int(dl.max()))
-        worst_frac = max(worst_frac, float((dl > 1).float().mean()))
+        m["lsb"] = max(m["lsb"], int(dl.max()))
+        m["frac"] = max(m["frac"], float((dl > 1).float().mean()))
         mse = float(((got - ref) / 255.0).pow(2).mean())
-        worst_psnr = min(worst_psnr, 99.0 if mse == 0 else -10.0 * np.log10(mse))
+        m["psnr"] = min(m["psnr"], 99.0 if mse == 0 else -10.0 * np.log10(mse))
         ft = out["flowt"][i].float().cpu()
         ft = ft if ft.dim() == 3 else ft[0]
         rf = torch.from_numpy(z[f"flowt_{i}"].astype(np.float32))
         assert tuple(ft[:, ::2, ::2].shape) == tuple(rf.shape)
-        d = ((ft[:, ::2, ::2] - rf).abs() - 1.5e-3 * rf.abs()).flatten()        # fp16 storage of the fixture: 2^-11 relative
-        worst_flow = max(worst_flow, float(d.kthvalue(int(d.numel() * 0.999))[0]))
-        worst_fmed = max(worst_fmed, float(d.median()))
-    print(f"{tag} {prec}: crops max |d| {worst_lsb} LSB ({worst_frac:.1e} of the pixels > 1 LSB), min PSNR {worst_psnr:.2f} dB, "
-          f"block-mean |d| max {worst_bm:.2e} p99.9 {worst_bm999:.2e}, flowt |d| median {worst_fmed:.2e} p99.9 {worst_flow:.2e} px "
-          f"(max |flow| {meta['flow_absmax']:.1f})")
+        d = ((ft[:, ::2, ::2] - rf).abs() - 1.5e-3 * rf.abs()).clamp_min(0).flatten()   # fp16 storage of the fixture: 2^-11 relative
+        m["flow999"] = max(m["flow999"], float(d.kthvalue(int(d.numel() * 0.999))[0]))
+        m["fmed"] = max(m["fmed"], float(d.median()))
+        m["fmean"] = max(m["fmean"], float(d.mean()))
+    return m
+
+
+def fmt_metrics(m, meta):
+    return (f"crops max |d| {m['lsb']} LSB ({m['frac']:.1e} of the pixels > 1 LSB), min PSNR {m['psnr']:.2f} dB, "
+            f"block-mean |d| max {m['bm']:.2e} p99.9 {m['bm999']:.2e}, flowt |d| mean {m['fmean']:.2e} median {m['fmed']:.2e} "
+            f"p99.9 {m['flow999']:.2e} px (max |flow| {meta['flow_absmax']:.1f})")
+
+
+def check_hr(out, meta, z, prec, tag, kind="r"):
+    m = hr_metrics(out, meta, z)
+    worst_psnr, worst_lsb, worst_bm, worst_flow, worst_frac, worst_bm999, worst_fmed = (
+        m["psnr"], m["lsb"], m["bm"], m["flow999"], m["frac"], m["bm999"], m["fmed"])
+    print(f"{tag} {prec}: " + fmt_metrics(m, meta))
     # The reference formula has discontinuities: splat holes (0/0 -> 1, softsplat.py:333-334) and foldovers flip on a
     # 1e-6 flow difference, more of them the rougher the flow (the seeded random weights give GIMM-VFI-F 40-50 px flows
     # full of them).  Hence: R fp32 everything within 1 LSB; F fp32 all but <= 2e-4 of the pixels (measured: 0 on three

@@ -47,6 +47,9 @@ CONV_SHAPES = [
     (2, 256, 448, 32, 32, 3, 3, dict(act1=L.ACT_LRELU, with_res=True)),                       # auto -> tall 256x32 tile (cnn encoder)
     (2, 64, 112, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),                    # tall 256x32 tile, 128-byte chunks
     (4, 32, 56, 384, 128, 1, 5, dict(split=128, act1=L.ACT_RELU)),                            # auto -> 64-row tiles (224 workgroups)
+    (4, 32, 56, 384, 128, 1, 5, dict(split=128, act1=L.ACT_RELU, tile=128 | (64 << 10) | (3 << 20))),   # 3-deep ring
+    (4, 32, 56, 256, 256, 3, 3, dict(act1=L.ACT_RELU, tile=128 | (64 << 10) | (4 << 20))),            # 4-deep ring
+    (4, 32, 56, 128, 64, 3, 3, dict(act1=L.ACT_RELU, tile=64 | (4 << 20))),
     (1, 40, 56, 96, 96, 3, 3, dict(act1=L.ACT_RELU)),                                         # 64-byte chunks, 4-deep ring (counted vmcnt)
     # halo-staged 3x3 kernel (conv_p3x3.hip)
     (1, 17, 19, 64, 256, 3, 3, dict(algo=4, act1=L.ACT_PRELU, pad16=True, bf16_only=True)),

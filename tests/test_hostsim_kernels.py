@@ -41,6 +41,13 @@ CONV_SHAPES = [
     (1, 9, 40, 64, 70, 3, 3, dict(tile=128 | (64 << 10), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
     (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
     (1, 9, 12, 64, 130, 3, 3, dict(algo=2 + 128, tile=128)),
+    # deeper rings at 128-byte chunks (tile_hint bits 20..23): 3 / 4 stages in flight, counted vmcnt, KT < / > ring depth
+    (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10) | (3 << 20), split=64, act1=L.ACT_RELU)),
+    (1, 9, 12, 64, 130, 3, 3, dict(tile=128 | (64 << 10) | (4 << 20), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
+    (1, 6, 20, 64, 128, 1, 1, dict(tile=128 | (64 << 10) | (4 << 20))),        # a single K chunk in a 4-deep ring
+    (1, 9, 12, 128, 130, 3, 3, dict(tile=128 | (128 << 10) | (3 << 20), act1=L.ACT_LRELU)),
+    (1, 9, 12, 64, 40, 3, 3, dict(tile=64 | (4 << 20), act1=L.ACT_LRELU)),
+    (1, 9, 11, 128, 24, 3, 3, dict(tile=32 | (128 << 10) | (3 << 20), out_f32=True)),
     (1, 9, 12, 96, 40, 3, 3, dict(act1=L.ACT_LRELU)),
     (1, 18, 20, 32, 32, 3, 3, dict(tile=32 | (256 << 10), act1=L.ACT_LRELU, with_res=True)),
     (1, 18, 20, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),
