@@ -399,6 +399,9 @@ static int patch_plan(const gvfi_conv_params& p, PatchArgs& a) {
 extern "C" int gvfi_conv2d_patch_eligible(const gvfi_conv_params* pp) {
     PatchArgs a;
     if (patch_plan(*pp, a) == 0) return 0;
+    // (the launcher needs 16-byte aligned bases: an unaligned problem is NOT eligible, so that auto-routing falls
+    // through to the generic kernel instead of failing with -3)
+    if (((uintptr_t)pp->x0 & 15) || ((uintptr_t)pp->w & 15)) return 0;
     // worth it when the input is re-read per tap by the generic kernel and the output is wide enough for 64-pixel rows
     if (pp->KH * pp->KW < 9 || pp->Wo < 32 || (long long)pp->N * pp->Ho * pp->Wo < 16384) return 0;
     return 1;

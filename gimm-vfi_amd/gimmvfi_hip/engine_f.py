@@ -39,21 +39,29 @@ def _enc_host(xs, ys, dim):
                       torch.sin(3.14 * y * fb * (1 / 200)), torch.cos(3.14 * y * fb * (1 / 200))], dim=-1)
 
 
-FLOW_STAGES = ("enc", "cost", "dec")
+FLOW_STAGES = ("enc", "cost", "tok", "upd")
 
 
 def parse_flow_policy(spec):
-    """'bf16' / None -> no stage in float; 'fp32' -> all three; else a comma list of the stages that run in float:
-    enc (Twins encoders + channel convertor), cost (cost volume + latent cost encoder), dec (32-iteration decoder)."""
+    """'bf16' / None -> no stage in float; 'fp32' -> all; else a comma list of the stages that run in float:
+    enc (Twins encoders + channel convertor), cost (cost volume + latent cost encoder), and of the 32-iteration decoder
+    tok (flow token: 81-tap cost look-up, token encoder, cross-attention against the cost memory -> cost_global) and upd
+    (GMA update block: motion encoder, aggregation, ConvGRU, flow head); dec = tok + upd."""
     if spec in (None, "", "bf16"):
         return ()
     if spec == "fp32":
         return FLOW_STAGES
-    st = tuple(x.strip() for x in spec.split(",") if x.strip())
-    for x in st:
-        if x not in FLOW_STAGES:
-            raise ValueError(f"flow_precision: unknown stage {x!r} (stages: {FLOW_STAGES}, or 'bf16' / 'fp32')")
-    return st
+    st = []
+    for x in (y.strip() for y in spec.split(",")):
+        if not x:
+            continue
+        if x == "dec":
+            st += ["tok", "upd"]
+        elif x in FLOW_STAGES:
+            st.append(x)
+        else:
+            raise ValueError(f"flow_precision: unknown stage {x!r} (stages: {FLOW_STAGES} + 'dec', or 'bf16' / 'fp32')")
+    return tuple(dict.fromkeys(st))
 
 
 class EngineF(Engine):
@@ -465,9 +473,14 @@ class EngineF(Engine):
             taps["f01_cost_memory"] = mem.view(n, K_LAT, P8, 128)[:B]
         return vol, mem
 
-    def _ff_decode(self, vol, mem, context, n, B, h8, w8, iters, taps):
-        """Stage "dec": MemoryDecoder (decoder.py:257-321) -> full-resolution flows [n,H,W,2] float."""
+    def _ff_decode(self, vol, mem, context, n, B, h8, w8, iters, taps, tok=None, mem_tok=None, cvt=None):
+        """Stages "tok" + "upd": MemoryDecoder (decoder.py:257-321) -> full-resolution flows [n,H,W,2] float.  This engine
+        runs the update block; `tok` (default: this engine) runs the flow-token path of every iteration on `mem_tok` (the
+        cost memory in its activation type) and its cost tensor is converted with `cvt` for the update block."""
         rt, Ls = self.rt, self.layers
+        tok = self if tok is None else tok
+        mem_tok = mem if mem_tok is None else mem_tok
+        rtt = tok.rt
         if not hasattr(self, "_grids"):
             self._grids = {}
         P8 = h8 * w8
@@ -492,10 +505,11 @@ class EngineF(Engine):
             self._wv_rep[n] = self._wv.view(1, 1, 128, 128).expand(n, 1, 128, 128).contiguous()
         wv_rep = self._wv_rep[n]
         ca = md + ".decoder_layer.cross_attend"
-        kvm = self._linear(ca + ".kv", mem)                         # [n*K*P8, 128] = [key(64) | value(64)]
+        kvm = tok._linear(ca + ".kv", mem_tok)                      # [n*K*P8, 128] = [key(64) | value(64)]
         coords = rt.coords_init(n, h8, w8)
         corr = rt.act(n, h8, w8, 145, zero=True, pitch=max(rt.cp64(145), 192))    # [cost_global(64) | cost_forward(81) | 0 ...]
-        corr_rows = corr.view(n * P8, corr.shape[-1])
+        # (mixed policy: the token path fills its own copy in its activation type, converted once per iteration)
+        corr_t = corr if tok is self else rtt.act(n, h8, w8, 145, zero=True, pitch=max(rtt.cp64(145), 192))
         flow8 = rt.act(n, h8, w8, 2, zero=True)
         X = rt.act(n, h8, w8, 256)          # [motion(126) flow(2) | aggregated motion(128)]   gru.py:150-152
         mfc = rt.act(n, h8, w8, 128)
@@ -526,6 +540,8 @@ class EngineF(Engine):
             vol_s = vol[a * P8:b * P8]
             kvm_s = kvm[a * K_LAT * P8:b * K_LAT * P8]
             co, cr, fl, Xs, mf, vt = coords[a:b], corr[a:b], flow8[a:b], X[a:b], mfc[a:b], vT[a:b]
+            crt = corr_t[a:b]
+            crt_rows = crt.view(rows, crt.shape[-1])
             at, wv = attn[a:b], wv_rep[a:b]
             c1_, cfl, f1_, zb, rh_, fh_ = c1[a:b], corflo[a:b], f1[a:b], zbuf[a:b], rh[a:b], fh[a:b]
             ha, hb, fc, fp = hA[a:b], hB[a:b], fcol[a:b], fpart[a:b]
@@ -533,18 +549,20 @@ class EngineF(Engine):
             cr_rows = cr.view(rows, cr.shape[-1])
             for it in range(iters):
                 # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
-                rt.cost_lookup(vol_s, co, View(cr, 64, 81), rows, h8, w8)
-                t1 = self._linear(md + ".flow_token_encoder.0", View(cr_rows, 64, 128), act=A.ACT_GELU)   # 81 taps + zeros
-                query = self._linear(md + ".flow_token_encoder.2", t1)
+                rtt.cost_lookup(vol_s, co, View(crt, 64, 81), rows, h8, w8)
+                t1 = tok._linear(md + ".flow_token_encoder.0", View(crt_rows, 64, 128), act=A.ACT_GELU)   # 81 taps + zeros
+                query = tok._linear(md + ".flow_token_encoder.2", t1)
                 # cross-attention of the one query against the map's 8 latent tokens   decoder.py:84-120
-                qn = rt.layernorm(query, self.ln[ca + ".norm1"], 1e-5)
-                rt.pos_embed(co, rows, 1.0, 0.0, 64, qn, rows, True)
-                q = self._linear(ca + ".q", qn)
-                a_ = self._tok(rows, 64)
-                rt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)
-                x = self._linear(ca + ".proj", a_, x1=query, res=query)
-                y = rt.layernorm(x, self.ln[ca + ".norm2"], 1e-5)
-                self._linear(ca + ".ffn.3", self._linear(ca + ".ffn.0", y, act=A.ACT_GELU), out=View(cr_rows, 0, 64), res=x)
+                qn = rtt.layernorm(query, tok.ln[ca + ".norm1"], 1e-5)
+                rtt.pos_embed(co, rows, 1.0, 0.0, 64, qn, rows, True)
+                q = tok._linear(ca + ".q", qn)
+                a_ = tok._tok(rows, 64)
+                rtt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)
+                x = tok._linear(ca + ".proj", a_, x1=query, res=query)
+                y = rtt.layernorm(x, tok.ln[ca + ".norm2"], 1e-5)
+                tok._linear(ca + ".ffn.3", tok._linear(ca + ".ffn.0", y, act=A.ACT_GELU), out=View(crt_rows, 0, 64), res=x)
+                if tok is not self:
+                    cvt(View(crt_rows, 0, 145), View(cr_rows, 0, 145), 145)
                 # GMAUpdateBlock   gru.py:130-160
                 rt.flow_pack(co, fl, View(Xs, 126, 2))
                 rt.conv(Ls[u + ".encoder.convc1"], cr, c1_, act1=A.ACT_RELU)
@@ -604,8 +622,9 @@ class EngineF(Engine):
         cfeat, fmap = eng["enc"]._ff_encode(img_e, B, seq)
         ec = eng["cost"]
         vol, mem = ec._ff_cost(self._cvt(fmap, ec), self._cvt(cfeat[1], ec), n, B, h8, w8, taps)
-        ed = eng["dec"]
-        flow_up = ed._ff_decode(vol, self._cvt(mem, ed), self._cvt(cfeat[1], ed), n, B, h8, w8, iters, taps)
+        ed, et = eng["upd"], eng["tok"]
+        flow_up = ed._ff_decode(vol, self._cvt(mem, ed), self._cvt(cfeat[1], ed), n, B, h8, w8, iters, taps, tok=et,
+                                mem_tok=self._cvt(mem, et), cvt=self.rt.copy)
         cfeat = [self._cvt(f, self) for f in cfeat]
         fmap = self._cvt(fmap, self)
         if taps is not None:

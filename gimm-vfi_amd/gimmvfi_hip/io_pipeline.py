@@ -8,7 +8,11 @@ milliseconds) that loop, not the model, sets the frames/s of the CLI.  Here:
   consumer, into pinned host memory; the H2D copy is enqueued on a side HIP stream and handed over with an event, so
   decode and upload of pair j+1 overlap the forward of pair j;
 * ``ResultDrain``: result tensors are copied D2H asynchronously into pinned buffers on a second side stream; the
-  consumer thread does the CPU post-processing (colour-coding of flow, BGR conversion) while the GPU runs ahead.
+  consumer thread does the CPU post-processing (colour-coding of flow, BGR conversion) while the GPU runs ahead.  At most
+  ``depth`` items are between `submit` and the end of their post-processing, so the pinned buffers in flight are bounded;
+* ``VideoSink``: the output video is written WHILE the GPU computes: frames are handed over by index from the
+  post-processing threads and encoded in order (cv2.VideoWriter) or as numbered PNGs (any order) by the sink -- the
+  reference collects every frame of the video in a list and writes it after the loop (video_Nx.py:236-250).
 
 Pure host plumbing (threads, pinned buffers, streams, events): no arithmetic of the hot path lives here.
 """
@@ -99,6 +103,7 @@ class ResultDrain:
     landed.  ``results()`` returns {key: post result} after ``finish()``."""
 
     def __init__(self, device, depth=8, workers=4):
+        self.slots = threading.Semaphore(max(1, depth))     # items between submit() and the end of their post()
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
@@ -113,6 +118,13 @@ class ResultDrain:
         self.thread.start()
 
     def submit(self, key, tensors, post):
+        """Returns the event that marks the end of the D2H copies (None on CPU): a caller that re-uses `tensors` as
+        staging buffers waits for it before overwriting them."""
+        self.slots.acquire()
+        if self.err is not None:
+            self.slots.release()
+            raise self.err
+        ev = None
         if self.on_gpu:
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(self.device))
@@ -128,6 +140,13 @@ class ResultDrain:
             self.q.put((key, hosts, ev, post, tensors))     # `tensors` kept alive until the copy has completed
         else:
             self.q.put((key, [t.clone() for t in tensors], None, post, None))
+        return ev
+
+    def _post(self, post, hosts):
+        try:
+            return post(*hosts)
+        finally:
+            self.slots.release()
 
     def _run(self):
         while True:
@@ -138,9 +157,12 @@ class ResultDrain:
             try:
                 if ev is not None:
                     ev.synchronize()
-                self.pending.append((key, self.pool.submit(post, *hosts)))
-            except Exception as e:      # surfaced by finish()
+                self.pending.append((key, self.pool.submit(self._post, post, hosts)))
+                self.pending = [(k, f) for k, f in self.pending if not (f.done() and f.exception() is None and f.result() is None)] \
+                    if len(self.pending) > 64 else self.pending       # posts that return nothing leave nothing behind
+            except Exception as e:      # surfaced by finish() / the next submit()
                 self.err = e
+                self.slots.release()
 
     def finish(self):
         self.q.put(None)
@@ -154,3 +176,93 @@ class ResultDrain:
         if self.err is not None:
             raise self.err
         return self.out
+
+
+class VideoSink:
+    """Incremental writer of one output video (reference images_to_video, video_Nx.py:53-84, fed frame by frame).
+
+    ``put(index, frame_hwc_bgr_u8)`` may be called from any thread in any order; ``close()`` returns the path that was
+    written.  With OpenCV (and frames the mp4v writer accepts) frames are encoded in index order by one writer thread --
+    out-of-order frames wait in a dict whose size the producers bound (ResultDrain depth); otherwise every frame is saved
+    at once as PNG ``<stem>_frames/<index>.png`` (compression level 1; zlib releases the GIL) and ffmpeg, when present,
+    encodes them at close.  ``total``: number of frames, known up front."""
+
+    def __init__(self, path, fps, total, frame_hw, use_cv2=None):
+        import os
+
+        self.path, self.fps, self.total = path, fps, total
+        try:
+            import cv2
+        except Exception:
+            cv2 = None
+        h, w = frame_hw
+        big = max(h, w // 2) > 2048
+        self.cv2 = cv2 if (cv2 is not None and not big and use_cv2 is not False) else None
+        self.written = 0
+        self.err = None
+        self._lock = threading.Condition()
+        self._pending = {}
+        self._closed = False
+        if self.cv2 is not None:
+            self.writer = self.cv2.VideoWriter(path, self.cv2.VideoWriter_fourcc(*"mp4v"), fps, (w, h))
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+        else:
+            self.frame_dir = os.path.splitext(path)[0] + "_frames"
+            os.makedirs(self.frame_dir, exist_ok=True)
+
+    def put(self, index, frame):
+        assert 0 <= index < self.total
+        if self.cv2 is None:
+            from PIL import Image
+            import os
+
+            Image.fromarray(np.ascontiguousarray(frame[:, :, ::-1])).save(os.path.join(self.frame_dir, f"{index:04d}.png"), compress_level=1)
+            with self._lock:
+                self.written += 1
+            return
+        with self._lock:
+            self._pending[index] = frame
+            self._lock.notify_all()
+
+    def _run(self):
+        nxt = 0
+        while nxt < self.total:
+            with self._lock:
+                while nxt not in self._pending and not self._closed:
+                    self._lock.wait(timeout=1.0)
+                if nxt not in self._pending:
+                    return                      # closed early (error path)
+                frame = self._pending.pop(nxt)
+            try:
+                self.writer.write(np.ascontiguousarray(frame))
+            except Exception as e:
+                self.err = e
+                return
+            nxt += 1
+            self.written = nxt
+
+    def close(self):
+        import os
+        import shutil
+        import subprocess
+
+        if self.cv2 is not None:
+            with self._lock:
+                missing = self.total - self.written - len(self._pending)
+                if missing > 0:
+                    self._closed = True
+                self._lock.notify_all()
+            self.thread.join()
+            self.writer.release()
+            if self.err is not None:
+                raise self.err
+            assert self.written == self.total, (self.written, self.total)
+            return self.path
+        assert self.written == self.total, (self.written, self.total)
+        if shutil.which("ffmpeg"):
+            subprocess.run(["ffmpeg", "-y", "-framerate", f"{self.fps}", "-i", f"{self.frame_dir}/%04d.png", "-c:v", "libx264",
+                            "-pix_fmt", "yuv420p", self.path])
+            shutil.rmtree(self.frame_dir, ignore_errors=True)
+            return self.path
+        return self.frame_dir

@@ -339,6 +339,10 @@ class Runtime:
                 p.algo = 5 | (algo & ~15)   # mid-channel sibling (conv_p3x3s.hip)
             else:
                 p.w, p.w_layout = keep
+        if not self.use_p3x3 and layer is not None and (p.algo & 15) == 0:
+            # A/B switch GVFI_P3X3=0: with algo 0 the LIBRARY would still route to the halo-staged / patch kernels by itself;
+            # an explicit algo (LDS-DMA where it is eligible, else generic) makes the baseline really theirs
+            p.algo = (2 if self.lib.conv2d_glds_eligible(C.byref(p)) else 1) | (p.algo & ~15)
         self.last_stats_fused = False
         if stats is not None:
             p.stats = stats.data_ptr()
@@ -588,6 +592,7 @@ class Runtime:
     def flow_to_image(self, flows, wheel, bgr=True):
         """flows: [n, 2, h, w] float (contiguous) -> [n, h, w, 3] uint8 pictures (reference flow_viz.flow_to_image per image)."""
         n, _, h, w = flows.shape
+        assert flows.dtype == torch.float32 and flows.is_contiguous(), "flow_to_image reads raw [n,2,h,w] float planes"
         out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=self.device)
         scratch = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._chk(self.lib.flow_to_image(flows.data_ptr(), 2 * h * w, n, h, w, wheel.data_ptr(), scratch.data_ptr(), out.data_ptr(),

@@ -7,8 +7,10 @@ Same public names and contracts:
   stream.  The reference JIT-compiles a CuPy kernel per shape; here it is ``gvfi_softsplat_out_nchw`` of
   libgimmvfi_hip.so.  CPU tensors raise ``AssertionError`` like the reference (``assert False``, softsplat.py:439-440).
   Inference only: there is no backward.
-* ``softsplat(tenIn, tenFlow, tenMetric, strMode, return_norm=False)`` (softsplat.py:286-352): every mode of the
-  reference ("sum", "avg", "linear[-addeps|-zeroeps|-clipeps]", "softmax[-...]"), the same asserts, the same NaN guards.
+* ``softsplat(tenIn, tenFlow, tenMetric, strMode, return_norm=False)`` (contract of softsplat.py:286-352, written from
+  that contract, not from its text): every mode of the reference ("sum", "avg", "linear[-addeps|-zeroeps|-clipeps]",
+  "softmax[-...]"), AssertionError on a wrong mode / metric combination and on NaN inputs or outputs.  A caller who keeps
+  the reference's own wrapper only swaps ``softsplat_func``.
 
 The GIMM-VFI forward itself does not go through this module (it splats NHWC latents with ``gvfi_softsplat_accum`` / ``_normalize``); this is the
 boundary for callers that use the reference's op directly.
@@ -36,49 +38,44 @@ class softsplat_func:
         return tenOut
 
 
+_KINDS = ("sum", "avg", "linear", "softmax")
+# how the normaliser (the splatted weight channel) is made safe to divide by   softsplat.py:322-334
+_EPS_POLICY = {
+    None: lambda n: n + 0.0000001,
+    "addeps": lambda n: n + 0.0000001,
+    "zeroeps": lambda n: torch.where(n == 0.0, torch.ones_like(n), n),
+    "clipeps": lambda n: n.clip(0.0000001, None),
+}
+
+
+def _finite_or_die(t, where):
+    # the reference prints a message and `assert False`s on NaN inputs / outputs (softsplat.py:310-312,317-319,349-351)
+    assert not bool(torch.isnan(t).any()), f"softsplat: NaN values in {where}"
+
+
 def softsplat(tenIn, tenFlow, tenMetric, strMode, return_norm=False):
-    assert strMode.split("-")[0] in ["sum", "avg", "linear", "softmax"]
-    if strMode == "sum":
-        assert tenMetric is None
-    if strMode == "avg":
-        assert tenMetric is None
-    if strMode.split("-")[0] == "linear":
-        assert tenMetric is not None
-    if strMode.split("-")[0] == "softmax":
-        assert tenMetric is not None
-
-    if strMode == "avg":
-        tenIn = torch.cat([tenIn, tenIn.new_ones([tenIn.shape[0], 1, tenIn.shape[2], tenIn.shape[3]])], 1)
-    elif strMode.split("-")[0] == "linear":
-        tenIn = torch.cat([tenIn * tenMetric, tenMetric], 1)
-    elif strMode.split("-")[0] == "softmax":
-        tenIn = torch.cat([tenIn * tenMetric.exp(), tenMetric.exp()], 1)
-
-    if torch.isnan(tenIn).any():
-        print("NaN values detected during training in tenIn. Exiting.")
-        assert False
-
-    tenOut = softsplat_func.apply(tenIn, tenFlow)
-
-    if torch.isnan(tenOut).any():
-        print("NaN values detected during training in tenOut_1. Exiting.")
-        assert False
-
-    if strMode.split("-")[0] in ["avg", "linear", "softmax"]:
-        tenNormalize = tenOut[:, -1:, :, :]
-        if len(strMode.split("-")) == 1:
-            tenNormalize = tenNormalize + 0.0000001
-        elif strMode.split("-")[1] == "addeps":
-            tenNormalize = tenNormalize + 0.0000001
-        elif strMode.split("-")[1] == "zeroeps":
-            tenNormalize[tenNormalize == 0.0] = 1.0
-        elif strMode.split("-")[1] == "clipeps":
-            tenNormalize = tenNormalize.clip(0.0000001, None)
-        if return_norm:
-            return tenOut[:, :-1, :, :], tenNormalize
-        tenOut = tenOut[:, :-1, :, :] / tenNormalize
-
-    if torch.isnan(tenOut).any():
-        print("NaN values detected during training in tenOut_2. Exiting.")
-        assert False
-    return tenOut
+    """Forward splat of tenIn along tenFlow (contract of reference softsplat.py:286-352).  strMode = kind[-eps policy]:
+    kind "sum" (plain), "avg" (weight 1), "linear" (weight = metric), "softmax" (weight = exp(metric)); weighted kinds
+    splat [tenIn * weight | weight] in one pass and divide by the splatted weight made non-zero by the eps policy
+    (default / "addeps": + 1e-7, "zeroeps": 0 -> 1, "clipeps": clip at 1e-7).  return_norm: (numerator, normaliser)."""
+    kind, _, eps = strMode.partition("-")
+    assert kind in _KINDS, strMode
+    assert (tenMetric is None) == (kind in ("sum", "avg")), f"mode {kind!r}: metric {'not ' if tenMetric is None else ''}given"
+    if kind == "sum":
+        weight = None
+    elif kind == "avg":
+        weight = tenIn.new_ones([tenIn.shape[0], 1, tenIn.shape[2], tenIn.shape[3]])
+    else:
+        weight = tenMetric if kind == "linear" else tenMetric.exp()
+    src = tenIn if weight is None else torch.cat([tenIn if kind == "avg" else tenIn * weight, weight], 1)
+    _finite_or_die(src, "the splat input")
+    acc = softsplat_func.apply(src, tenFlow)
+    _finite_or_die(acc, "the splatted sums")
+    if weight is None:
+        return acc
+    norm = _EPS_POLICY[eps if eps in _EPS_POLICY else None](acc[:, -1:, :, :])
+    if return_norm:
+        return acc[:, :-1, :, :], norm
+    out = acc[:, :-1, :, :] / norm
+    _finite_or_die(out, "the normalised result")
+    return out

@@ -73,8 +73,9 @@ typedef struct {
                                          * outputs, atomically accumulated by the LDS-DMA kernel's bf16 store loop
                                          * (InstanceNorm statistics of raft/extractor.py:26-58 fused into the producing
                                          * convolution); needs Ho*Wo % BM == 0, see gvfi_conv2d_stats_ok */
-    int tile_hint;                      /* 0 = auto, else BN | BM << 10: Cout tile width 32/64/128/256 and (LDS-DMA kernel,
-                                         * BN = 128) pixel tile height 64/128 (BN = 128) or 128/256 (BN = 32) */
+    int tile_hint;                      /* 0 = auto, else BN | BM << 10 | NS << 20: Cout tile width 32/64/128/256, (LDS-DMA
+                                         * kernel) pixel tile height 64/128 (BN = 128) or 128/256 (BN = 32), and ring depth
+                                         * NS = 2..4 of its 128-byte K chunks (4-wave tiles) */
     int w_layout;                       /* 0: [Cout][KH][KW][Cin];  1 (LDS-DMA kernel only): K-chunk major,  *
                                          * [K/64][Cout][64] with the 16-byte groups of a row XOR-swizzled by *
                                          * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
@@ -259,7 +260,9 @@ int gvfi_cost_embed1(const float* vol, const float* w, const float* bias, void* 
 int gvfi_cost_lookup(const float* maps, const float* coords, void* out, int ldo, long long Q, int h, int w,
                      int radius, int dtype, void* stream);
 /* locally-grouped attention over ws x ws windows of an H x W token grid (twins.py:814-867, 331-427); kpad/vpad float
- * [ws*ws][heads*head_dim]: key / value of the window positions outside the grid; head_dim 8, 16 or 32 */
+ * [ws*ws][heads*head_dim]: key / value of the window positions outside the grid; head_dim 8, 16 or 32.  (bf16, head_dim
+ * 16 / 32: the MFMA path of attn_mfma.hip rounds these float tables to bf16 like every other key / value -- they are
+ * MFMA operands there; the scalar kernels of the float mode use them as given) */
 int gvfi_attn_window(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
                      const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
                      int head_dim, float scale, int dtype, void* stream);

@@ -226,3 +226,4 @@ def test_hires_f_matches_reference_fixture(sd_f, name, prec):
     check_hr(out, meta, z, prec, "F " + name, "f")
     del out, m
     torch.cuda.empty_cache()
+

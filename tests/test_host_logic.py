@@ -35,12 +35,30 @@ def _worker(rank, world, port, num_pairs, q):
     local = torch.stack([torch.full((3, 4, 5, 3), j, dtype=torch.uint8) for j in range(a, b)]) if b > a else \
         torch.zeros((0, 3, 4, 5, 3), dtype=torch.uint8)
     out = shard.gather_frames(local, num_pairs, rank, world)
-    out2 = shard.gather_frames_chunked(local, num_pairs, rank, world, chunk_pairs=2)     # several rounds, ragged last one
+    # streaming schedule of the CLI: rounds of world x 2 pairs, two result tensors per forward (frames + flow pictures),
+    # ragged / empty last sub-blocks; rank 0 re-assembles the video in order from the per-round pieces
+    ppf = 2
+    rg = shard.RoundGather(rank, world)
+    pieces = []
+    for rnd in shard.round_schedule(num_pairs, ppf, world):
+        j0, b = rnd[rank]
+        fr = torch.stack([torch.full((3, 4, 5, 3), j, dtype=torch.uint8) for j in range(j0, j0 + b)]) if b else \
+            torch.zeros((0, 3, 4, 5, 3), dtype=torch.uint8)
+        pics = (fr[:, :, :2, :2].reshape(-1, 2, 2, 3) + 100) if b else torch.zeros((0, 2, 2, 3), dtype=torch.uint8)
+        got = rg.gather([fr, pics], [(ppf, 3, 4, 5, 3), (ppf * 3, 2, 2, 3)],
+                        [[c for _, c in rnd], [3 * c for _, c in rnd]])
+        if rank == 0:
+            for r in range(world):
+                assert got[0][r].shape[0] == rnd[r][1] and got[1][r].shape[0] == 3 * rnd[r][1]
+                assert bool((got[1][r].reshape(-1) == (got[0][r][:, :, :2, :2].reshape(-1) + 100)).all())
+                pieces.append(got[0][r].clone())
+        else:
+            assert got is None
     if rank == 0:
-        assert torch.equal(out, out2)
+        assert torch.equal(out, torch.cat(pieces, 0))
         q.put(out.numpy())
     else:
-        assert out is None and out2 is None
+        assert out is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,6 +81,42 @@ def test_gather_frames_gloo_world2(num_pairs):
     assert got.shape == (num_pairs, 3, 4, 5, 3)
     for j in range(num_pairs):
         assert (got[j] == j).all()
+
+
+def test_round_schedule_covers_every_pair_once_in_order():
+    for m in (0, 1, 7, 8, 9, 31, 64):
+        for w in (1, 2, 3, 8):
+            for ppf in (1, 2, 8):
+                seen = []
+                for rnd in shard.round_schedule(m, ppf, w):
+                    assert len(rnd) == w
+                    for j0, b in rnd:
+                        assert 0 <= b <= ppf
+                        seen += list(range(j0, j0 + b))
+                assert seen == list(range(m))           # rank-major inside a round == video order
+
+
+def test_bench_launches_itself_world2_stub():
+    """`python bench.py --gpus 2` without a torchrun world starts its own two ranks (VERDICT r2: the driver's invocation);
+    `--stub` swaps the GPU step for a CPU/gloo stand-in so the launcher, the barrier / max-over-ranks timing and the
+    one-JSON-line contract are exercised here."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["world_size_rccl"] == 2 and rec["config"]["parallelism"] == "pair-sharded x2"
+    assert rec["value"] > 0 and rec["higher_is_better"] is True
+    # without the stub, more GPUs than the node has is a clear error, not an assertion deep inside
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert r2.returncode == 2 and "GPU(s) are visible" in r2.stderr
 
 
 def test_cli_helpers_config_padder_flowviz():
