@@ -233,18 +233,20 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
                     if (p.res) v += ld_any<T>(p.res, pix * p.ldr + cout, p.res_f32);   // hoisted context term
                     const float s = gvfi_sigmoid(v);
                     if (cout < half) {
-                        st_any<T>(p.y, pix * p.ldy + cout, 0, s);
+                        st_any<T>(p.y, pix * p.ldy + cout, p.state_f32, s);      // (state_f32: z stays float)
                     } else {
                         const int c = cout - half;
-                        const float h = ld_any<T>(p.aux0, pix * p.lda0 + c, 0);
+                        const float h = ld_any<T>(p.aux0, pix * p.lda0 + c, p.state_f32);
                         st_any<T>(p.y2, pix * p.ldy2 + c, 0, s * h);
                     }
                 } else {  // GVFI_EPI_GRU_Q
                     if (p.res) v += ld_any<T>(p.res, pix * p.ldr + cout, p.res_f32);
                     const float q = tanhf(v);
-                    const float h = ld_any<T>(p.aux0, pix * p.lda0 + cout, 0);
-                    const float z = ld_any<T>(p.aux1, pix * p.lda1 + cout, 0);
-                    st_any<T>(p.y, pix * p.ldy + cout, 0, (1.f - z) * h + z * q);
+                    const float h = ld_any<T>(p.aux0, pix * p.lda0 + cout, p.state_f32);
+                    const float z = ld_any<T>(p.aux1, pix * p.lda1 + cout, p.state_f32);
+                    const float hn = (1.f - z) * h + z * q;
+                    st_any<T>(p.y, pix * p.ldy + cout, 0, hn);
+                    if (p.state_f32 && p.y2 != nullptr) st_any<T>(p.y2, pix * p.ldy2 + cout, 1, hn);   // the float state
                 }
             }
         }

@@ -41,7 +41,18 @@ struct ConvArgs2 {
 // 8 consecutive output channels of one pixel: bias / activation / residual / GRU gate math on 8 values
 // and ONE 16-byte store (bf16) or two (f32), fully coalesced along the channel axis.  This keeps the
 // register footprint of the epilogue tiny (no spills with 128 accumulators) and replaces 2-byte stores.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE, int PPS = 1>
+//
+// BDIR ("weights direct", round 3; w_layout = 2): the recurrence convolutions (M = 14-28 k pixels, 224-448 workgroups, all
+// resident at once) were bound by the LATENCY of their own staging chain -- a 2-deep ring holds one 24 KB chunk in flight
+// per workgroup and a chunk takes ~1 us to land, against 256 cycles of MFMAs per wave (tools/ring_bench.py: 900-1350
+// cycles per K step whatever the tile).  Here only the A operand (pixels) goes through LDS; every wave owns a 32 / 64
+// column slice of the output for ALL rows of the tile and loads its weight fragments straight from a fragment-ordered
+// image ([K chunk][32-column block][k-step][lane][8]: one fully coalesced 1 KiB global load = one MFMA operand) into a
+// REGISTER ring NSTAGE chunks deep -- the register file, 512 KB per CU, is the prefetch buffer of the weight stream; the
+// LDS ring of the same depth costs 8 KB per stage.  The loads are ordinary loads (the compiler places their counted
+// s_waitcnt); the counted waits of the A pieces include them (every wave issues A_INSTR + NI*KK operations per chunk, in
+// that order, fenced by the asm statements around them).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE, int PPS = 1, bool BDIR = false>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel(ConvArgs2 a) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int VE = Elem<T>::VE;
@@ -52,11 +63,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     constexpr int KK = KB / 32;                    // MFMA k-steps per chunk
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_TOTAL = BM / RPI, B_TOTAL = BN / RPI;
+    constexpr int A_TOTAL = BM / RPI, B_TOTAL = BDIR ? 1 : BN / RPI;
     constexpr int A_INSTR = (A_TOTAL + NW - 1) / NW;   // LDS-DMA instructions per wave for the A / B tile
-    constexpr int B_INSTR = (B_TOTAL + NW - 1) / NW;
+    constexpr int B_INSTR = BDIR ? 0 : (B_TOTAL + NW - 1) / NW;
     constexpr int NPIECE = A_INSTR + B_INSTR;
-    constexpr int STAGE = (BM + BN) * RB;
+    constexpr int STAGE = (BM + (BDIR ? 0 : BN)) * RB;
+    static_assert(!BDIR || (WAVES_M == 1 && KB == 128 && sizeof(T) == 2 && A_TOTAL % NW == 0), "weights-direct variant");
     constexpr int AHEAD = NSTAGE - 1;              // chunks in flight beyond the one being consumed
     static_assert(MI >= 1 && NI >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile");
     static_assert((NSTAGE - 2) * NPIECE <= 63, "vmcnt range");
@@ -142,7 +154,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         a_mask[i] = ok ? mask : 0u;
     }
     stamp(7);   // (profiling) per-row decode + tap masks done
-    unsigned b_off[B_INSTR];
+    unsigned b_off[B_INSTR > 0 ? B_INSTR : 1];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int row = ((i * NW + wave) % B_TOTAL) * RPI + lrow;
@@ -249,7 +261,46 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         ld8f(p.act1 == GVFI_ACT_PRELU ? p.slope1 : nullptr, f1, gc.s1);
         ld8f(p.act2 == GVFI_ACT_PRELU ? p.slope2 : nullptr, f2, gc.s2);
     };
+    // (BDIR) register ring of weight fragments: slot = chunk % NSTAGE, [column block][k-step]
+    constexpr int NBL = NI * KK;                       // fragment loads per chunk and wave
+    uint4 bq[BDIR ? NSTAGE : 1][NI][KK];
+    // (the image holds ceil(Cout / 32) column blocks; blocks of a ragged last tile beyond it re-read the last one --
+    // their columns are never stored)
+    const int nb_tot = (p.Cout + 31) >> 5;
+    const size_t wf_chunk = (size_t)nb_tot * KK * 1024;     // bytes per K chunk of the fragment image
+    const unsigned char* wfrag[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        int nb = n0 / 32 + wn * NI + j;
+        nb = nb < nb_tot ? nb : nb_tot - 1;
+        wfrag[j] = (const unsigned char*)wg + ((size_t)nb * KK) * 1024 + lane * 16;
+    }
+    auto load_b = [&](int kt_, int slot) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const unsigned char* src = wfrag[j] + (size_t)kt_ * wf_chunk;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) bq[slot][j][kk] = *(const uint4*)(src + kk * 1024);
+        }
+    };
     // ---- prologue: fill the ring with chunks 0 .. AHEAD-1
+    if constexpr (BDIR) {
+        // unconditional issue (hipcc's counted waits need a fixed number of loads in flight on every path into the K
+        // loop): with fewer than AHEAD chunks the missing ones are phantoms -- all-zero A pieces (every row out of range)
+        // and a re-load of the last chunk's fragments into a slot nobody reads
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q) {
+            if (q < a.KT) stage_begin(q);
+            else {
+                st_sa = smem_lds + q * STAGE;
+                st_tapbit = 0u;
+            }
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc);
+            load_b(q < a.KT ? q : a.KT - 1, q);
+            GVFI_SCHED_BARRIER();
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < AHEAD; ++q) {
         if (q < a.KT) {
@@ -257,6 +308,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 #pragma unroll
             for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc);
         }
+    }
     }
     if (GC_EARLY) load_gc();   // behind the first chunk's DMA, in its shadow
     // MFMAs of chunk kt; when DMA is true the pieces of chunk kt+AHEAD are issued behind the MFMA groups (every wave
@@ -300,7 +352,68 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     // per chunk, so (AHEAD-1)*NPIECE is the count to wait for.  The last AHEAD chunks are drained without prefetch.
     stamp(1);
     int kt = (a.dbg & 16) ? a.KT : 0;   // profiling only: skip the K loop
-    if constexpr (NSTAGE == 2 && KK >= 2 && PIPE) {
+    if constexpr (BDIR) {
+        constexpr int OPS = A_INSTR + NBL;             // vector-memory operations per chunk and wave
+        static_assert((AHEAD - 1) * OPS <= 63, "vmcnt range");
+        // Unrolled by the ring depth: the register slot of a chunk is a compile-time index (U = c % NSTAGE), and so is
+        // whether a chunk issues the chunk AHEAD of it (ISSUE) and how many younger chunks are in flight behind it
+        // (YOUNGER): with the issue inside a run-time `if`, hipcc's own counted waits for the weight fragments fall back to
+        // the path on which nothing was issued and drain the ring (vmcnt(7) instead of 12+: one chunk of look-ahead left).
+        auto chunk = [&](int c, auto u_tag, auto issue_tag, auto younger_tag) {
+            constexpr int U = decltype(u_tag)::value;
+            constexpr bool ISSUE = decltype(issue_tag)::value;
+            constexpr int YOUNGER = decltype(younger_tag)::value;
+            glds_wait_n<YOUNGER * OPS>();     // chunk c (A pieces of this wave + its weight fragments) has landed
+            __syncthreads();      // every wave's A pieces of chunk c visible; every wave is done with chunk c-1's slot
+            if (c == 0) stamp(2);
+            if constexpr (ISSUE) {
+                stage_begin(c + AHEAD);
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc);
+                load_b(c + AHEAD, (U + AHEAD) % NSTAGE);
+            }
+            GVFI_SCHED_BARRIER();
+            const unsigned char* sa = smem + U * STAGE;
+            uint4 fa[2][MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[0][i] = *(const uint4*)(sa + a_rd[0] + i * 32 * RB);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk + 1 < KK) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[(kk + 1) & 1][i] = *(const uint4*)(sa + a_rd[kk + 1] + i * 32 * RB);
+                }
+                GVFI_SCHED_BARRIER();
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fa[kk & 1][i], bq[U][j][kk]);
+                GVFI_SCHED_BARRIER();
+            }
+        };
+        static_assert(NSTAGE == 4 && AHEAD == 3, "the chunk sequences below are written out for a ring of 4");
+        using std::integral_constant;
+        typedef std::true_type Y;
+        typedef std::false_type N;
+#define GVFI_CH(off, issue, younger) chunk(kt + (off), integral_constant<int, (off) % 4>{}, issue{}, integral_constant<int, younger>{})
+        // steady state: every chunk of the group issues
+        for (; kt + NSTAGE + AHEAD <= a.KT; kt += NSTAGE) {
+            GVFI_CH(0, Y, 2); GVFI_CH(1, Y, 2); GVFI_CH(2, Y, 2); GVFI_CH(3, Y, 2);
+        }
+        // tail: R = KT - kt chunks left (kt % 4 == 0); the first R - 3 of them still issue, the last three drain
+        switch (a.KT - kt) {
+            case 1: GVFI_CH(0, N, 2); break;                       // (KT < 3: phantom chunks are the younger ones)
+            case 2: GVFI_CH(0, N, 2); GVFI_CH(1, N, 1); break;
+            case 3: GVFI_CH(0, N, 2); GVFI_CH(1, N, 1); GVFI_CH(2, N, 0); break;
+            case 4: GVFI_CH(0, Y, 2); GVFI_CH(1, N, 2); GVFI_CH(2, N, 1); GVFI_CH(3, N, 0); break;
+            case 5: GVFI_CH(0, Y, 2); GVFI_CH(1, Y, 2); GVFI_CH(2, N, 2); GVFI_CH(3, N, 1); GVFI_CH(4, N, 0); break;
+            case 6: GVFI_CH(0, Y, 2); GVFI_CH(1, Y, 2); GVFI_CH(2, Y, 2); GVFI_CH(3, N, 2); GVFI_CH(4, N, 1); GVFI_CH(5, N, 0); break;
+            default: break;
+        }
+#undef GVFI_CH
+        glds_wait_n<0>();      // (phantom chunks of a K loop shorter than the ring: nothing may land after this point)
+        kt = a.KT;
+    } else if constexpr (NSTAGE == 2 && KK >= 2 && PIPE) {
         // ---- (8-wave tile only: with 2-3 resident 4-wave workgroups another workgroup fills the bubble and the shorter
         // DMA slack of this schedule costs 5-10 %, re-measured in round 2 with the peeled loop: 4-wave tiles stay on the
         // plain loop below)  two-buffer ring, software-pipelined across chunks: the barrier that publishes chunk kt+1 sits INSIDE the
@@ -590,70 +703,110 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             const int row_a = tid / GROUPS_PER_ROW;
             const long long pix0 = (long long)g * a.Mg + m_tile0;
             const bool is_q = p.epi_mode == GVFI_EPI_GRU_Q;
+            const bool sf = p.state_f32 != 0;    // float recurrent state: h (aux0), z (y of ZR / aux1 of Q) float, + y2 of Q
             const int half = p.Cout >> 1;
             const bool zhalf = !is_q && my_cout0 < half;
             const int c0 = (is_q || zhalf) ? my_cout0 : my_cout0 - half;
             bf16_t* yp = (zhalf || is_q ? (bf16_t*)p.y + pix0 * p.ldy : (bf16_t*)p.y2 + pix0 * p.ldy2) + c0;
             const int ldo = (zhalf || is_q) ? p.ldy : p.ldy2;
+            float* yzf = (float*)p.y + pix0 * p.ldy + c0;               // (sf) z as float
+            float* yhf = (float*)p.y2 + pix0 * p.ldy2 + c0;             // (sf, Q) new state as float
             const bf16_t* hp = (const bf16_t*)p.aux0 + pix0 * p.lda0 + c0;
             const bf16_t* zp = (const bf16_t*)p.aux1 + pix0 * p.lda1 + c0;
+            const float* hpf = (const float*)p.aux0 + pix0 * p.lda0 + c0;
+            const float* zpf = (const float*)p.aux1 + pix0 * p.lda1 + c0;
             const float* cp = cs + row_a * BN + my_cg * 8;
             // pre-activation context term (f32 [pixel][Cout]): the part of the gate convolution that reads RAFT's
             // constant context features is evaluated once per forward, not once per iteration
             const float* rp = (const float*)p.res + pix0 * p.ldr + my_cout0;
             const bool has_ctx = p.res != nullptr;
-            uint4 cpre[ITERS][2];
-            if (has_ctx) {
+            auto unpack_f32x8 = [](const uint4 (&u)[2], float (&o)[8]) {
+                o[0] = __builtin_bit_cast(float, u[0].x); o[1] = __builtin_bit_cast(float, u[0].y);
+                o[2] = __builtin_bit_cast(float, u[0].z); o[3] = __builtin_bit_cast(float, u[0].w);
+                o[4] = __builtin_bit_cast(float, u[1].x); o[5] = __builtin_bit_cast(float, u[1].y);
+                o[6] = __builtin_bit_cast(float, u[1].z); o[7] = __builtin_bit_cast(float, u[1].w);
+            };
+            auto store_f32x8 = [](float* dst, const float (&v)[8]) {
+                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            };
+            // rows are processed PF iterations at a time, the state operands of a group all in flight together: the whole
+            // pass with bf16 state, two iterations with float state (twice the registers per row)
+            auto gru_rows = [&](auto sf_tag) {
+                constexpr bool SF = decltype(sf_tag)::value;
+                constexpr int PF = SF ? (ITERS < 2 ? ITERS : 2) : ITERS;
+                static_assert(ITERS % PF == 0, "prefetch groups");
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
-                    if (m_tile0 + tr < a.Mg) {
-                        const uint4* q4 = (const uint4*)(rp + (long long)tr * p.ldr);
-                        cpre[it][0] = q4[0];
-                        cpre[it][1] = q4[1];
+                for (int c = 0; c < ITERS / PF; ++c) {
+                    uint4 cpre[PF][2], hpre[PF][SF ? 2 : 1], zpre[PF][SF ? 2 : 1];
+#pragma unroll
+                    for (int q = 0; q < PF; ++q) {
+                        const int it = c * PF + q;
+                        const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
+                        if (m_tile0 + tr >= a.Mg) continue;
+                        if (has_ctx) {
+                            const uint4* q4 = (const uint4*)(rp + (long long)tr * p.ldr);
+                            cpre[q][0] = q4[0];
+                            cpre[q][1] = q4[1];
+                        }
+                        if (!zhalf) {
+                            if constexpr (SF) {
+                                const uint4* h4 = (const uint4*)(hpf + (long long)tr * p.lda0);
+                                hpre[q][0] = h4[0];
+                                hpre[q][1] = h4[1];
+                                if (is_q) {
+                                    const uint4* z4 = (const uint4*)(zpf + (long long)tr * p.lda1);
+                                    zpre[q][0] = z4[0];
+                                    zpre[q][1] = z4[1];
+                                }
+                            } else {
+                                hpre[q][0] = *(const uint4*)(hp + (long long)tr * p.lda0);
+                                if (is_q) zpre[q][0] = *(const uint4*)(zp + (long long)tr * p.lda1);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < PF; ++q) {
+                        const int it = c * PF + q;
+                        const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
+                        if (m_tile0 + tr >= a.Mg) continue;
+                        const float4 c0v = *(const float4*)(cp + it * ROWS_PER_IT * BN);
+                        const float4 c1v = *(const float4*)(cp + it * ROWS_PER_IT * BN + 4);
+                        float vv[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
+                        float hh[8], zz[8];
+                        if (!zhalf) {
+                            if constexpr (SF) unpack_f32x8(hpre[q], hh); else unpack_bf16x8(hpre[q][0], hh);
+                        }
+                        if (is_q) {
+                            if constexpr (SF) unpack_f32x8(zpre[q], zz); else unpack_bf16x8(zpre[q][0], zz);
+                        }
+                        if (has_ctx) {
+                            float cc[8];
+                            unpack_f32x8(cpre[q], cc);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) vv[e] += cc[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float t = vv[e] + gc.bias[e];
+                            if (is_q) vv[e] = (1.f - zz[e]) * hh[e] + zz[e] * fast_tanh(t);
+                            else vv[e] = zhalf ? fast_sigmoid(t) : fast_sigmoid(t) * hh[e];
+                        }
+                        if (SF && zhalf) {
+                            store_f32x8(yzf + (long long)tr * p.ldy, vv);       // z stays float
+                            continue;
+                        }
+                        uint4 u;
+                        u.x = pack_bf16x2(vv[0], vv[1]);
+                        u.y = pack_bf16x2(vv[2], vv[3]);
+                        u.z = pack_bf16x2(vv[4], vv[5]);
+                        u.w = pack_bf16x2(vv[6], vv[7]);
+                        *(uint4*)(yp + (long long)tr * ldo) = u;
+                        if (SF && is_q && p.y2 != nullptr) store_f32x8(yhf + (long long)tr * p.ldy2, vv);   // the state itself
                     }
                 }
-            }
-            uint4 hpre[ITERS], zpre[ITERS];
-            if (!zhalf) {
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
-                    if (m_tile0 + tr < a.Mg) {
-                        hpre[it] = *(const uint4*)(hp + (long long)tr * p.lda0);
-                        if (is_q) zpre[it] = *(const uint4*)(zp + (long long)tr * p.lda1);
-                    }
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
-                if (m_tile0 + tr >= a.Mg) continue;
-                const float4 c0v = *(const float4*)(cp + it * ROWS_PER_IT * BN);
-                const float4 c1v = *(const float4*)(cp + it * ROWS_PER_IT * BN + 4);
-                float vv[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
-                float hh[8], zz[8];
-                if (!zhalf) unpack_bf16x8(hpre[it], hh);
-                if (is_q) unpack_bf16x8(zpre[it], zz);
-                if (has_ctx) {
-                    vv[0] += __builtin_bit_cast(float, cpre[it][0].x); vv[1] += __builtin_bit_cast(float, cpre[it][0].y);
-                    vv[2] += __builtin_bit_cast(float, cpre[it][0].z); vv[3] += __builtin_bit_cast(float, cpre[it][0].w);
-                    vv[4] += __builtin_bit_cast(float, cpre[it][1].x); vv[5] += __builtin_bit_cast(float, cpre[it][1].y);
-                    vv[6] += __builtin_bit_cast(float, cpre[it][1].z); vv[7] += __builtin_bit_cast(float, cpre[it][1].w);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = vv[e] + gc.bias[e];
-                    if (is_q) vv[e] = (1.f - zz[e]) * hh[e] + zz[e] * fast_tanh(t);
-                    else vv[e] = zhalf ? fast_sigmoid(t) : fast_sigmoid(t) * hh[e];
-                }
-                uint4 u;
-                u.x = pack_bf16x2(vv[0], vv[1]);
-                u.y = pack_bf16x2(vv[2], vv[3]);
-                u.z = pack_bf16x2(vv[4], vv[5]);
-                u.w = pack_bf16x2(vv[6], vv[7]);
-                *(uint4*)(yp + (long long)tr * ldo) = u;
-            }
+            };
+            if (sf) gru_rows(std::true_type{}); else gru_rows(std::false_type{});
             if (ps + 1 < NPASS) __syncthreads();
             continue;
         }
@@ -709,7 +862,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE = false, int PPS = 1>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE = false, int PPS = 1, bool BDIR = false>
 static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     constexpr int BKE = KB / (int)sizeof(T);
     ConvArgs2 a;
@@ -727,7 +880,7 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     gvfi_magic_div((unsigned)p.Wo, a.wo_mul, a.wo_sh);
     a.dbg = (p.algo >> 8) & 0xff;   // profiling switches: algo bits 8.. (8 = no epilogue, 16 = no K loop)
     dim3 grid(a.per_xcd * 8, 1, groups);
-    GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE, PPS>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
+    GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE, PPS, BDIR>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
     return (int)hipGetLastError();
 }
 
@@ -738,6 +891,7 @@ extern "C" int gvfi_conv2d_stats_ok(const gvfi_conv_params* pp) {
     int plan[5];
     // the mid-channel halo-staged kernel (conv_p3x3s.hip) accumulates them in its store loop too
     if ((p.algo & 15) == 5 || ((p.algo & 15) == 0 && gvfi_conv2d_p3x3s_eligible(pp) == 1)) return gvfi_conv2d_p3x3s_eligible(pp) != 0;
+    if (p.w_layout == 2) return 0;   // (the recurrence layers of the weights-direct variant are not normalised)
     if (p.dtype != GVFI_BF16 || (p.algo & 15) == 1 || !((p.algo & 15) == 2 || gvfi_conv2d_glds_eligible(pp))) return 0;
     if (gvfi_conv2d_glds_plan(pp, plan) != 0 || plan[2] >= 256) return 0;   // (not in the 8-wave tile)
     if (p.epi_mode != GVFI_EPI_STD || p.y_f32 || (p.res && p.res_f32) || p.act1 > GVFI_ACT_PRELU || p.act2 > GVFI_ACT_PRELU)
@@ -773,6 +927,17 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     if (!kb) return -2;
     const int groups = p.groups > 0 ? p.groups : 1;
     const long long M = (long long)p.N * p.Ho * p.Wo / groups;
+    if (p.w_layout == 2) {
+        // weights-direct variant: fragment-ordered weight image, 64-row tiles, column tile 128 (wave slices of 32) or 256
+        // (slices of 64; tile_hint 256), register / LDS ring of 4 chunks
+        if (kb != 128 || p.dtype != GVFI_BF16 || groups != 1) return -5;
+        plan[0] = 6;
+        plan[1] = 64;
+        plan[2] = (p.tile_hint & 1023) == 256 ? 256 : 128;
+        plan[3] = 128;
+        plan[4] = 4;
+        return 0;
+    }
     int tile = p.tile_hint & 1023, bm = (p.tile_hint >> 10) & 1023;
     const int ns_hint = (p.tile_hint >> 20) & 15;   // ring depth override (0 = auto), 128-byte chunks only
     if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
@@ -814,6 +979,10 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (p.groups > 1 && (p.N % p.groups)) return -4;
     if (p.stats != nullptr && !gvfi_conv2d_stats_ok(pp)) return -6;   // statistics requested but not computable here
     hipStream_t st = (hipStream_t)stream;
+    if (plan[0] == 6) {
+        if (plan[2] == 256) return launch_glds<bf16_t, 64, 256, 1, 4, 128, 4, false, 1, true>(p, st);
+        return launch_glds<bf16_t, 64, 128, 1, 4, 128, 4, false, 1, true>(p, st);
+    }
     const int bm = plan[1], tile = plan[2], k = plan[3], ns = plan[4];
 #define GLDS_DISPATCH(TT)                                                                                     \
     if (tile == 256) {                                                                                        \

@@ -278,19 +278,20 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gvfi_sigmoid(v[e]);
+        const int sf = p.state_f32;     // float recurrent state (z, h), see gvfi_conv_params.state_f32
         if (cout0 < half) {
-            if (vec) st8(p.y, pix * p.ldy + cout0, 0, BF, v);
+            if (vec) st8(p.y, pix * p.ldy + cout0, sf, BF, v);
             else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, 0, v[e]);
+                for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, sf, v[e]);
             }
         } else {
             const int c0 = cout0 - half;
             float h[8];
-            if (vec) ld8(p.aux0, pix * p.lda0 + c0, 0, BF, h);
+            if (vec) ld8(p.aux0, pix * p.lda0 + c0, sf, BF, h);
             else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) h[e] = (e < n_valid) ? ld_any<T>(p.aux0, pix * p.lda0 + c0 + e, 0) : 0.f;
+                for (int e = 0; e < 8; ++e) h[e] = (e < n_valid) ? ld_any<T>(p.aux0, pix * p.lda0 + c0 + e, sf) : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= h[e];
@@ -306,15 +307,16 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
             for (int e = 0; e < 8; ++e)
                 if (e < n_valid) v[e] += ld_any<T>(p.res, pix * p.ldr + cout0 + e, p.res_f32);
         }
+        const int sf = p.state_f32;
         float h[8], z[8];
         if (vec) {
-            ld8(p.aux0, pix * p.lda0 + cout0, 0, BF, h);
-            ld8(p.aux1, pix * p.lda1 + cout0, 0, BF, z);
+            ld8(p.aux0, pix * p.lda0 + cout0, sf, BF, h);
+            ld8(p.aux1, pix * p.lda1 + cout0, sf, BF, z);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                h[e] = (e < n_valid) ? ld_any<T>(p.aux0, pix * p.lda0 + cout0 + e, 0) : 0.f;
-                z[e] = (e < n_valid) ? ld_any<T>(p.aux1, pix * p.lda1 + cout0 + e, 0) : 0.f;
+                h[e] = (e < n_valid) ? ld_any<T>(p.aux0, pix * p.lda0 + cout0 + e, sf) : 0.f;
+                z[e] = (e < n_valid) ? ld_any<T>(p.aux1, pix * p.lda1 + cout0 + e, sf) : 0.f;
             }
         }
 #pragma unroll
@@ -323,6 +325,13 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, 0, v[e]);
+        }
+        if (sf && p.y2 != nullptr) {   // the float state beside its bf16 operand copy
+            if (vec) st8(p.y2, pix * p.ldy2 + cout0, 1, BF, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y2, pix * p.ldy2 + cout0 + e, 1, v[e]);
+            }
         }
     }
 }

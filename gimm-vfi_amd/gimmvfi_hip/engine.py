@@ -55,6 +55,8 @@ class Engine:
         self.g9 = sd["g_filter"].float().reshape(9).contiguous().to(rt.device)
         # number of parallel launch sequences the flow estimator's recurrence is split into (sub-batches of images)
         self.raft_lanes = int(os.environ.get("GVFI_RAFT_LANES", "2"))
+        # float GRU state in bf16 mode (gvfi_conv_params.state_f32); GVFI_GRU_STATE_F32=0 is the A/B switch
+        self.gru_state_f32 = os.environ.get("GVFI_GRU_STATE_F32", "1") != "0"
         self.layers = {}
         self._build(sd)
 
@@ -62,8 +64,8 @@ class Engine:
     def _add(self, name, w, b, **kw):
         self.layers[name] = ConvLayer(self.rt, w, b, **kw)
 
-    def _patch_conv(self, sd, key):
-        self.layers[key] = PatchConvLayer(self.rt, sd[key + ".weight"], sd[key + ".bias"])
+    def _patch_conv(self, sd, key, wdir=False):
+        self.layers[key] = PatchConvLayer(self.rt, sd[key + ".weight"], sd[key + ".bias"], wdir=wdir)
 
     def _conv(self, sd, key, name=None, bn=None, slope=None, **kw):
         w, b = sd[key + ".weight"], sd[key + ".bias"]
@@ -138,10 +140,12 @@ class Engine:
         self._add("cnet.out_net", w[:128], b[:128])   # tanh half   raft/raft.py:134-136
         self._add("cnet.out_inp", w[128:], b[128:])   # relu half
         u = fe + ".update_block"
-        self._conv(sd, f"{u}.encoder.convc1", cin_pad=self.rt.cp64(324))
-        self._patch_conv(sd, f"{u}.encoder.convf1")   # 2 -> 128, 7x7: im2col + 1x1
-        for k in ("encoder.convc2", "encoder.convf2", "encoder.conv",
-                  "flow_head.conv1", "mask.0", "mask.2"):
+        # wdir: the layers of the 20-iteration recurrence take the weights-direct variant of the LDS-DMA kernel
+        self._conv(sd, f"{u}.encoder.convc1", cin_pad=self.rt.cp64(324), wdir=True)
+        self._patch_conv(sd, f"{u}.encoder.convf1", wdir=True)   # 2 -> 128, 7x7: im2col + 1x1
+        for k in ("encoder.convc2", "encoder.convf2", "encoder.conv", "flow_head.conv1"):
+            self._conv(sd, f"{u}.{k}", wdir=True)
+        for k in ("mask.0", "mask.2"):
             self._conv(sd, f"{u}.{k}")
         # 256 -> 2, 3x3 on the iteration's critical path: 1x1 to the 18 per-tap partial sums + tap gather
         k = f"{u}.flow_head.conv2"
@@ -156,8 +160,8 @@ class Engine:
             wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
             wq, bq = sd[f"{u}.gru.convq{n}.weight"], sd[f"{u}.gru.convq{n}.bias"]
             keep = list(range(0, 128)) + list(range(256, 384))
-            self._add(f"gru.zr{n}", wzr[:, keep], None)
-            self._add(f"gru.q{n}", wq[:, keep], None)
+            self._add(f"gru.zr{n}", wzr[:, keep], None, wdir=True)
+            self._add(f"gru.q{n}", wq[:, keep], None, wdir=True)
             self._add(f"gru.zr{n}.ctx", wzr[:, 128:256], bzr)
             self._add(f"gru.q{n}.ctx", wq[:, 128:256], bq)
         for k in ("amt_last_cproj", "amt_second_last_cproj", "amt_fproj"):
@@ -292,7 +296,16 @@ class Engine:
         hA = rt.act(n, h8, w8, 128)
         hB = rt.act(n, h8, w8, 128)
         xbuf = rt.act(n, h8, w8, 256)     # [inp(128) | motion(126) | flow(2)]  raft/update.py:143-144
-        rt.conv(Ls["cnet.out_net"], c128, hA, act1=A.ACT_TANH)
+        # bf16 mode: the GRU state h (and the gate z) live in FLOAT beside the bf16 operand copies the convolutions read --
+        # the state is an accumulator over the iterations, the one place where bf16 rounding would pile up
+        sf = self.gru_state_f32 and rt.precision == "bf16"
+        h32A = rt.f32(n, h8, w8, 128) if sf else None
+        h32B = rt.f32(n, h8, w8, 128) if sf else None
+        if sf:
+            rt.conv(Ls["cnet.out_net"], c128, h32A, act1=A.ACT_TANH)
+            rt.copy(h32A, hA, 128)
+        else:
+            rt.conv(Ls["cnet.out_net"], c128, hA, act1=A.ACT_TANH)
         rt.conv(Ls["cnet.out_inp"], c128, View(xbuf, 0, 128), act1=A.ACT_RELU)
         # correlation pyramids: direction 0->1 for images [0,B), 1->0 for [B,2B)
         # correlation pyramids of both directions in one grouped GEMM: image i against its partner (i +- B)
@@ -311,7 +324,7 @@ class Engine:
         c1 = rt.act(n, h8, w8, 256)
         corflo = rt.act(n, h8, w8, 256)
         f1 = rt.act(n, h8, w8, 128)
-        zbuf = rt.act(n, h8, w8, 128)
+        zbuf = rt.f32(n, h8, w8, 128) if sf else rt.act(n, h8, w8, 128)
         rh = rt.act(n, h8, w8, 128)
         fh = rt.act(n, h8, w8, 256)
         u = fe + ".update_block"
@@ -333,6 +346,7 @@ class Engine:
             co, cf, fl, xb = coords[a:b], corrf[a:b], flow8[a:b], xbuf[a:b]
             c1_, cfl, f1_, zb, rh_, fh_ = c1[a:b], corflo[a:b], f1[a:b], zbuf[a:b], rh[a:b], fh[a:b]
             ha, hb, fc, fp = hA[a:b], hB[a:b], fcol[a:b], fpart[a:b]
+            h32 = (h32A[a:b], h32B[a:b]) if sf else (None, None)
             cx = {k: v[a:b] for k, v in ctx.items()}
             for it in range(iters):
                 rt.corr_lookup(pyr_s, co, cf, m, h8, w8, h8, w8)
@@ -346,11 +360,15 @@ class Engine:
                 rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.conv"], cfl, View(xb, 128, 126), act1=A.ACT_RELU)
                 hc, hn = ha, hb
+                sc, sn = h32
                 for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73
                     xm = View(xb, 128, 128)   # [motion(126) | flow(2)]
-                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=xm, epi=A.EPI_GRU_ZR, y2=rh_, aux0=hc, res=cx["gru.zr" + nn_])
-                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=xm, epi=A.EPI_GRU_Q, aux0=hc, aux1=zb, res=cx["gru.q" + nn_])
+                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=xm, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
+                            res=cx["gru.zr" + nn_], state_f32=sf)
+                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=xm, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
+                            y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
                     hc, hn = hn, hc
+                    sc, sn = sn, sc
                 # after two passes the state is back in hA
                 rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)
                 rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh_, View(co), res=View(co), scratch=fp)   # coords1 += delta

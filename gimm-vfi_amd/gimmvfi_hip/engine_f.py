@@ -85,14 +85,15 @@ class EngineF(Engine):
 
     # ------------------------------------------------------------------ weight preparation
     def _lin(self, sd, key, name=None, **kw):
+        kw = {k: v for k, v in kw.items() if k != "wdir" or v}
         w = sd[key + ".weight"]
         b = sd.get(key + ".bias")
         self._add(name or key, w.reshape(w.shape[0], w.shape[1], 1, 1), b, **kw)
 
-    def _lin_cat(self, sd, keys, name):
+    def _lin_cat(self, sd, keys, name, **kw):
         w = torch.cat([sd[k + ".weight"] for k in keys], 0)
         b = torch.cat([sd[k + ".bias"] for k in keys], 0)
-        self._add(name, w.reshape(w.shape[0], w.shape[1], 1, 1), b)
+        self._add(name, w.reshape(w.shape[0], w.shape[1], 1, 1), b, **kw)
 
     def _ln(self, sd, key):
         self.ln[key] = (sd[key + ".weight"].float().contiguous().to(self.rt.device),
@@ -131,17 +132,17 @@ class EngineF(Engine):
             self.consts[k + ".b"] = self._f32(sd[k + ".bias"])
             cin = c
 
-    def _build_attn_layer(self, sd, p, merge_qkv):
+    def _build_attn_layer(self, sd, p, merge_qkv, wdir=False):
         self._ln(sd, p + ".norm1")
         self._ln(sd, p + ".norm2")
         if merge_qkv:
             self._lin_cat(sd, (p + ".q", p + ".k", p + ".v"), p + ".qkv")
         else:
-            self._lin(sd, p + ".q")
+            self._lin(sd, p + ".q", wdir=wdir)
             self._lin_cat(sd, (p + ".k", p + ".v"), p + ".kv")
-        self._lin(sd, p + ".proj")
-        self._lin(sd, p + ".ffn.0")
-        self._lin(sd, p + ".ffn.3")
+        self._lin(sd, p + ".proj", wdir=wdir)
+        self._lin(sd, p + ".ffn.0", wdir=wdir)
+        self._lin(sd, p + ".ffn.3", wdir=wdir)
 
     def _build_vertical(self, sd, p, local):
         self._ln(sd, p + ".norm1")
@@ -196,17 +197,20 @@ class EngineF(Engine):
         md = fe + ".memory_decoder"
         # (K = 81 cost taps padded to 128 zero-weighted channels: two whole K chunks of the LDS-DMA kernel instead of 88
         # channels on the generic one -- 61 -> 12 us per decoder iteration)
-        self._conv(sd, md + ".flow_token_encoder.0", cin_pad=128)
-        self._conv(sd, md + ".flow_token_encoder.2")
+        self._conv(sd, md + ".flow_token_encoder.0", cin_pad=128, wdir=True)
+        self._conv(sd, md + ".flow_token_encoder.2", wdir=True)
         w, b = sd[md + ".proj.weight"], sd[md + ".proj.bias"]
         self._add("ff.proj_net", w[:128], b[:128])     # tanh half   decoder.py:279-281
         self._add("ff.proj_inp", w[128:], b[128:])     # relu half
-        self._build_attn_layer(sd, md + ".decoder_layer.cross_attend", False)
+        self._build_attn_layer(sd, md + ".decoder_layer.cross_attend", False, wdir=True)
         u = md + ".update_block"
-        self._conv(sd, u + ".encoder.convc1", cin_pad=max(self.rt.cp64(145), 192))     # = the pitch of the cost tensor
+        # wdir: the layers of the 32-iteration recurrence take the weights-direct variant of the LDS-DMA kernel
+        self._conv(sd, u + ".encoder.convc1", cin_pad=max(self.rt.cp64(145), 192), wdir=True)     # = the pitch of the cost tensor
         self.layers[u + ".encoder.convf1"] = PatchConvLayer(self.rt, sd[u + ".encoder.convf1.weight"],
-                                                            sd[u + ".encoder.convf1.bias"])
-        for k in ("encoder.convc2", "encoder.convf2", "encoder.conv", "flow_head.conv1", "mask.0", "mask.2"):
+                                                            sd[u + ".encoder.convf1.bias"], wdir=True)
+        for k in ("encoder.convc2", "encoder.convf2", "encoder.conv", "flow_head.conv1"):
+            self._conv(sd, f"{u}.{k}", wdir=True)
+        for k in ("mask.0", "mask.2"):
             self._conv(sd, f"{u}.{k}")
         k = u + ".flow_head.conv2"
         self.layers[k] = TapSplitConvLayer(self.rt, sd[k + ".weight"], sd[k + ".bias"])
@@ -218,8 +222,8 @@ class EngineF(Engine):
             wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
             wq, bq = sd[f"{u}.gru.convq{n}.weight"], sd[f"{u}.gru.convq{n}.bias"]
             keep = list(range(0, 128)) + list(range(256, 512))
-            self._add(f"gru.zr{n}", wzr[:, keep], None)
-            self._add(f"gru.q{n}", wq[:, keep], None)
+            self._add(f"gru.zr{n}", wzr[:, keep], None, wdir=True)
+            self._add(f"gru.q{n}", wq[:, keep], None, wdir=True)
             self._add(f"gru.zr{n}.ctx", wzr[:, 128:256], bzr)
             self._add(f"gru.q{n}.ctx", wq[:, 128:256], bq)
         # GMA (gma.py:32-115): q pre-scaled by dim_head^-0.5, gamma folded into to_v
@@ -488,7 +492,15 @@ class EngineF(Engine):
         hA = rt.act(n, h8, w8, 128)
         hB = rt.act(n, h8, w8, 128)
         inp = rt.act(n, h8, w8, 128)
-        rt.conv(Ls["ff.proj_net"], context, hA, act1=A.ACT_TANH)
+        # bf16 mode: float GRU state beside the bf16 operand copies, as in Engine._raft
+        sf = self.gru_state_f32 and rt.precision == "bf16"
+        h32A = rt.f32(n, h8, w8, 128) if sf else None
+        h32B = rt.f32(n, h8, w8, 128) if sf else None
+        if sf:
+            rt.conv(Ls["ff.proj_net"], context, h32A, act1=A.ACT_TANH)
+            rt.copy(h32A, hA, 128)
+        else:
+            rt.conv(Ls["ff.proj_net"], context, hA, act1=A.ACT_TANH)
         rt.conv(Ls["ff.proj_inp"], context, inp, act1=A.ACT_RELU)
         # GMA attention (once): softmax(q k^T / sqrt(128))   gma.py:53-76
         gq = rt.act(n, h8, w8, 128)
@@ -517,7 +529,7 @@ class EngineF(Engine):
         c1 = rt.act(n, h8, w8, 256)
         corflo = rt.act(n, h8, w8, 256)
         f1 = rt.act(n, h8, w8, 128)
-        zbuf = rt.act(n, h8, w8, 128)
+        zbuf = rt.f32(n, h8, w8, 128) if sf else rt.act(n, h8, w8, 128)
         rh = rt.act(n, h8, w8, 128)
         fh = rt.act(n, h8, w8, 256)
         u = md + ".update_block"
@@ -545,6 +557,7 @@ class EngineF(Engine):
             at, wv = attn[a:b], wv_rep[a:b]
             c1_, cfl, f1_, zb, rh_, fh_ = c1[a:b], corflo[a:b], f1[a:b], zbuf[a:b], rh[a:b], fh[a:b]
             ha, hb, fc, fp = hA[a:b], hB[a:b], fcol[a:b], fpart[a:b]
+            h32 = (h32A[a:b], h32B[a:b]) if sf else (None, None)
             cx = {k_: v[a:b] for k_, v in ctxg.items()}
             cr_rows = cr.view(rows, cr.shape[-1])
             for it in range(iters):
@@ -577,10 +590,14 @@ class EngineF(Engine):
                 rt.conv(None, View(at, 0, P8), View(Xr, 128, 128), groups=m, w_group_stride=128 * P8p, w_raw=vt, cout=128,
                         res=View(Xr, 0, 128))
                 hc, hn = ha, hb
+                sc, sn = h32
                 for nn_ in ("1", "2"):
-                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=Xs, epi=A.EPI_GRU_ZR, y2=rh_, aux0=hc, res=cx["gru.zr" + nn_])
-                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=Xs, epi=A.EPI_GRU_Q, aux0=hc, aux1=zb, res=cx["gru.q" + nn_])
+                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=Xs, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
+                            res=cx["gru.zr" + nn_], state_f32=sf)
+                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=Xs, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
+                            y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
                     hc, hn = hn, hc
+                    sc, sn = sn, sc
                 rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)
                 rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh_, View(co), res=View(co), scratch=fp)
                 if taps is not None and it in (0, iters - 1):

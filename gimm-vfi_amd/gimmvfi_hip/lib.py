@@ -49,6 +49,7 @@ class ConvParams(C.Structure):
         ("tile_hint", C.c_int),
         ("w_layout", C.c_int),
         ("algo", C.c_int),
+        ("state_f32", C.c_int),
     ]
 
 

@@ -56,7 +56,9 @@ def V(t, coff=0, c=None):
 class ConvLayer:
     """Packed weights [Cout][KH][KW][cin_pad] (+ float bias / PReLU slope) of one convolution."""
 
-    def __init__(self, rt, w, b, stride=1, pad=None, pad_mode=L.PAD_ZEROS, slope=None, cin_pad=None):
+    def __init__(self, rt, w, b, stride=1, pad=None, pad_mode=L.PAD_ZEROS, slope=None, cin_pad=None, wdir=False):
+        """wdir: also pack the MFMA-fragment-ordered image (w_layout = 2) of the weights-direct variant of the LDS-DMA
+        kernel -- for the layers of the flow estimators' recurrences (small M, launch time = one workgroup's K chain)."""
         cout, cin, kh, kw = w.shape
         cp = roundup(cin, rt.VE) if cin_pad is None else cin_pad
         pk = torch.zeros(cout, kh, kw, cp, dtype=torch.float32, device=w.device)
@@ -75,6 +77,16 @@ class ConvLayer:
             src_slot = torch.arange(8, device=pk.device)[None, :] ^ sw[:, None]    # dest slot s holds source slot s^sw
             wk = torch.gather(wk, 2, src_slot[:, None, :, None].expand(cout, k // bke, 8, rt.VE))
             self.w_glds = wk.permute(1, 0, 2, 3).contiguous().to(rt.tdtype).to(rt.device)   # [chunk][n][slot][ve]
+        self.w_frag = None
+        if (wdir and rt.precision == "bf16" and cp % 64 == 0 and pad_mode == L.PAD_ZEROS and kh * kw <= 32
+                and os.environ.get("GVFI_WDIR", "1") != "0"):
+            k = kh * kw * cp
+            nb = (cout + 31) // 32
+            wp = torch.zeros(nb * 32, kh * kw, cp, dtype=torch.float32, device=pk.device)
+            wp[:cout] = pk.reshape(cout, kh * kw, cp)
+            # K chunks in the kernel's walk order (channel chunk outer, tap inner), then [chunk][col block][k-step][half][col][8]
+            wk = wp.reshape(nb, 32, kh * kw, cp // 64, 4, 2, 8).permute(3, 2, 0, 4, 5, 1, 6)
+            self.w_frag = wk.contiguous().reshape(k // 64, nb, 4, 64, 8).to(rt.tdtype).to(rt.device)
         self.b = None if b is None else b.detach().float().contiguous().to(rt.device)
         self.slope = None if slope is None else slope.detach().float().contiguous().to(rt.device)
         self.cout, self.cin, self.cin_pad, self.kh, self.kw = cout, cin, cp, kh, kw
@@ -87,13 +99,13 @@ class PatchConvLayer:
     """A KHxKW stride-1 zero-padded convolution over a few channels, run as im2col (gvfi_im2col) + 1x1 convolution:
     K = KH*KW*cin real products, padded once to a whole K chunk instead of padding every tap's channels."""
 
-    def __init__(self, rt, w, b, slope=None):
+    def __init__(self, rt, w, b, slope=None, wdir=False):
         cout, cin, kh, kw = w.shape
         self.kh, self.kw, self.cin, self.cout = kh, kw, cin, cout
         self.kpad = roundup(kh * kw * cin, 8 * rt.VE)
         w2 = torch.zeros(cout, self.kpad, 1, 1, dtype=torch.float32, device=w.device)
         w2[:, :kh * kw * cin, 0, 0] = w.detach().float().permute(0, 2, 3, 1).reshape(cout, -1)   # K order (kh, kw, c)
-        self.inner = ConvLayer(rt, w2, b, slope=slope)
+        self.inner = ConvLayer(rt, w2, b, slope=slope, wdir=wdir)
         self.inner.cin = kh * kw * cin      # real products per output (FLOP accounting)
 
 
@@ -247,8 +259,9 @@ class Runtime:
     # ------------------------------------------------------------------ convolution
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False):
-        """stats: optional zero-initialised f32 [N, cout, 2]; when the library can fuse the InstanceNorm statistics
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False):
+        """state_f32 (GRU epilogues, bf16 mode): the recurrent state tensors are float (gvfi_conv_params.state_f32).
+        stats: optional zero-initialised f32 [N, cout, 2]; when the library can fuse the InstanceNorm statistics
         into this convolution (gvfi_conv2d_stats_ok) they are accumulated there and True is returned in
         ``self.last_stats_fused``, else the caller computes them with instnorm_stats."""
         x0 = V(x0)
@@ -277,6 +290,10 @@ class Runtime:
                       and (want == 5 or n * h * w_ >= 65536))
             if want == 5:
                 p.w, p.w_layout = layer.w.data_ptr(), 0
+            elif want in (0, 6) and layer.w_frag is not None and p.c0 % 64 == 0 and p.c1 % 64 == 0 and groups == 1:
+                p.w, p.w_layout = layer.w_frag.data_ptr(), 2      # weights-direct variant of the LDS-DMA kernel
+                algo = 2 | (algo & ~15)
+                want = 2
             elif want in (0, 2, 4) and aligned and not (algo & 128):
                 p.w, p.w_layout = layer.w_glds.data_ptr(), 1
                 algo = (4 if want == 4 else 2) | (algo & ~15)
@@ -328,6 +345,7 @@ class Runtime:
             algo |= 16
         p.tile_hint = tile
         p.algo = algo
+        p.state_f32 = 1 if (state_f32 and self.dtype == L.BF16) else 0
         p.stats = None
         if layer is not None and want == 0 and p.w_layout == 1 and stats is None and self.use_p3x3 \
                 and self.lib.conv2d_p3x3_eligible(C.byref(p)) == 1:
@@ -363,7 +381,8 @@ class Runtime:
             self._chk(self.lib.conv2d_plan(C.byref(p), plan), "conv2d_plan")   # the library says which kernel it ran
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
-            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel"}[plan[0]]
+            kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel",
+                     6: "conv_igemm_glds_kernel[wdir]"}[plan[0]]
             tag = f"{kname}<{'float' if self.dtype == L.F32 else 'bf16'},{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"

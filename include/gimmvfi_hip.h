@@ -80,7 +80,12 @@ typedef struct {
                                          * [K/64][Cout][64] with the 16-byte groups of a row XOR-swizzled by *
                                          * (cout>>1)&7 -- the exact LDS image, so the weight tile DMA is one  *
                                          * contiguous copy (K chunk = 128 bytes).  Chunk index =               *
-                                         * channel_chunk * KH*KW + tap (the kernel walks the taps innermost)   */
+                                         * channel_chunk * KH*KW + tap (the kernel walks the taps innermost);  *
+                                         * 2 (LDS-DMA kernel, bf16, "weights direct"): MFMA-fragment order      *
+                                         * [K/64][ceil(Cout/32)][4 k-steps][64 lanes][8]: lane l of a fragment  *
+                                         * holds W[32*nb + (l&31)][64*chunk + 16*kk + 8*(l>>5) .. +8] (zeros    *
+                                         * beyond Cout) -- one coalesced 1 KiB load per MFMA operand, no LDS;   *
+                                         * same chunk order as layout 1                                          */
     int algo;                           /* bits 0..3: 0 = auto, 1 = generic register-staged kernel,    *
                                          * 2 = LDS-DMA kernel (needs c0,c1 % 64 bf16 / 32 f32),   *
                                          * 3 = patch kernel (few channels, see gvfi_conv2d_patch); *
@@ -93,6 +98,12 @@ typedef struct {
                                          * bit 5 / 7: A/B switches (8-wave tile: DMA issue spread *
                                          * over the MFMA groups; 64-byte K chunks), bits 8..:      *
                                          * profiling switches (skip phases, s_memtime stamps)     */
+    int state_f32;                      /* GRU epilogues, bf16 mode: the recurrent state is FLOAT -- the hidden state is *
+                                         * an accumulator over 20-32 iterations; rounding it to bf16 every iteration is   *
+                                         * the one place where bf16 error accumulates instead of only rounding MFMA       *
+                                         * operands.  GRU_ZR: aux0 (h) and y (z) are float, y2 (r*h, an operand) stays    *
+                                         * bf16.  GRU_Q: aux0 (h), aux1 (z) float; y = new h in bf16 (operand copy for the *
+                                         * next convolutions), y2 = new h in float (the state).                           */
 } gvfi_conv_params;
 
 int gvfi_conv2d(const gvfi_conv_params* p, void* stream);

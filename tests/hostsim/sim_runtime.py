@@ -69,10 +69,10 @@ class SimRuntime(Runtime):
 
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False):
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False):
         if self.emulate_conv:
             return super().conv(layer, x0, out, x1, act1, res, act2, out_scale, slope1, slope2, epi, y2, aux0, aux1,
-                                groups, w_group_stride, w_raw, cout, tile, algo, stats, pad16)
+                                groups, w_group_stride, w_raw, cout, tile, algo, stats, pad16, state_f32)
         self.last_stats_fused = False     # the torch statement leaves the statistics to gvfi_instnorm_stats
         return self._torch_conv(layer, V(x0), V(out), None if x1 is None else V(x1), act1, res, act2, out_scale,
                                 slope1, slope2, epi, y2, aux0, aux1, groups, w_raw, cout)
@@ -139,5 +139,9 @@ class SimRuntime(Runtime):
             q = torch.tanh(v)
             h = self._sl(V(aux0), cout)
             z = self._sl(V(aux1), cout)
-            out.t[..., out.coff:out.coff + cout] = ((1 - z) * h + z * q).to(out.t.dtype)
+            hn = (1 - z) * h + z * q
+            out.t[..., out.coff:out.coff + cout] = hn.to(out.t.dtype)
+            if y2 is not None:      # float state beside its operand copy (state_f32; the tensors' dtypes say the rest)
+                y2 = V(y2)
+                y2.t[..., y2.coff:y2.coff + cout] = hn.to(y2.t.dtype)
         return out

@@ -43,7 +43,9 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     x, w = _rounded(rt, x), _rounded(rt, w)
     dev = _dev(rt)
     lay = ConvLayer(rt, w, b, stride=stride, pad=None if pad is None else (pad, pad),
-                    pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope)
+                    pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope, wdir=(algo & 15) == 6)
+    if (algo & 15) == 6:
+        assert lay.w_frag is not None, "weights-direct image not packed"
     if split is None:
         xa = _to_act(rt, x).to(dev)
         x0, x1 = View(xa, 0, Cin), None
@@ -139,43 +141,59 @@ def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, 
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
-def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5, ctx_split=False):
-    """SepConvGRU half step with the fused epilogues (raft/update.py:58-66)."""
+def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5, ctx_split=False, state_f32=False, wdir=False):
+    """SepConvGRU half step with the fused epilogues (raft/update.py:58-66).  state_f32: float recurrent state (h, z)
+    beside the bf16 operand copy (gvfi_conv_params.state_f32); wdir: weights-direct variant of the LDS-DMA kernel."""
     g = torch.Generator().manual_seed(seed)
     h = _rounded(rt, torch.tanh(torch.randn(N, C, H, W, generator=g)))
     x = _rounded(rt, torch.randn(N, 2 * C, H, W, generator=g))
     wz, wr, wq = (_rounded(rt, torch.randn(C, 3 * C, kh, kw, generator=g) / (3 * C * kh * kw) ** 0.5) for _ in range(3))
     bz, br, bq = (torch.randn(C, generator=g) for _ in range(3))
     dev = _dev(rt)
-    lzr = ConvLayer(rt, torch.cat([wz, wr], 0), torch.cat([bz, br], 0))
-    lq = ConvLayer(rt, wq, bq)
-    ha, xa = _to_act(rt, h).to(dev), _to_act(rt, x).to(dev)
-    zb, rh, hn = rt.act(N, H, W, C), rt.act(N, H, W, C), rt.act(N, H, W, C)
+    lzr = ConvLayer(rt, torch.cat([wz, wr], 0), torch.cat([bz, br], 0), wdir=wdir)
+    lq = ConvLayer(rt, wq, bq, wdir=wdir)
+    sf = state_f32 and rt.precision == "bf16"
+    if sf:
+        h = torch.tanh(torch.randn(N, C, H, W, generator=g))        # the float state is NOT rounded to bf16
+    ha, xa = _to_act(rt, h).to(dev), _to_act(rt, x).to(dev)         # operand copy of h (bf16-rounded)
+    h32 = h.permute(0, 2, 3, 1).contiguous().to(dev) if sf else None
+    hn32 = rt.f32(N, H, W, C) if sf else None
+    zb = rt.f32(N, H, W, C) if sf else rt.act(N, H, W, C)
+    rh, hn = rt.act(N, H, W, C), rt.act(N, H, W, C)
+    st = dict(state_f32=True) if sf else {}
     if not ctx_split:
-        rt.conv(lzr, ha, zb, x1=xa, epi=L.EPI_GRU_ZR, y2=rh, aux0=ha)
-        rt.conv(lq, rh, hn, x1=xa, epi=L.EPI_GRU_Q, aux0=ha, aux1=zb)
+        rt.conv(lzr, ha, zb, x1=xa, epi=L.EPI_GRU_ZR, y2=rh, aux0=h32 if sf else ha, **st)
+        rt.conv(lq, rh, hn, x1=xa, epi=L.EPI_GRU_Q, aux0=h32 if sf else ha, aux1=zb, y2=hn32, **st)
     else:
         # the first C channels of x play RAFT's constant context: their share of both convolutions is a separate
         # (bias-carrying) convolution evaluated once, handed to the gate epilogues as a pre-activation term
         keep = list(range(0, C)) + list(range(2 * C, 3 * C))
         wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
-        lzr_m, lq_m = ConvLayer(rt, wzr[:, keep], None), ConvLayer(rt, wq[:, keep], None)
+        lzr_m, lq_m = ConvLayer(rt, wzr[:, keep], None, wdir=wdir), ConvLayer(rt, wq[:, keep], None, wdir=wdir)
         lzr_c, lq_c = ConvLayer(rt, wzr[:, C:2 * C], bzr), ConvLayer(rt, wq[:, C:2 * C], bq)
         czr, cq = rt.f32(N, H, W, 2 * C), rt.f32(N, H, W, C)
         rt.conv(lzr_c, View(xa, 0, C), czr)
         rt.conv(lq_c, View(xa, 0, C), cq)
         xm = View(xa, C, C)
-        rt.conv(lzr_m, ha, zb, x1=xm, epi=L.EPI_GRU_ZR, y2=rh, aux0=ha, res=czr)
-        rt.conv(lq_m, rh, hn, x1=xm, epi=L.EPI_GRU_Q, aux0=ha, aux1=zb, res=cq)
+        rt.conv(lzr_m, ha, zb, x1=xm, epi=L.EPI_GRU_ZR, y2=rh, aux0=h32 if sf else ha, res=czr, **st)
+        rt.conv(lq_m, rh, hn, x1=xm, epi=L.EPI_GRU_Q, aux0=h32 if sf else ha, aux1=zb, y2=hn32, res=cq, **st)
     pad = (kh // 2, kw // 2)
-    hx = torch.cat([h, x], 1)
+    hop = _rounded(rt, h)                                       # what the convolutions read
+    hx = torch.cat([hop, x], 1)
     z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=pad))
     r = torch.sigmoid(F.conv2d(hx, wr, br, padding=pad))
     rhr = _rounded(rt, r * h)
     q = torch.tanh(F.conv2d(torch.cat([rhr, x], 1), wq, bq, padding=pad))
-    ref = (1 - _rounded(rt, z)) * h + _rounded(rt, z) * q
+    zz = z if sf else _rounded(rt, z)
+    ref = (1 - zz) * h + zz * q
     err = float((hn.float().cpu().permute(0, 3, 1, 2) - ref).abs().max())
     assert err <= tol(rt, 2.0), err
+    if sf:     # the float state itself: no bf16 rounding of h, z or the result (hardware exp / rcp approximations only)
+        e32 = float((hn32.cpu().permute(0, 3, 1, 2) - ref).abs().max())
+        assert e32 <= 2e-4, e32
+        assert torch.equal(hn.float().cpu(), hn32.cpu().to(torch.bfloat16).float())     # operand copy = rounded state
+        ez = float((zb.cpu().permute(0, 3, 1, 2) - z).abs().max())
+        assert ez <= 1e-4, ez
     return err
 
 

@@ -130,6 +130,13 @@ def test_gru_epilogues(rt):
     kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=5, kw=1, seed=3, ctx_split=True)   # hoisted context term (LDS-DMA kernel)
     kc.gru_case(rt, kh=1, kw=5, seed=4, ctx_split=True)                          # same on the generic kernel
     kc.gru_case(rt, N=2, H=32, W=56, C=128, kh=1, kw=5, seed=2)
+    if rt.precision == "bf16":
+        # float recurrent state (h, z) beside the bf16 operand copy -- slim store loops of the LDS-DMA kernel, its
+        # weights-direct variant (both column tiles come up: 2C = 256 / C = 128 outputs), and the generic kernel
+        kc.gru_case(rt, N=2, H=32, W=56, C=128, kh=1, kw=5, seed=5, state_f32=True, ctx_split=True)
+        kc.gru_case(rt, N=2, H=32, W=56, C=128, kh=5, kw=1, seed=6, state_f32=True, ctx_split=True, wdir=True)
+        kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=1, kw=5, seed=7, state_f32=True, wdir=True)
+        kc.gru_case(rt, kh=1, kw=5, seed=8, state_f32=True)
 
 
 def test_corr_volume_grouped_gemm(rt):

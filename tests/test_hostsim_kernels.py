@@ -48,6 +48,19 @@ CONV_SHAPES = [
     (1, 9, 12, 128, 130, 3, 3, dict(tile=128 | (128 << 10) | (3 << 20), act1=L.ACT_LRELU)),
     (1, 9, 12, 64, 40, 3, 3, dict(tile=64 | (4 << 20), act1=L.ACT_LRELU)),
     (1, 9, 11, 128, 24, 3, 3, dict(tile=32 | (128 << 10) | (3 << 20), out_f32=True)),
+    # weights-direct variant (w_layout 2: fragment-ordered weights loaded straight into MFMA operand registers, ring of 4):
+    # K loops longer / shorter than the ring (steady state, every tail case, phantom chunks), two sources, ragged Cout
+    # (column blocks beyond the image), ragged rows, both column tiles, residual + second activation, float output
+    (1, 8, 10, 128, 130, 1, 5, dict(algo=6, split=64, act1=L.ACT_RELU, bf16_only=True)),                 # KT = 10
+    (1, 9, 12, 64, 130, 3, 3, dict(algo=6, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU, bf16_only=True)),   # KT = 9
+    (1, 6, 20, 64, 128, 1, 1, dict(algo=6, bf16_only=True)),                                           # KT = 1
+    (1, 6, 20, 128, 96, 1, 1, dict(algo=6, act1=L.ACT_GELU, bf16_only=True)),                          # KT = 2
+    (1, 5, 9, 192, 40, 1, 1, dict(algo=6, split=64, out_f32=True, bf16_only=True)),                    # KT = 3
+    (1, 7, 9, 64, 256, 2, 2, dict(algo=6, tile=256, act1=L.ACT_LRELU, pad=1, bf16_only=True)),         # KT = 4, 256 columns
+    (1, 7, 9, 64, 200, 1, 5, dict(algo=6, tile=256, act1=L.ACT_RELU, bf16_only=True)),                 # KT = 5, ragged 256 tile
+    (1, 7, 9, 128, 64, 3, 1, dict(algo=6, bf16_only=True)),                                            # KT = 6
+    (1, 7, 9, 64, 32, 7, 1, dict(algo=6, bf16_only=True)),                                             # KT = 7
+    (1, 7, 9, 64, 160, 3, 3, dict(algo=6, tile=256, with_res=True, bf16_only=True)),                   # KT = 9
     (1, 9, 12, 96, 40, 3, 3, dict(act1=L.ACT_LRELU)),
     (1, 18, 20, 32, 32, 3, 3, dict(tile=32 | (256 << 10), act1=L.ACT_LRELU, with_res=True)),
     (1, 18, 20, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),
@@ -120,6 +133,12 @@ def test_gru_epilogues(rt):
         kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=1, kw=5, seed=2)   # 64-multiples -> LDS-DMA kernel and its GRU store loops
     kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=5, kw=1, seed=3, ctx_split=True)   # hoisted context term (LDS-DMA kernel)
     kc.gru_case(rt, kh=1, kw=5, seed=4, ctx_split=True)                          # same on the generic kernel
+    if rt.precision == "bf16":
+        # float recurrent state (h, z) beside the bf16 operand copy: LDS-DMA kernel, its weights-direct variant, generic kernel
+        kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=1, kw=5, seed=5, state_f32=True, ctx_split=True)
+        kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=5, kw=1, seed=6, state_f32=True, ctx_split=True, wdir=True)
+        kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=1, kw=5, seed=7, state_f32=True, wdir=True)
+        kc.gru_case(rt, kh=1, kw=5, seed=8, state_f32=True)
 
 
 def test_corr_volume_grouped_gemm(rt):

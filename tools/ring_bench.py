@@ -31,11 +31,12 @@ SHAPES = [
 
 
 def variants(cout):
+    """(bm, bn, ring depth); depth 0 = the weights-direct variant (w_layout 2, register ring of 4)"""
     if cout > 64:
-        return [(64, 128, 2), (64, 128, 3), (64, 128, 4), (128, 128, 2), (128, 128, 3)]
+        return [(64, 128, 2), (64, 128, 3), (128, 128, 2), (64, 128, 0), (64, 256, 0)]
     if cout > 32:
-        return [(128, 64, 2), (128, 64, 3), (128, 64, 4)]
-    return [(128, 32, 2), (128, 32, 3), (128, 32, 4)]
+        return [(128, 64, 2), (128, 64, 3), (64, 128, 0)]
+    return [(128, 32, 2), (128, 32, 3), (64, 128, 0)]
 
 
 def main():
@@ -43,7 +44,7 @@ def main():
     rt = Runtime(L.get(), "bf16", "cuda:0")
     for name, N, H, W, Cin, Cout, KH, KW, split in SHAPES:
         w = torch.randn(Cout, Cin, KH, KW) / (Cin * KH * KW) ** 0.5
-        lay = ConvLayer(rt, w, torch.randn(Cout))
+        lay = ConvLayer(rt, w, torch.randn(Cout), wdir=True)
         x = torch.randn(N, H, W, Cin, device="cuda").to(rt.tdtype)
         if split is None:
             x0, x1 = View(x, 0, Cin), None
@@ -56,9 +57,10 @@ def main():
         cells = []
         for bm, bn, ns in variants(Cout):
             tile = bn | (bm << 10) | (ns << 20)
+            algo = 2 if ns else 6
             try:
                 for _ in range(3):
-                    rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=2, tile=tile)
+                    rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
             except RuntimeError as e:
                 cells.append(f"{bm}x{bn}/s{ns} n/a")
                 continue
@@ -68,7 +70,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=2, tile=tile)
+                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo, tile=tile)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / reps * 1e3
@@ -76,10 +78,10 @@ def main():
             if ref is None:
                 ref = o
             d = float((o - ref).abs().max())
-            cells.append(f"{bm}x{bn}/s{ns} {us:6.1f} us {flops / us / 1e6:6.0f} TF/s" + ("" if d == 0 else f" d={d:.1e}"))
+            cells.append(f"{bm}x{bn}/{'s%d' % ns if ns else 'wdir'} {us:6.1f} us {flops / us / 1e6:6.0f} TF/s" + ("" if d == 0 else f" d={d:.1e}"))
             if stamps_mode:
                 st = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
-                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=2 + 256 * 128, tile=tile, aux1=st)
+                rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo + 256 * 128, tile=tile, aux1=st)
                 torch.cuda.synchronize()
                 s = st.cpu().view(-1, 8)
                 s = s[s[:, 0] != 0].double()
