@@ -81,6 +81,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];   // ring of K chunks
 
     const gvfi_conv_params& p = a.p;
+#ifndef GVFI_HOSTSIM
+    // Every kernel argument the prologue and the K loop read, fetched in ONE batch of scalar loads.  Left alone hipcc
+    // loads each field right before its first use: ~10 dependent s_load -> s_waitcnt round trips (the scalar cache is
+    // cold at kernel start) spread over the prologue -- 3 us per workgroup in s_memtime stamps, more than the K loop of
+    // the small recurrence layers (tools/ring_bench.py --stamps).  The empty asm statements only make the values live here.
+    asm volatile("" ::"s"(p.x0), "s"(p.x1), "s"(p.w), "s"(p.w_group_stride), "s"(p.ld0), "s"(p.ld1), "s"(p.c0), "s"(p.N), "s"(p.H),
+                 "s"(p.W), "s"(p.Cout), "s"(p.KH), "s"(p.KW), "s"(p.stride), "s"(p.pad_h), "s"(p.pad_w), "s"(p.Ho), "s"(p.Wo),
+                 "s"(p.groups), "s"(p.w_layout));
+    asm volatile("" ::"s"(a.chunks0), "s"(a.chunks_tap), "s"(a.KT), "s"(a.Mg), "s"(a.MT), "s"(a.NT), "s"(a.per_xcd), "s"(a.dbg),
+                 "s"(a.Ktot), "s"(a.howo_mul), "s"(a.howo_sh), "s"(a.wo_mul), "s"(a.wo_sh), "s"(p.bias), "s"(p.act1), "s"(p.act2),
+                 "s"(p.slope1), "s"(p.slope2), "s"(p.epi_mode));
+#endif
     // ---- XCD-aware tile order (blockIdx.x round-robins over the 8 XCDs)
     const int bid = blockIdx.x;
     const int v = (bid & 7) * a.per_xcd + (bid >> 3);

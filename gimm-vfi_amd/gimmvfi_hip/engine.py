@@ -55,8 +55,11 @@ class Engine:
         self.g9 = sd["g_filter"].float().reshape(9).contiguous().to(rt.device)
         # number of parallel launch sequences the flow estimator's recurrence is split into (sub-batches of images)
         self.raft_lanes = int(os.environ.get("GVFI_RAFT_LANES", "2"))
-        # float GRU state in bf16 mode (gvfi_conv_params.state_f32); GVFI_GRU_STATE_F32=0 is the A/B switch
-        self.gru_state_f32 = os.environ.get("GVFI_GRU_STATE_F32", "1") != "0"
+        # float GRU state in bf16 mode (gvfi_conv_params.state_f32), OFF by default.  Built to test whether the bf16 rounding
+        # of the recurrent state is what costs GIMM-VFI-F its reference fidelity at 2K / 4K: it is not (demo-2K 32.47 dB
+        # with the float state against 32.26 dB without, profiles/r3_f_policy.md -- the loss is the rounding of the update
+        # block's MFMA operands, amplified by the un-trained recurrence) and it costs 1.3 % (326.2 vs 330.7 frames/s)
+        self.gru_state_f32 = os.environ.get("GVFI_GRU_STATE_F32", "0") == "1"
         self.layers = {}
         self._build(sd)
 

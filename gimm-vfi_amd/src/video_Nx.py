@@ -4,11 +4,12 @@
 
 writes OUT/output.mp4 (side-by-side [original | interpolated], fps 2N) and OUT/flow.mp4 (colour-coded
 flow_t).  Differences: runs on the MI355X HIP kernels (no CuPy / CUDA), and under
-``python -m torch.distributed.run --nproc-per-node G`` the frame pairs are sharded over G GPUs with one
-RCCL gather of the device-resident uint8 result frames to rank 0 (flow pictures are written by the rank that computed
-them); every rank runs `--batch` consecutive pairs per forward and encodes each frame once (model.forward_sequence);
-frame decode / upload and result download / colour-coding run in a host pipeline beside the GPU
-(gimmvfi_hip/io_pipeline.py).  Without OpenCV the frames are written as PNGs
+``python -m torch.distributed.run --nproc-per-node G`` the frame pairs are sharded over G GPUs in ROUNDS of G x `--batch`
+consecutive pairs (gimmvfi_hip/shard.py:round_schedule); after every round the device-resident uint8 result frames and
+flow pictures are gathered to rank 0 over RCCL (the path's only collective) and written to the videos in order while the
+next round computes -- memory on every rank is O(one round).  Every rank runs `--batch` consecutive pairs per forward and
+encodes each frame once (model.forward_sequence); frame decode / upload, result download, composition and video writing
+run in a host pipeline beside the GPU (gimmvfi_hip/io_pipeline.py).  Without OpenCV the frames are written as PNGs
 (OUT/output_frames, OUT/flow_frames) and encoded with ffmpeg when it is on PATH.
 ``--random-init`` (addition) runs with seeded random weights when no checkpoint is available."""
 import argparse
@@ -29,7 +30,7 @@ from utils.setup import single_setup  # noqa: E402
 from utils.utils import InputPadder, set_seed  # noqa: E402
 
 from gimmvfi_hip import shard  # noqa: E402  (models/__init__ put the package root on sys.path)
-from gimmvfi_hip.io_pipeline import FramePrefetcher, ResultDrain  # noqa: E402
+from gimmvfi_hip.io_pipeline import FramePrefetcher, ResultDrain, VideoSink  # noqa: E402
 
 try:
     import cv2
@@ -136,121 +137,141 @@ def main(argv=None):
     img_list = sorted(os.listdir(args.source_path))
     num_pairs = len(img_list) - 1
     N = args.N
-    p0, p1 = shard.pair_range(num_pairs, rank, world)
     ds_factor = args.ds_factor
-    # host pipeline: frames of this rank's pair range are decoded once, ahead of the GPU, into pinned memory and
-    # uploaded on a side stream; results come back asynchronously and are colour-coded in a consumer thread
+    # host pipeline: frames are decoded once, ahead of the GPU, into pinned memory and uploaded on a side stream; results
+    # come back asynchronously, are composed / colour-coded in worker threads and written WHILE the GPU runs (VideoSink)
     first = load_image(os.path.join(args.source_path, img_list[0]))
     padder = InputPadder(first.shape, 32)
     H0, W0 = first.shape[-2:]
     paths = [os.path.join(args.source_path, f) for f in img_list]
-    # pairs per forward: consecutive pairs of this rank's contiguous range run as ONE batch whose per-frame encoder work
-    # is shared (model.forward_sequence); the default keeps ~1 Mpixel of frames per forward
+    # pairs per forward: consecutive pairs run as ONE batch whose per-frame encoder work is shared
+    # (model.forward_sequence); the default keeps ~1 Mpixel of frames per forward
     bsz = args.batch if args.batch > 0 else max(1, min(8, (1 << 20) // max(1, H0 * W0)))
+    # streaming schedule (gimmvfi_hip/shard.py): round k = the next world x bsz pairs of the video, rank r its r-th block;
+    # the results of a round are gathered to rank 0 (the path's only collective) and written in order -- memory on
+    # every rank is O(one round), whatever the length of the video
+    rounds = shard.round_schedule(num_pairs, bsz, world)
+    my_blocks = [rnd[rank] for rnd in rounds]
     frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image, lookahead=bsz + 3)
     drain = ResultDrain(device)
     rt = model.engine(device).rt
-    flow_dir = os.path.join(args.output_path, "flow_parts")     # per-rank flow pictures, assembled by rank 0
-    os.makedirs(flow_dir, exist_ok=True)
-
+    gatherer = shard.RoundGather(rank, world) if world > 1 else None
     wheel = torch.from_numpy(make_colorwheel()).float().to(device)
+    # size of a flow picture: flow_t lives at the working resolution and is cropped by the FULL-resolution pad amounts
+    # (padder.unpad on the down-scaled field -- the reference's behaviour, video_Nx.py:199-207)
+    pw_, ph_ = padder._pad[0] + padder._pad[1], padder._pad[2] + padder._pad[3]
+    hf, wf = (H0, W0) if ds_factor == 1.0 else (int((H0 + ph_) * ds_factor) - ph_, int((W0 + pw_) * ds_factor) - pw_)
 
-    def post(j0, single):
-        def fn(pred_u8, pics_u8):
+    t_start = time.perf_counter()
+    sinks = None
+    if rank == 0 and num_pairs > 0:
+        sinks = (VideoSink(os.path.join(args.output_path, "output.mp4"), N * 2, num_pairs * N, (H0, 2 * W0)),
+                 VideoSink(os.path.join(args.output_path, "flow.mp4"), N * 2, num_pairs * (N - 1), (H0, W0)))
+
+    prof = {"decode_wait": 0.0, "enqueue": 0.0, "submit": 0.0, "post": 0.0} if os.environ.get("GVFI_CLI_TIMING") else None
+
+    def post(blocks):
+        """blocks: [(first pair, pairs)] of the tensors handed to the drain, in order (one per contributing rank)."""
+        def fn(*hosts):
             tq = time.perf_counter()
-            # pred_u8: [b, N-1, H, W, 3] uint8 RGB ; pics_u8: [b*(N-1), h, w, 3] uint8 BGR flow pictures, colour-coded on the
-            # GPU (gvfi_flow_to_image: the numpy coding of seven 2K pictures per pair cost the host 3x the model's time).
-            # They are made by the rank that computed the flows (they never enter the collective): kept in memory on a
-            # single-GPU run, written to OUT/flow_parts (raw .npy, assembled by rank 0) otherwise
-            pics = []
-            for fimg in pics_u8.numpy():
-                if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
-                    fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
-                pics.append(fimg)
+            # hosts: per block (pred_u8 [b, N-1, H, W, 3] RGB, pics_u8 [b*(N-1), h, w, 3] BGR flow pictures, colour-coded on
+            # the GPU by gvfi_flow_to_image).  Output frame order of the reference (video_Nx.py:225-246): [orig0|orig0],
+            # then per pair its N-1 [orig_j | interp] frames and [orig_j+1 | orig_j+1]; the very last frame is dropped
+            out_sink, flow_sink = sinks
+            for k, (j0, b) in enumerate(blocks):
+                pred, pics = hosts[2 * k].numpy(), hosts[2 * k + 1].numpy()
+                origs = [to_bgr_u8(load_image(paths[j])[0]) for j in range(j0, j0 + b + 1)]
+                for jj in range(b):
+                    j = j0 + jj
+                    if j == 0:
+                        out_sink.put(0, np.concatenate([origs[0], origs[0]], 1))
+                    for i in range(N - 1):
+                        out_sink.put(1 + j * N + i, np.concatenate([origs[jj], pred[jj, i][:, :, ::-1]], 1))   # hconcat([orig, interp])
+                        fimg = pics[jj * (N - 1) + i]
+                        if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
+                            fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
+                        flow_sink.put(j * (N - 1) + i, fimg)
+                    if j + 1 < num_pairs:
+                        out_sink.put(1 + j * N + (N - 1), np.concatenate([origs[jj + 1], origs[jj + 1]], 1))
             if prof is not None:
                 prof["post"] += time.perf_counter() - tq
-            if single:
-                return pred_u8.numpy(), pics
-            np.save(os.path.join(flow_dir, f"{j0:07d}.npy"), np.stack(pics, 0))
             return None
         return fn
 
-    prof = {"decode_wait": 0.0, "enqueue": 0.0, "submit": 0.0, "post": 0.0} if os.environ.get("GVFI_CLI_TIMING") else None
     coord_cache = {}
-    local_dev = []     # device-resident uint8 result frames of this rank (gathered once at the end when world > 1)
+    copied = [None, None]      # D2H-complete events of the gather staging buffers (two parities)
     t_warm, pairs_warm = None, 0
-    for j0 in tqdm(range(p0, p1, bsz)):
-        if j0 == p0 + bsz:           # the first batch pays model packing + graph capture: steady state starts here
+    for k, (j0, b) in enumerate(tqdm(my_blocks)):
+        if k == 1:           # the first round pays model packing + graph capture: steady state starts here
             torch.cuda.synchronize(device)
-            t_warm, pairs_warm = time.perf_counter(), j0 - p0
-        b = min(bsz, p1 - j0)
+            t_warm, pairs_warm = time.perf_counter(), sum(c for _, c in rounds[0])
+        pred_u8 = torch.zeros((0, N - 1, H0, W0, 3), dtype=torch.uint8, device=device)
+        pics_u8 = torch.zeros((0, hf, wf, 3), dtype=torch.uint8, device=device)
+        if b > 0:
+            tp = time.perf_counter()
+            frames = torch.cat([frames_in.get(j) for j in range(j0, j0 + b + 1)], 0)      # (b+1, 3, Hp, Wp), each decoded once
+            if prof is not None:
+                prof["decode_wait"] += time.perf_counter() - tp
+                tp = time.perf_counter()
+            s_shape = frames.shape[-2:]
+            with torch.no_grad():
+                key = (b, tuple(s_shape))
+                if key not in coord_cache:     # the coordinate grids only depend on the batch and frame size
+                    coord_cache[key] = (
+                        [(model.sample_coord_input(b, s_shape, [1 / N * i], device=device, upsample_ratio=ds_factor), None)
+                         for i in range(1, N)],
+                        [i * 1 / N * torch.ones(b, device=device, dtype=torch.float) for i in range(1, N)])
+                coord_inputs, timesteps = coord_cache[key]
+                out = model.forward_sequence(frames, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
+                preds = torch.stack([padder.unpad(out["imgt_pred"][i]) for i in range(N - 1)], 1)       # [b, N-1, 3, H, W]
+                pred_u8 = rt.frames_to_u8(preds.reshape(-1, *preds.shape[2:]).contiguous()).reshape(b, N - 1, H0, W0, 3)
+                flows = []
+                for i in range(N - 1):
+                    u = padder.unpad(out["flowt"][i])
+                    flows.append(u.reshape(b, 2, *u.shape[-2:]))
+                flows = torch.stack(flows, 1).contiguous()                                              # [b, N-1, 2, h, w]
+                pics_u8 = rt.flow_to_image(flows.reshape(-1, 2, *flows.shape[-2:]), wheel, bgr=True)     # reference :199-207
+            if prof is not None:
+                prof["enqueue"] += time.perf_counter() - tp
         tp = time.perf_counter()
-        frames = torch.cat([frames_in.get(j) for j in range(j0, j0 + b + 1)], 0)      # (b+1, 3, Hp, Wp), each decoded once
-        if prof is not None:
-            prof["decode_wait"] += time.perf_counter() - tp
-            tp = time.perf_counter()
-        s_shape = frames.shape[-2:]
-        with torch.no_grad():
-            key = (b, tuple(s_shape))
-            if key not in coord_cache:     # the coordinate grids only depend on the batch and frame size
-                coord_cache[key] = (
-                    [(model.sample_coord_input(b, s_shape, [1 / N * i], device=device, upsample_ratio=ds_factor), None)
-                     for i in range(1, N)],
-                    [i * 1 / N * torch.ones(b, device=device, dtype=torch.float) for i in range(1, N)])
-            coord_inputs, timesteps = coord_cache[key]
-            out = model.forward_sequence(frames, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
-            preds = torch.stack([padder.unpad(out["imgt_pred"][i]) for i in range(N - 1)], 1)       # [b, N-1, 3, H, W]
-            pred_u8 = rt.frames_to_u8(preds.reshape(-1, *preds.shape[2:]).contiguous()).reshape(b, N - 1, H0, W0, 3)
-            flows = []
-            for i in range(N - 1):
-                u = padder.unpad(out["flowt"][i])
-                flows.append(u.reshape(b, 2, *u.shape[-2:]))
-            flows = torch.stack(flows, 1).contiguous()                                              # [b, N-1, 2, h, w]
-            pics_u8 = rt.flow_to_image(flows.reshape(-1, 2, *flows.shape[-2:]), wheel, bgr=True)     # reference :199-207
         if world > 1:
-            local_dev.append(pred_u8)
-        if prof is not None:
-            prof["enqueue"] += time.perf_counter() - tp
-            tp = time.perf_counter()
-        drain.submit(j0, [pred_u8, pics_u8], post(j0, single=(world == 1)))
+            # one gather per round and result kind (uint8, device resident); only rank 0 copies anything to the host
+            par = gatherer.parity
+            if copied[par] is not None:
+                torch.cuda.current_stream(device).wait_event(copied[par])    # staging buffers of round k-2 fully drained
+            cnt = [c for _, c in rounds[k]]
+            got = gatherer.gather([pred_u8, pics_u8], [(bsz, N - 1, H0, W0, 3), (bsz * (N - 1), hf, wf, 3)],
+                                  [cnt, [c * (N - 1) for c in cnt]])
+            if rank == 0:
+                blocks = [blk for blk in rounds[k] if blk[1] > 0]
+                tens = []
+                for r, blk in enumerate(rounds[k]):
+                    if blk[1] > 0:
+                        tens += [got[0][r], got[1][r]]
+                copied[par] = drain.submit(k, tens, post(blocks))
+        elif b > 0:
+            drain.submit(k, [pred_u8, pics_u8], post([(j0, b)]))
         if prof is not None:
             prof["submit"] += time.perf_counter() - tp
     tp = time.perf_counter()
-    results = drain.finish()
+    drain.finish()
     frames_in.close()
     if prof is not None:
-        print("[video_Nx] host seconds of the main loop: " + ", ".join(f"{k} {v:.3f}" for k, v in prof.items())
+        print("[video_Nx] host seconds of the main loop: " + ", ".join(f"{k_}: {v:.3f}" for k_, v in prof.items())
               + f", final drain {time.perf_counter() - tp:.3f}")
     if t_warm is not None and rank == 0:
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t_warm
-        nfr = (p1 - p0 - pairs_warm) * (N - 1)
-        print(f"[video_Nx] steady state: {nfr} interpolated frames ({W0}x{H0}, {N}x, {bsz} pairs/forward) in {dt:.3f} s = "
-              f"{nfr / dt:.1f} frames/s on rank 0 incl. PNG decode, H2D, D2H and flow colour-coding")
-    if world > 1:
-        lf = torch.cat(local_dev, 0) if local_dev else torch.zeros((0, N - 1, H0, W0, 3), dtype=torch.uint8, device=device)
-        allf = shard.gather_frames_chunked(lf, num_pairs, rank, world)   # the path's only collective: uint8 frames, RCCL
-        torch.distributed.barrier()                                      # every rank's flow pictures are on disk
-        if rank == 0:
-            allf = allf.cpu().numpy()
-    else:
-        allf = np.concatenate([results[j0][0] for j0 in range(p0, p1, bsz)], 0) if num_pairs > 0 else None
-    if rank == 0:
-        originals = [to_bgr_u8(load_image(os.path.join(args.source_path, f))[0]) for f in img_list]
-        images = [np.concatenate([originals[0], originals[0]], 1)]
-        for j in range(num_pairs):
-            for i in range(N - 1):
-                images.append(np.concatenate([originals[j], allf[j, i][:, :, ::-1]], 1))   # cv2.hconcat([orig, interp])
-            images.append(np.concatenate([originals[j + 1], originals[j + 1]], 1))
-        if world == 1:
-            flows = [pic for j0 in range(p0, p1, bsz) for pic in results[j0][1]]
-        else:
-            flows = [pic for f in sorted(os.listdir(flow_dir)) for pic in np.load(os.path.join(flow_dir, f))]
-        o1 = images_to_video(images[:-1], os.path.join(args.output_path, "output.mp4"), fps=N * 2)
-        o2 = images_to_video(flows, os.path.join(args.output_path, "flow.mp4"), fps=N * 2)
-        shutil.rmtree(flow_dir, ignore_errors=True)
+        nfr = (num_pairs - pairs_warm) * (N - 1)
+        print(f"[video_Nx] steady state: {nfr} interpolated frames ({W0}x{H0}, {N}x, {bsz} pairs/forward x {world} GPU(s)) in {dt:.3f} s = "
+              f"{nfr / dt:.1f} frames/s incl. PNG decode, H2D, gather, D2H and flow colour-coding (video encoding runs beside it)")
+    if rank == 0 and sinks is not None:
+        o1, o2 = sinks[0].close(), sinks[1].close()
+        wall = time.perf_counter() - t_start
+        print(f"[video_Nx] wall clock incl. video writing: {num_pairs * (N - 1)} interpolated frames in {wall:.2f} s = "
+              f"{num_pairs * (N - 1) / wall:.1f} frames/s (first forward includes weight packing + graph capture)")
         print("=========================Interpolation Finished=========================")
-        print(len(images), o1, o2)
+        print(num_pairs * N + 1, o1, o2)
     if world > 1:
         torch.distributed.destroy_process_group()
 

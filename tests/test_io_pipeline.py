@@ -50,3 +50,77 @@ def test_result_drain_surfaces_errors():
     drain.submit(0, [torch.zeros(1)], lambda a: (_ for _ in ()).throw(ValueError("boom")))
     with pytest.raises(ValueError):
         drain.finish()
+
+
+def test_result_drain_bounds_items_in_flight():
+    """At most `depth` items are between submit() and the end of their post-processing (with the posts handed
+    to an unbounded pool the pinned buffers in flight were no longer bounded by the queue depth)."""
+    depth = 3
+    drain = ResultDrain("cpu", depth=depth, workers=2)
+    lock = threading.Lock()
+    live, peak = [0], [0]
+    gate = threading.Event()
+
+    def post(a):
+        with lock:
+            live[0] += 1
+            peak[0] = max(peak[0], live[0])
+        gate.wait(timeout=5)
+        with lock:
+            live[0] -= 1
+        return None
+
+    done = []
+
+    def producer():
+        for k in range(10):
+            drain.submit(k, [torch.zeros(4)], post)
+            done.append(k)
+
+    t = threading.Thread(target=producer)
+    t.start()
+    time.sleep(0.3)
+    assert len(done) <= depth          # the producer is blocked by the bound while the posts hang
+    gate.set()
+    t.join(timeout=20)
+    assert len(done) == 10
+    drain.finish()
+    assert peak[0] <= 2                # (the pool has 2 workers)
+
+
+def test_video_sink_writes_frames_by_index_from_many_threads(tmp_path):
+    """PNG mode of the incremental video writer: frames arrive out of order from several threads, every index is written
+    once under its own name; close() checks completeness."""
+    import os
+
+    import numpy as np
+    from PIL import Image
+
+    from gimmvfi_hip.io_pipeline import VideoSink
+
+    total, h, w = 17, 6, 10
+    sink = VideoSink(str(tmp_path / "output.mp4"), 8, total, (h, w), use_cv2=False)
+    frames = {i: np.full((h, w, 3), i * 7 % 251, dtype=np.uint8) for i in range(total)}
+    for i in frames:
+        frames[i][0, 0] = (1, 2, 3)          # BGR marker -> RGB (3, 2, 1) on disk
+    order = list(range(total))[::-1]
+
+    def work(idxs):
+        for i in idxs:
+            sink.put(i, frames[i])
+
+    ts = [threading.Thread(target=work, args=(order[k::3],)) for k in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    out = sink.close()
+    if os.path.isdir(out):                   # no ffmpeg here: the numbered PNGs stay
+        names = sorted(os.listdir(out))
+        assert names == [f"{i:04d}.png" for i in range(total)]
+        im = np.array(Image.open(os.path.join(out, "0005.png")))
+        assert im.shape == (h, w, 3) and tuple(im[0, 0]) == (3, 2, 1) and int(im[1, 1, 0]) == 5 * 7 % 251
+    sink2 = VideoSink(str(tmp_path / "flow.mp4"), 8, 3, (h, w), use_cv2=False)
+    sink2.put(0, frames[0])
+    with pytest.raises(AssertionError):
+        sink2.close()                        # two frames missing

@@ -1,5 +1,7 @@
 """End-to-end throughput of the CLI (PNG decode -> pad -> H2D -> model -> D2H -> colour-coding), synthetic frames.
-usage: python tools/cli_bench.py [n_frames] [W] [H] [N] [DS_SCALE]"""
+usage: python tools/cli_bench.py [n_frames] [W] [H] [N] [DS_SCALE] [GPUS]
+With GPUS > 1 the CLI is started under torch.distributed.run on this node (one rank per GPU, free port), as
+scripts/video_Nx.sh does."""
 import os
 import subprocess
 import sys
@@ -19,6 +21,7 @@ def main():
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     N = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     ds = sys.argv[5] if len(sys.argv) > 5 else "1.0"
+    gpus = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     from gimmvfi_hip.synth import synthetic_pairs
 
     with tempfile.TemporaryDirectory() as d:
@@ -28,14 +31,27 @@ def main():
         for i in range(n):
             f = np.roll((x[:, i % 2].permute(1, 2, 0).numpy() * 255).astype(np.uint8), 3 * i, axis=1)
             Image.fromarray(f).save(os.path.join(src, f"{i:04d}.png"))
-        cmd = [sys.executable, os.path.join(ROOT, "gimm-vfi_amd", "src", "video_Nx.py"), "--source-path", src,
+        launcher = [sys.executable]
+        if gpus > 1:
+            import socket
+
+            import torch
+
+            if torch.cuda.device_count() < gpus:
+                sys.exit(f"cli_bench: {gpus} GPUs requested, {torch.cuda.device_count()} visible")
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port)]
+        cmd = launcher + [os.path.join(ROOT, "gimm-vfi_amd", "src", "video_Nx.py"), "--source-path", src,
                "--output-path", out, "--N", str(N), "--ds-factor", ds, "-m",
                os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml"), "--random-init", "--eval"]
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True)
         dt = time.perf_counter() - t0
         print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("[video_Nx]")), r.stderr[-300:] if r.returncode else "")
-        print(f"CLI: {n} frames {W}x{H}, {N}x, DS_SCALE {ds} -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
+        print(f"CLI: {n} frames {W}x{H}, {N}x, DS_SCALE {ds}, {gpus} GPU(s) -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
               f"(incl. process start, model build, graph capture, PNG/video writing)")
 
 

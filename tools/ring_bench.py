@@ -87,7 +87,7 @@ def main():
                 s = s[s[:, 0] != 0].double()
                 us_ = (s - s[:, 0].min()) / 100.0
                 kt = KH * KW * (Cin // 64)
-                cells[-1] += (f" [wg {s.shape[0]}: prologue {float((us_[:, 1] - us_[:, 0]).mean()):.2f}, chunk0 +{float((us_[:, 2] - us_[:, 1]).mean()):.2f}, "
+                cells[-1] += (f" [wg {s.shape[0]}: decode {float((us_[:, 7] - us_[:, 0]).mean()):.2f}, prologue {float((us_[:, 1] - us_[:, 0]).mean()):.2f}, chunk0 +{float((us_[:, 2] - us_[:, 1]).mean()):.2f}, "
                               f"K loop {float((us_[:, 3] - us_[:, 2]).mean()):.2f} = {float((us_[:, 3] - us_[:, 2]).mean()) / kt:.3f}/step x {kt}, "
                               f"epilogue {float((us_[:, 5] - us_[:, 3]).mean()):.2f}, span {float(us_[:, 5].max()):.1f} us]")
         print(f"{name:34s} " + " | ".join(cells), flush=True)
