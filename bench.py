@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--model", default="r", choices=["r", "f"],
                     help="r = GIMM-VFI-R (RAFT flow estimator, BASELINE.json configs[1], the default bench line); "
                          "f = GIMM-VFI-F (FlowFormer flow estimator, configs[3])")
+    ap.add_argument("--flow-precision", default=None,
+                    help="(--model f) precision policy of the flow estimator: 'dec' (model default: decoder in float, >= 40 dB "
+                         "against the reference everywhere), 'bf16' (fast mode), 'fp32', or a stage list -- GIMMVFI_F.__init__")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default=None, help="write a per-conv-shape time table (markdown) to this path")
     ap.add_argument("--stub", action="store_true",
@@ -117,7 +120,7 @@ def main():
 
     B, H, W = args.batch, args.height, args.width
     if args.model == "f":
-        model = GIMMVFI_F(precision=args.precision)
+        model = GIMMVFI_F(precision=args.precision, flow_precision=args.flow_precision)
         model.load_state_dict(random_state_dict_f(0), strict=True)
     else:
         model = GIMMVFI_R(precision=args.precision)
@@ -267,6 +270,7 @@ def main():
             "config": {"workload": f"GIMM-VFI-{args.model.upper()} {W}x{H} batch={B} pairs/GPU, {NI}x interpolation (t=i/{NI}), "
                                    f"DS_SCALE={args.ds:g}, seeded random-init weights",
                        "pairs_per_step_per_gpu": B, "flow_iters": 20 if args.model == "r" else 32,
+                       **({"flow_precision": model.flow_precision} if args.model == "f" else {}),
                        "parallelism": f"pair-sharded x{world}",
                        "world_size_rccl": dist.get_world_size() if world > 1 else 1},
             "roofline": roofline, "cpu_baseline": cpu,

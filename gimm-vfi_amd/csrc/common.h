@@ -53,7 +53,54 @@ __host__ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 
-// element traits: T = float or bf16_t
+// IEEE half as a storage type of its own (bf16_t is a plain uint16_t): conversions saturate at +-65504
+struct f16_t { uint16_t v; };
+__host__ __device__ __forceinline__ float h2f(f16_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(_Float16, h.v);
+#else
+    const uint32_t s = (uint32_t)(h.v & 0x8000u) << 16, e = (h.v >> 10) & 31u, m = h.v & 0x3ffu;
+    union { uint32_t u; float f; } c;
+    if (e == 0) {            // zero / subnormal: m * 2^-24
+        c.f = (float)m * (1.0f / 16777216.0f);
+        c.u |= s;
+        return c.f;
+    }
+    c.u = s | (e == 31 ? 0x7f800000u | (m << 13) : ((e + 112u) << 23) | (m << 13));
+    return c.f;
+#endif
+}
+__host__ __device__ __forceinline__ f16_t f2h(float f) {
+    f16_t r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);          // saturate (NaN passes through)
+    r.v = __builtin_bit_cast(uint16_t, (_Float16)f);            // v_cvt_f16_f32, round to nearest even
+    return r;
+#else
+    if (f != f) { r.v = 0x7e00; return r; }
+    f = f < -65504.f ? -65504.f : (f > 65504.f ? 65504.f : f);
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    const uint32_t s = (c.u >> 16) & 0x8000u;
+    c.u &= 0x7fffffffu;
+    const float a = c.f;
+    if (a < 6.103515625e-05f) {                                   // subnormal half: round a * 2^24 to nearest even
+        const float sc = a * 16777216.0f;
+        uint32_t q = (uint32_t)sc;
+        const float fr = sc - (float)q;
+        if (fr > 0.5f || (fr == 0.5f && (q & 1u))) ++q;
+        r.v = (uint16_t)(s | q);
+        return r;
+    }
+    uint32_t u = c.u;
+    u += 0xfffu + ((u >> 13) & 1u);                               // round the 13 dropped bits to nearest even
+    const uint32_t e = (u >> 23) - 112u, m = (u >> 13) & 0x3ffu;
+    r.v = (uint16_t)(s | (e << 10) | m);
+    return r;
+#endif
+}
+
+// element traits: T = float, bf16_t or f16_t
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int VE = 4;  // elements per 16-byte vector
@@ -64,6 +111,12 @@ template <> struct Elem<bf16_t> {
     static constexpr int VE = 8;
     __host__ __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
     __host__ __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+template <> struct Elem<f16_t> {
+    static constexpr int VE = 8;
+    __host__ __device__ static __forceinline__ float ld(const f16_t* p) { return h2f(*p); }
+    __host__ __device__ static __forceinline__ void st(f16_t* p, float v) { *p = f2h(v); }
 };
 
 // load / store one element of a tensor whose dtype is a runtime flag (f32 = 1)
@@ -127,5 +180,6 @@ static inline void gvfi_magic_div(unsigned d, unsigned& mul, unsigned& sh) {
 #define GVFI_DISPATCH_T(dtype, ...)                         \
     do {                                                    \
         if ((dtype) == GVFI_F32) { typedef float T; __VA_ARGS__; } \
+        else if ((dtype) == GVFI_F16) { typedef f16_t T; __VA_ARGS__; } \
         else { typedef bf16_t T; __VA_ARGS__; }             \
     } while (0)

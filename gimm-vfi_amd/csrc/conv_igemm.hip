@@ -30,9 +30,18 @@ __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4
 __device__ __forceinline__ f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
 #endif
 
 template <typename T> struct Mma;
+template <> struct Mma<f16_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+        acc = mfma_f16_32x32x16(a, b, acc);
+    }
+};
 template <> struct Mma<bf16_t> {
     static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
         acc = mfma_bf16_32x32x16(a, b, acc);
@@ -335,5 +344,6 @@ extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15)) return -3;
     if (p.groups > 1 && (p.N % p.groups)) return -4;
     if (p.dtype == GVFI_F32) return dispatch_conv<float>(p, (hipStream_t)stream);
+    if (p.dtype == GVFI_F16) return dispatch_conv<f16_t>(p, (hipStream_t)stream);
     return dispatch_conv<bf16_t>(p, (hipStream_t)stream);
 }

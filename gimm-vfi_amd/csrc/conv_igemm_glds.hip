@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                         const float t = acc[i][j][r] + bj;
                         float v = gelu1 ? fast_gelu(t) : fmaxf(t, 0.f) + sj * fminf(t, 0.f);
                         if (has_sc) v *= p.out_scale;
-                        cs16[row * BN + col] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+                        cs16[row * BN + col] = (bf16_t)(pack16x2<T>(v, 0.f) & 0xffffu);
                     }
                 }
             }
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                     }
                     if (has_res) {
                         float r[8];
-                        unpack_bf16x8(rpre[q], r);
+                        unpack16x8<T>(rpre[q], r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) vv[e] += r[e];
                     }
@@ -686,15 +686,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                         for (int e = 0; e < 8; ++e) vv[e] *= p.out_scale;
                     }
                     uint4 u;
-                    u.x = pack_bf16x2(vv[0], vv[1]);
-                    u.y = pack_bf16x2(vv[2], vv[3]);
-                    u.z = pack_bf16x2(vv[4], vv[5]);
-                    u.w = pack_bf16x2(vv[6], vv[7]);
+                    u.x = pack16x2<T>(vv[0], vv[1]);
+                    u.y = pack16x2<T>(vv[2], vv[3]);
+                    u.z = pack16x2<T>(vv[4], vv[5]);
+                    u.w = pack16x2<T>(vv[6], vv[7]);
                     *(uint4*)(yp + (long long)tr * p.ldy) = u;
                     if constexpr (STATS) {
                         if (do_stats) {   // statistics of the values as stored (bf16-rounded), like gvfi_instnorm_stats
                             float sv[8];
-                            unpack_bf16x8(u, sv);
+                            unpack16x8<T>(u, sv);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 st_sum[e] += sv[e];
@@ -787,10 +787,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                         float vv[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
                         float hh[8], zz[8];
                         if (!zhalf) {
-                            if constexpr (SF) unpack_f32x8(hpre[q], hh); else unpack_bf16x8(hpre[q][0], hh);
+                            if constexpr (SF) unpack_f32x8(hpre[q], hh); else unpack16x8<T>(hpre[q][0], hh);
                         }
                         if (is_q) {
-                            if constexpr (SF) unpack_f32x8(zpre[q], zz); else unpack_bf16x8(zpre[q][0], zz);
+                            if constexpr (SF) unpack_f32x8(zpre[q], zz); else unpack16x8<T>(zpre[q][0], zz);
                         }
                         if (has_ctx) {
                             float cc[8];
@@ -809,10 +809,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
                             continue;
                         }
                         uint4 u;
-                        u.x = pack_bf16x2(vv[0], vv[1]);
-                        u.y = pack_bf16x2(vv[2], vv[3]);
-                        u.z = pack_bf16x2(vv[4], vv[5]);
-                        u.w = pack_bf16x2(vv[6], vv[7]);
+                        u.x = pack16x2<T>(vv[0], vv[1]);
+                        u.y = pack16x2<T>(vv[2], vv[3]);
+                        u.z = pack16x2<T>(vv[4], vv[5]);
+                        u.w = pack16x2<T>(vv[6], vv[7]);
                         *(uint4*)(yp + (long long)tr * ldo) = u;
                         if (SF && is_q && p.y2 != nullptr) store_f32x8(yhf + (long long)tr * p.ldy2, vv);   // the state itself
                     }
@@ -920,6 +920,7 @@ extern "C" int gvfi_conv2d_glds_eligible(const gvfi_conv_params* pp) {
     const int e128 = p.dtype == GVFI_F32 ? 32 : 64;
     if (p.c0 % e128 == 0 && p.c1 % e128 == 0) return 128;
     if (p.w_layout != 0) return 0;   // 64-byte chunking reads the plain [Cout][K] weight image
+    if (p.dtype == GVFI_F16) return 0;   // (half operands: only the 128-byte chunk variants are instantiated)
     const int e64 = e128 / 2;
     if (p.c0 % e64 == 0 && p.c1 % e64 == 0) return 64;
     return 0;
@@ -942,7 +943,7 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     if (p.w_layout == 2) {
         // weights-direct variant: fragment-ordered weight image, 64-row tiles, column tile 128 (wave slices of 32) or 256
         // (slices of 64; tile_hint 256), register / LDS ring of 4 chunks
-        if (kb != 128 || p.dtype != GVFI_BF16 || groups != 1) return -5;
+        if (kb != 128 || p.dtype == GVFI_F32 || groups != 1) return -5;
         plan[0] = 6;
         plan[1] = 64;
         plan[2] = (p.tile_hint & 1023) == 256 ? 256 : 128;
@@ -952,7 +953,8 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     }
     int tile = p.tile_hint & 1023, bm = (p.tile_hint >> 10) & 1023;
     const int ns_hint = (p.tile_hint >> 20) & 15;   // ring depth override (0 = auto), 128-byte chunks only
-    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
+    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256 && p.dtype != GVFI_F16) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
+    if (p.dtype == GVFI_F16 && tile >= 256) tile = 128;
     tile = tile >= 256 ? 256 : (tile >= 128 ? 128 : (tile >= 64 ? 64 : 32));
     int k = 64, ns = 2;
     if (tile == 256) k = p.w_layout == 0 ? 64 : 128;
@@ -992,6 +994,10 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (p.stats != nullptr && !gvfi_conv2d_stats_ok(pp)) return -6;   // statistics requested but not computable here
     hipStream_t st = (hipStream_t)stream;
     if (plan[0] == 6) {
+        if (p.dtype == GVFI_F16) {
+            if (plan[2] == 256) return launch_glds<f16_t, 64, 256, 1, 4, 128, 4, false, 1, true>(p, st);
+            return launch_glds<f16_t, 64, 128, 1, 4, 128, 4, false, 1, true>(p, st);
+        }
         if (plan[2] == 256) return launch_glds<bf16_t, 64, 256, 1, 4, 128, 4, false, 1, true>(p, st);
         return launch_glds<bf16_t, 64, 128, 1, 4, 128, 4, false, 1, true>(p, st);
     }
@@ -1025,6 +1031,17 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (ns == 4) return launch_glds<TT, 128, 32, 4, 1, 128, 4>(p, st);                                        \
     return launch_glds<TT, 128, 32, 4, 1, 128, 2>(p, st);
     if (p.dtype == GVFI_F32) { GLDS_DISPATCH(float) }
+    if (p.dtype == GVFI_F16) {
+        // IEEE-half operands: the tiles of the flow estimators' recurrence (small M); everything else of that size takes the
+        // 128-wide 4-wave tiles
+        if (tile == 256 || k != 128) return -7;
+        if (tile == 128) {
+            if (bm == 64) return launch_glds<f16_t, 64, 128, 2, 2, 128, 2>(p, st);
+            return launch_glds<f16_t, 128, 128, 2, 2, 128, 2>(p, st);
+        }
+        if (tile == 64) return launch_glds<f16_t, 128, 64, 2, 2, 128, 2>(p, st);
+        return launch_glds<f16_t, 128, 32, 4, 1, 128, 2>(p, st);
+    }
     GLDS_DISPATCH(bf16_t)
 #undef GLDS_DISPATCH
 }

@@ -9,6 +9,10 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -100,6 +104,11 @@ template <> struct Mma2<bf16_t> {
         acc = mfma_bf16_32x32x16(a, b, acc);
     }
 };
+template <> struct Mma2<f16_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+        acc = mfma_f16_32x32x16(a, b, acc);
+    }
+};
 template <> struct Mma2<float> {
     static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
         acc = mfma_f32_32x32x2(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc);
@@ -129,30 +138,51 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 #endif
 }
+// two floats -> packed IEEE half x2 (round to nearest even, saturating)
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    return (uint32_t)f2h(lo).v | ((uint32_t)f2h(hi).v << 16);
+}
+// 16-bit element types: pack two / unpack eight values of type T (bf16_t or f16_t)
+template <typename T> __device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) return pack_f16x2(lo, hi);
+    else return pack_bf16x2(lo, hi);
+}
+template <typename T> __device__ __forceinline__ float cvt16(uint32_t bits16) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {
+        f16_t h;
+        h.v = (uint16_t)bits16;
+        return h2f(h);
+    } else return bf2f((bf16_t)bits16);
+}
+template <typename T> __device__ __forceinline__ void unpack16x8(const uint4& u, float (&o)[8]) {
+    o[0] = cvt16<T>(u.x & 0xffff); o[1] = cvt16<T>(u.x >> 16);
+    o[2] = cvt16<T>(u.y & 0xffff); o[3] = cvt16<T>(u.y >> 16);
+    o[4] = cvt16<T>(u.z & 0xffff); o[5] = cvt16<T>(u.z >> 16);
+    o[6] = cvt16<T>(u.w & 0xffff); o[7] = cvt16<T>(u.w >> 16);
+}
+template <typename T>
 __device__ __forceinline__ void ld8(const void* base, long long idx, int is_f32, bool bf16_elems, float (&o)[8]) {
     if (is_f32 || !bf16_elems) {
         const float4 a = *(const float4*)((const float*)base + idx);
         const float4 b = *(const float4*)((const float*)base + idx + 4);
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     } else {
-        const uint4 u = *(const uint4*)((const bf16_t*)base + idx);
-        o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16));
-        o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
-        o[4] = bf2f((bf16_t)(u.z & 0xffff)); o[5] = bf2f((bf16_t)(u.z >> 16));
-        o[6] = bf2f((bf16_t)(u.w & 0xffff)); o[7] = bf2f((bf16_t)(u.w >> 16));
+        const uint4 u = *(const uint4*)((const uint16_t*)base + idx);
+        unpack16x8<T>(u, o);
     }
 }
+template <typename T>
 __device__ __forceinline__ void st8(void* base, long long idx, int is_f32, bool bf16_elems, const float (&v)[8]) {
     if (is_f32 || !bf16_elems) {
         *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
         *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
         uint4 u;
-        u.x = pack_bf16x2(v[0], v[1]);
-        u.y = pack_bf16x2(v[2], v[3]);
-        u.z = pack_bf16x2(v[4], v[5]);
-        u.w = pack_bf16x2(v[6], v[7]);
-        *(uint4*)((bf16_t*)base + idx) = u;
+        u.x = pack16x2<T>(v[0], v[1]);
+        u.y = pack16x2<T>(v[2], v[3]);
+        u.z = pack16x2<T>(v[4], v[5]);
+        u.w = pack16x2<T>(v[6], v[7]);
+        *(uint4*)((uint16_t*)base + idx) = u;
     }
 }
 // hardware-rate sigmoid / tanh for the bf16 path (v_exp_f32 + v_rcp_f32, ~1 ulp each: far inside bf16 rounding);
@@ -251,7 +281,7 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         act8s(v, p.act1, gc.s1);
         if (p.res) {
             float r[8];
-            if (vec) ld8(p.res, pix * p.ldr + cout0, p.res_f32, BF, r);
+            if (vec) ld8<T>(p.res, pix * p.ldr + cout0, p.res_f32, BF, r);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = (e < n_valid) ? ld_any<T>(p.res, pix * p.ldr + cout0 + e, p.res_f32) : 0.f;
@@ -264,7 +294,7 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
         }
-        if (vec) st8(p.y, pix * p.ldy + cout0, p.y_f32, BF, v);
+        if (vec) st8<T>(p.y, pix * p.ldy + cout0, p.y_f32, BF, v);
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, p.y_f32, v[e]);
@@ -280,7 +310,7 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         for (int e = 0; e < 8; ++e) v[e] = gvfi_sigmoid(v[e]);
         const int sf = p.state_f32;     // float recurrent state (z, h), see gvfi_conv_params.state_f32
         if (cout0 < half) {
-            if (vec) st8(p.y, pix * p.ldy + cout0, sf, BF, v);
+            if (vec) st8<T>(p.y, pix * p.ldy + cout0, sf, BF, v);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, sf, v[e]);
@@ -288,14 +318,14 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         } else {
             const int c0 = cout0 - half;
             float h[8];
-            if (vec) ld8(p.aux0, pix * p.lda0 + c0, sf, BF, h);
+            if (vec) ld8<T>(p.aux0, pix * p.lda0 + c0, sf, BF, h);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h[e] = (e < n_valid) ? ld_any<T>(p.aux0, pix * p.lda0 + c0 + e, sf) : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= h[e];
-            if (vec) st8(p.y2, pix * p.ldy2 + c0, 0, BF, v);
+            if (vec) st8<T>(p.y2, pix * p.ldy2 + c0, 0, BF, v);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y2, pix * p.ldy2 + c0 + e, 0, v[e]);
@@ -310,8 +340,8 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         const int sf = p.state_f32;
         float h[8], z[8];
         if (vec) {
-            ld8(p.aux0, pix * p.lda0 + cout0, sf, BF, h);
-            ld8(p.aux1, pix * p.lda1 + cout0, sf, BF, z);
+            ld8<T>(p.aux0, pix * p.lda0 + cout0, sf, BF, h);
+            ld8<T>(p.aux1, pix * p.lda1 + cout0, sf, BF, z);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -321,13 +351,13 @@ __device__ __forceinline__ void epilogue_group(const gvfi_conv_params& p, const 
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (1.f - z[e]) * h[e] + z[e] * tanhf(v[e]);
-        if (vec) st8(p.y, pix * p.ldy + cout0, 0, BF, v);
+        if (vec) st8<T>(p.y, pix * p.ldy + cout0, 0, BF, v);
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y, pix * p.ldy + cout0 + e, 0, v[e]);
         }
         if (sf && p.y2 != nullptr) {   // the float state beside its bf16 operand copy
-            if (vec) st8(p.y2, pix * p.ldy2 + cout0, 1, BF, v);
+            if (vec) st8<T>(p.y2, pix * p.ldy2 + cout0, 1, BF, v);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (e < n_valid) st_any<T>(p.y2, pix * p.ldy2 + cout0 + e, 1, v[e]);

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(PatchArgs a) {
                             const int oy = oy0 + lp / TW, ox = ox0 + lp % TW;
                             if (k < iters && oy < p.Ho && ox < p.Wo) {
                                 const long long pix = ((long long)n_img * p.Ho + oy) * p.Wo + ox;
-                                if (vec && !pad16) ld8(p.res, pix * p.ldr + cout0, p.res_f32, BF, rr[k]);
+                                if (vec && !pad16) ld8<T>(p.res, pix * p.ldr + cout0, p.res_f32, BF, rr[k]);
                                 else if (vec && (p.res_f32 || !BF)) {     // whole float4 units up to the padded end
                                     const float* rp = (const float*)p.res + pix * p.ldr + cout0;
                                     const float4 q0 = *(const float4*)rp;
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(PatchArgs a) {
                                         const float4 q1 = *(const float4*)(rp + 4);
                                         rr[k][4] = q1.x; rr[k][5] = q1.y; rr[k][6] = q1.z; rr[k][7] = q1.w;
                                     }
-                                } else if (vec) ld8(p.res, pix * p.ldr + cout0, 0, BF, rr[k]);
+                                } else if (vec) ld8<T>(p.res, pix * p.ldr + cout0, 0, BF, rr[k]);
                                 else {
 #pragma unroll
                                     for (int e = 0; e < 8; ++e)
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(PatchArgs a) {
                             for (int e = 0; e < 8; ++e)
                                 if (e >= n_valid) vv[e] = 0.f;      // pad channels are written as zeros
                         }
-                        if (vec && nst == 8) st8(p.y, pix * p.ldy + cout0, p.y_f32, BF, vv);
+                        if (vec && nst == 8) st8<T>(p.y, pix * p.ldy + cout0, p.y_f32, BF, vv);
                         else if (vec) {    // f32 output, one float4 (nst == 4)
                             *(float4*)((float*)p.y + pix * p.ldy + cout0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                         } else {
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(PatchArgs a) {
 static int patch_plan(const gvfi_conv_params& p, PatchArgs& a) {
     const int ve = p.dtype == GVFI_F32 ? 4 : 8, esz = p.dtype == GVFI_F32 ? 4 : 2;
     if (p.c1 != 0 || p.x1 != nullptr || p.c0 <= 0 || (p.c0 % ve) || p.groups > 1 || p.epi_mode != GVFI_EPI_STD) return 0;
-    if (p.w_layout != 0 || p.stats != nullptr || p.Cout > 64 || p.Cout <= 0) return 0;
+    if (p.w_layout != 0 || p.stats != nullptr || p.Cout > 64 || p.Cout <= 0 || p.dtype == GVFI_F16) return 0;
     if (p.stride != 1 && p.stride != 2) return 0;
     if (p.KH > 7 || p.KW > 7 || p.KH * p.KW < 1) return 0;
     if (p.pad_mode == GVFI_PAD_REFLECT && (p.pad_h >= p.H || p.pad_w >= p.W)) return 0;

@@ -43,39 +43,45 @@ FLOW_STAGES = ("enc", "cost", "tok", "upd")
 
 
 def parse_flow_policy(spec):
-    """'bf16' / None -> no stage in float; 'fp32' -> all; else a comma list of the stages that run in float:
-    enc (Twins encoders + channel convertor), cost (cost volume + latent cost encoder), and of the 32-iteration decoder
-    tok (flow token: 81-tap cost look-up, token encoder, cross-attention against the cost memory -> cost_global) and upd
-    (GMA update block: motion encoder, aggregation, ConvGRU, flow head); dec = tok + upd."""
+    """flow_precision -> {stage: "fp32" | "fp16"} for the stages that leave bf16.  Stages: enc (Twins encoders + channel
+    convertor), cost (cost volume + latent cost encoder), and of the 32-iteration decoder tok (flow token: 81-tap cost
+    look-up, token encoder, cross-attention against the cost memory -> cost_global) and upd (GMA update block: motion
+    encoder, aggregation, ConvGRU, flow head); dec = tok + upd.  Grammar: "bf16" (none), "fp32" (all four in float), or a
+    comma list of stage[:type] with type f16 (IEEE half operands, bf16 speed) or fp32 (default), e.g. "dec:f16"."""
     if spec in (None, "", "bf16"):
-        return ()
+        return {}
     if spec == "fp32":
-        return FLOW_STAGES
-    st = []
-    for x in (y.strip() for y in spec.split(",")):
-        if not x:
+        return {st: "fp32" for st in FLOW_STAGES}
+    pol = {}
+    for item in (y.strip() for y in spec.split(",")):
+        if not item:
             continue
-        if x == "dec":
-            st += ["tok", "upd"]
-        elif x in FLOW_STAGES:
-            st.append(x)
-        else:
-            raise ValueError(f"flow_precision: unknown stage {x!r} (stages: {FLOW_STAGES} + 'dec', or 'bf16' / 'fp32')")
-    return tuple(dict.fromkeys(st))
+        name, _, typ = item.partition(":")
+        typ = {"": "fp32", "fp32": "fp32", "f32": "fp32", "f16": "fp16", "fp16": "fp16"}.get(typ.strip())
+        if typ is None:
+            raise ValueError(f"flow_precision: unknown type in {item!r} (f16 or fp32)")
+        name = name.strip()
+        stages = ("tok", "upd") if name == "dec" else (name,)
+        for st in stages:
+            if st not in FLOW_STAGES:
+                raise ValueError(f"flow_precision: unknown stage {name!r} (stages: {FLOW_STAGES} + 'dec', or 'bf16' / 'fp32')")
+            pol[st] = typ
+    return pol
 
 
 class EngineF(Engine):
     def __init__(self, rt, sd, motion_only=False, flow_precision=None, flow_only=False):
-        """flow_precision (bf16 runtime only): which stages of the FLOW ESTIMATOR run in float (exact-f32 MFMA) while
-        everything behind it stays bf16 -- see parse_flow_policy.  The float stages run on a second engine over the same
-        library (`self.hi`, flow-estimator layers only); tensors crossing a stage boundary are converted by
-        gvfi_copy_channels."""
+        """flow_precision (bf16 runtime only): which stages of the FLOW ESTIMATOR run in float (exact-f32 MFMA) or with
+        IEEE-half operands while everything behind it stays bf16 -- see parse_flow_policy.  Those stages run on side
+        engines over the same library (`self.side[type]`, flow-estimator layers only); tensors crossing a stage boundary
+        are converted by gvfi_copy_channels."""
         self._flow_only = flow_only
-        self.flow_f32 = parse_flow_policy(flow_precision) if rt.precision == "bf16" else ()
-        self.hi = None
+        self.flow_policy = parse_flow_policy(flow_precision) if rt.precision == "bf16" else {}
+        self.side = {}          # "fp32" / "fp16" -> engine of that precision holding the flow-estimator layers
         super().__init__(rt, sd, motion_only=motion_only)
-        if self.flow_f32 and not motion_only:
-            self.hi = EngineF(rt.sibling("fp32"), sd, flow_only=True)
+        if not motion_only:
+            for typ in sorted(set(self.flow_policy.values())):
+                self.side[typ] = EngineF(rt.sibling(typ), sd, flow_only=True)
 
     def _build(self, sd):
         if self._flow_only:
@@ -619,29 +625,49 @@ class EngineF(Engine):
         return rt.convex_upsample(coords, mask)
 
     def _cvt(self, t, eng):
-        """t in the activation type of engine `eng` (stage boundary of the precision policy; gvfi_copy_channels)."""
-        if t.dtype == eng.rt.tdtype:
+        """t in the activation type of engine `eng` (stage boundary of the precision policy; gvfi_copy_channels converts
+        between float and ONE 16-bit type, so bf16 <-> half goes through a float temporary)."""
+        want = eng.rt.tdtype
+        if t.dtype == want:
             return t
-        out = torch.empty(t.shape, dtype=eng.rt.tdtype, device=t.device)
         c = t.shape[-1]
         v = lambda x: View(x.view(-1, c))
-        self.rt.copy(v(t), v(out), c)
-        return out
+
+        def one(src, dst_dtype):
+            rt16 = next(e.rt for e in (self, *self.side.values())
+                        if e.rt.tdtype == (src.dtype if src.dtype != torch.float32 else dst_dtype))
+            dst = torch.empty(src.shape, dtype=dst_dtype, device=src.device)
+            rt16.copy(v(src), v(dst), c)
+            return dst
+
+        if t.dtype != torch.float32 and want != torch.float32:
+            t = one(t, torch.float32)
+        return one(t, want)
+
+    def _cvt_into(self, src, dst, c):
+        """per-iteration hand-over of the token path's cost tensor to the update block (Views, c channels)"""
+        if src.t.dtype != torch.float32 and dst.t.dtype != torch.float32 and src.t.dtype != dst.t.dtype:
+            tmp = torch.empty((src.npix, c), dtype=torch.float32, device=src.t.device)
+            self._cvt_into(src, View(tmp), c)
+            src = View(tmp)
+        d16 = src.t.dtype if src.t.dtype != torch.float32 else dst.t.dtype
+        rt16 = next(e.rt for e in (self, *self.side.values()) if e.rt.tdtype == d16)
+        rt16.copy(src, dst, c)
 
     def _flowformer(self, imgA, B, iters, taps, seq=False):
         n = 2 * B
         H, W = imgA.shape[1:3]
         h8, w8 = H // 8, W // 8
-        eng = {st: (self.hi if st in self.flow_f32 else self) for st in FLOW_STAGES}
+        eng = {st: (self.side[self.flow_policy[st]] if st in self.flow_policy else self) for st in FLOW_STAGES}
         img_e = imgA
-        if eng["enc"] is not self:      # the float stage reads the float image, not its bf16 rounding
-            img_e, _ = self.hi.rt.prep_images(self._cur_img_xs)
+        if eng["enc"] is not self:      # the side stage reads the float image, not its bf16 rounding
+            img_e, _ = eng["enc"].rt.prep_images(self._cur_img_xs)
         cfeat, fmap = eng["enc"]._ff_encode(img_e, B, seq)
         ec = eng["cost"]
         vol, mem = ec._ff_cost(self._cvt(fmap, ec), self._cvt(cfeat[1], ec), n, B, h8, w8, taps)
         ed, et = eng["upd"], eng["tok"]
         flow_up = ed._ff_decode(vol, self._cvt(mem, ed), self._cvt(cfeat[1], ed), n, B, h8, w8, iters, taps, tok=et,
-                                mem_tok=self._cvt(mem, et), cvt=self.rt.copy)
+                                mem_tok=self._cvt(mem, et), cvt=self._cvt_into)
         cfeat = [self._cvt(f, self) for f in cfeat]
         fmap = self._cvt(fmap, self)
         if taps is not None:

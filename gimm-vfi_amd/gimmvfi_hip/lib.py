@@ -17,7 +17,7 @@ REPO_ROOT = os.path.abspath(os.path.join(_HERE, "..", ".."))
 HEADER = os.path.join(REPO_ROOT, "include", "gimmvfi_hip.h")
 LIB_PATH = os.path.abspath(os.path.join(_HERE, "..", "lib", "libgimmvfi_hip.so"))
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU, ACT_SIGMOID, ACT_TANH, ACT_SIN, ACT_GELU = range(8)
 PAD_ZEROS, PAD_REFLECT = 0, 1
 EPI_STD, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2

@@ -263,14 +263,17 @@ class GIMMVFI_F(GIMMVFI_R):
     _init_sd = staticmethod(random_state_dict_f)
 
     def __init__(self, config=None, precision=None, flow_precision=None):
-        """flow_precision (with precision "bf16"): precision policy of the FlowFormer flow estimator only --
-        "bf16" (all bf16 MFMA), "fp32" (the whole flow estimator on exact-f32 MFMA, synthesis and motion INR stay
-        bf16), or a comma list of the stages to run in float: enc (Twins encoders), cost (cost volume + latent cost
-        encoder), dec (32-iteration decoder).  Default: config.flow_precision, $GIMMVFI_F_FLOW_PRECISION, else "bf16".
-        See DESIGN.md section 9 for the measured fidelity / speed of each policy."""
+        """flow_precision (with precision "bf16"): precision policy of the FlowFormer flow estimator only -- a comma list
+        of the stages that run in float (exact-f32 MFMA) while everything else stays bf16: enc (Twins encoders), cost (cost
+        volume + latent cost encoder), tok / upd (flow-token path / GMA update block of the 32-iteration decoder; dec =
+        both), "fp32" = all of them, "bf16" = none.  Default: config.flow_precision, $GIMMVFI_F_FLOW_PRECISION, else
+        "dec": measured against the reference's own outputs (profiles/r3_f_policy.md), the update block is the one stage
+        whose bf16 operand rounding shows in the frames when the flows are large (32-40 dB at 2K / 4K with 40-50 px flows;
+        42.9-51.9 dB with "dec"; >= 52 dB in pure bf16 when the flows stay below 10 px) -- the default meets the 40 dB
+        tolerance everywhere, "bf16" is the fast mode (174 vs 91 frames/s at 448x256, B = 8).  DESIGN.md section 9."""
         super().__init__(config, precision)
         cfg_fp = _cfg_get(config, "flow_precision")
-        self.flow_precision = flow_precision or cfg_fp or os.environ.get("GIMMVFI_F_FLOW_PRECISION", "bf16")
+        self.flow_precision = flow_precision or cfg_fp or os.environ.get("GIMMVFI_F_FLOW_PRECISION", "dec")
 
     def _make_engine(self, runtime):
         return self._engine_cls(runtime, self.state_dict(), flow_precision=self.flow_precision)

@@ -78,7 +78,7 @@ class ConvLayer:
             wk = torch.gather(wk, 2, src_slot[:, None, :, None].expand(cout, k // bke, 8, rt.VE))
             self.w_glds = wk.permute(1, 0, 2, 3).contiguous().to(rt.tdtype).to(rt.device)   # [chunk][n][slot][ve]
         self.w_frag = None
-        if (wdir and rt.precision == "bf16" and cp % 64 == 0 and pad_mode == L.PAD_ZEROS and kh * kw <= 32
+        if (wdir and rt.precision in ("bf16", "fp16") and cp % 64 == 0 and pad_mode == L.PAD_ZEROS and kh * kw <= 32
                 and os.environ.get("GVFI_WDIR", "1") != "0"):
             k = kh * kw * cp
             nb = (cout + 31) // 32
@@ -200,8 +200,12 @@ class Runtime:
             self.dtype, self.tdtype, self.VE = L.F32, torch.float32, 4
         elif precision == "bf16":
             self.dtype, self.tdtype, self.VE = L.BF16, torch.bfloat16, 8
+        elif precision == "fp16":
+            # IEEE half activations / weights (GVFI_F16): the decoder of GIMM-VFI-F's flow estimator -- not a mode of the
+            # whole model (the halo-staged 3x3 / patch / fused-INR kernels of the synthesis path are bf16 / float only)
+            self.dtype, self.tdtype, self.VE = L.F16, torch.float16, 8
         else:
-            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision}")
+            raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {precision}")
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.n_launch = 0
@@ -345,7 +349,7 @@ class Runtime:
             algo |= 16
         p.tile_hint = tile
         p.algo = algo
-        p.state_f32 = 1 if (state_f32 and self.dtype == L.BF16) else 0
+        p.state_f32 = 1 if (state_f32 and self.dtype != L.F32) else 0
         p.stats = None
         if layer is not None and want == 0 and p.w_layout == 1 and stats is None and self.use_p3x3 \
                 and self.lib.conv2d_p3x3_eligible(C.byref(p)) == 1:
@@ -383,7 +387,7 @@ class Runtime:
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
             kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel",
                      6: "conv_igemm_glds_kernel[wdir]"}[plan[0]]
-            tag = f"{kname}<{'float' if self.dtype == L.F32 else 'bf16'},{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
+            tag = f"{kname}<{ {L.F32: 'float', L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"
             self.ev_log.append((tag, flops, e0, e1))

@@ -22,7 +22,14 @@
 extern "C" {
 #endif
 
-enum { GVFI_F32 = 0, GVFI_BF16 = 1 };
+/* element type of the activation / weight tensors of a call ("dtype").  GVFI_F16 (IEEE half, MFMA
+ * v_mfma_f32_32x32x16_f16 at the bf16 rate, float accumulation, conversions saturate at +-65504) exists for the
+ * recurrence of the FlowFormer flow estimator: 11 significand bits instead of 8 -- bf16 operand rounding inside the
+ * un-trained 32-iteration update block costs GIMM-VFI-F its reference fidelity at 2K / 4K, half precision does not
+ * (DESIGN.md section 9).  Supported by the LDS-DMA convolution (4-wave tiles + weights-direct variant), the generic
+ * convolution and every element-wise / gather kernel; the halo-staged 3x3, patch, fused-INR and MFMA-attention kernels
+ * are bf16 / float only and report "not eligible" for it. */
+enum { GVFI_F32 = 0, GVFI_BF16 = 1, GVFI_F16 = 2 };
 enum {
     GVFI_ACT_NONE = 0,
     GVFI_ACT_RELU = 1,

@@ -147,6 +147,41 @@ static inline f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4& b, f32x16 c
     emu::wave_sync();
     return c;
 }
+// v_mfma_f32_32x32x16_f16: the same layouts with IEEE half operands
+static inline float emu_h2f(uint16_t v) {
+    const uint32_t sg = (uint32_t)(v & 0x8000u) << 16, e = (v >> 10) & 31u, m = v & 0x3ffu;
+    uint32_t u;
+    float f;
+    if (e == 0) {
+        f = (float)m * (1.0f / 16777216.0f);
+        std::memcpy(&u, &f, 4);
+        u |= sg;
+    } else {
+        u = sg | (e == 31 ? 0x7f800000u | (m << 13) : ((e + 112u) << 23) | (m << 13));
+    }
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+static inline f32x16 mfma_f16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
+    uint32_t* s = emu::wave_scratch();
+    const int l = emu::tl_lane;
+    std::memcpy(&s[l * 16], &a, 16);
+    std::memcpy(&s[l * 16 + 4], &b, 16);
+    emu::wave_sync();
+    const int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const uint16_t* pa = reinterpret_cast<const uint16_t*>(&s[(i + 32 * (k >> 3)) * 16]);
+            const uint16_t* pb = reinterpret_cast<const uint16_t*>(&s[(j + 32 * (k >> 3)) * 16 + 4]);
+            acc += emu_h2f(pa[k & 7]) * emu_h2f(pb[k & 7]);
+        }
+        c[r] = acc;
+    }
+    emu::wave_sync();
+    return c;
+}
 // v_mfma_f32_32x32x2_f32: A lane l holds A[i=l&31][k=l>>5]; B lane l holds B[k=l>>5][j=l&31].
 static inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     uint32_t* s = emu::wave_scratch();

@@ -30,7 +30,7 @@ def _rounded(rt, x):
 
 
 def tol(rt, scale):
-    return (2e-5 if rt.precision == "fp32" else 1.2e-2) * scale
+    return {"fp32": 2e-5, "bf16": 1.2e-2, "fp16": 1.6e-3}[rt.precision] * scale
 
 
 def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.ACT_NONE, with_res=False,

@@ -84,21 +84,23 @@ def test_engine_f_sim_flow_precision_policy(sd_f):
     from gimmvfi_hip.engine_f import EngineF, parse_flow_policy
     from sim_runtime import SimRuntime
 
-    assert parse_flow_policy("bf16") == () and parse_flow_policy("fp32") == ("enc", "cost", "tok", "upd")
-    assert parse_flow_policy("cost, dec") == ("cost", "tok", "upd") and parse_flow_policy("tok") == ("tok",)
-    with pytest.raises(ValueError):
-        parse_flow_policy("decoder")
+    assert parse_flow_policy("bf16") == {} and parse_flow_policy("fp32") == {s: "fp32" for s in ("enc", "cost", "tok", "upd")}
+    assert parse_flow_policy("cost, dec") == {"cost": "fp32", "tok": "fp32", "upd": "fp32"}
+    assert parse_flow_policy("dec:f16") == {"tok": "fp16", "upd": "fp16"} and parse_flow_policy("upd:f16,enc") == {"upd": "fp16", "enc": "fp32"}
+    for bad in ("decoder", "dec:f8"):
+        with pytest.raises(ValueError):
+            parse_flow_policy(bad)
     meta, gold = load_golden("f_128x192_t050")
     x, coords, ts = golden_inputs(meta)
     mixed = EngineF(SimRuntime("bf16"), sd_f, flow_precision="fp32").forward(x, coords, ts, iters=None)
     assert maxabs(mixed["raft_flow"], gold["raft_flow"]) < 2e-3          # the float flow estimator
     p_mixed = psnr(mixed["imgt_pred"][0], gold["imgt_pred_0"])
     assert p_mixed > 50.0, p_mixed                                       # bf16 synthesis on exact flows
-    for pol in ("tok", "upd", "enc"):      # one float stage: every stage-boundary conversion of the launch list
+    for pol in ("tok", "upd", "enc", "dec:f16", "upd:f16,tok"):      # every stage-boundary conversion of the launch list
         part = EngineF(SimRuntime("bf16"), sd_f, flow_precision=pol).forward(x, coords, ts, iters=None)
         assert psnr(part["imgt_pred"][0], gold["imgt_pred_0"]) > 40.0, pol
     # an fp32 engine ignores the policy (everything is float already)
-    assert EngineF(SimRuntime("fp32"), sd_f, flow_precision="fp32").hi is None
+    assert EngineF(SimRuntime("fp32"), sd_f, flow_precision="fp32").side == {}
 
 
 def test_engine_f_sim_ragged_grid(sd_f):

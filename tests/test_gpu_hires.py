@@ -240,7 +240,7 @@ def fmt_metrics(m, meta):
             f"p99.9 {m['flow999']:.2e} px (max |flow| {meta['flow_absmax']:.1f})")
 
 
-def check_hr(out, meta, z, prec, tag, kind="r"):
+def check_hr(out, meta, z, prec, tag, kind="r", bounds=None):
     m = hr_metrics(out, meta, z)
     worst_psnr, worst_lsb, worst_bm, worst_flow, worst_frac, worst_bm999, worst_fmed = (
         m["psnr"], m["lsb"], m["bm"], m["flow999"], m["frac"], m["bm999"], m["fmed"])
@@ -248,9 +248,8 @@ def check_hr(out, meta, z, prec, tag, kind="r"):
     # The reference formula has discontinuities: splat holes (0/0 -> 1, softsplat.py:333-334) and foldovers flip on a
     # 1e-6 flow difference, more of them the rougher the flow (the seeded random weights give GIMM-VFI-F 40-50 px flows
     # full of them).  Hence: R fp32 everything within 1 LSB; F fp32 all but <= 2e-4 of the pixels (measured: 0 on three
-    # cases, 7e-5 on the demo pair with 51 px flows); bf16 judged by PSNR
-    # and the median / p99.9 flow error.  tools/f_bf16_diag.py shows where F's bf16 mode leaves its fp32 mode: the flow
-    # estimator stays within 0.1-0.25 px rms, the splat then turns that into a 10 % relative difference of the latent.
+    # cases, 7e-5 on the demo pair with 51 px flows); bf16 judged by PSNR, the fraction of crop pixels off by more than
+    # 1 LSB and the mean / median / p99.9 flow error.
     if prec == "fp32":
         if kind == "r":
             assert worst_lsb <= 1, worst_lsb                    # +-1 LSB of the 8-bit frame
@@ -264,8 +263,14 @@ def check_hr(out, meta, z, prec, tag, kind="r"):
         assert worst_bm <= 1e-1, worst_bm      # one 16x16 block; sub-pixel flow differences at occlusion edges
         assert worst_flow <= 0.25, worst_flow
     else:
-        assert worst_psnr >= 30.0, worst_psnr
-        assert worst_fmed <= 0.5, worst_fmed
+        # GIMM-VFI-F, bf16: `bounds` = (min PSNR, max fraction of crop pixels > 1 LSB, max mean flow error, max p99.9 flow
+        # error) -- the default policy (decoder of the flow estimator in float) has one set for all cases, the all-bf16 fast
+        # mode is pinned per case to what it measures (profiles/r3_f_policy.md) plus a margin
+        min_psnr, max_frac, max_fmean, max_f999 = bounds
+        assert worst_psnr >= min_psnr, worst_psnr
+        assert worst_frac <= max_frac, worst_frac
+        assert m["fmean"] <= max_fmean, m["fmean"]
+        assert worst_flow <= max_f999, worst_flow
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -280,17 +285,68 @@ def test_hires_matches_reference_fixture(sd, name, prec):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+# GIMM-VFI-F in bf16 against the reference fixtures.  Default policy (flow_precision = "dec"): the 40 dB tolerance of
+# every other bf16 test.  Fast mode (flow_precision = "bf16"): per-case pins = measured value + margin (three calls of
+# round 3 agree within 0.3 dB): it reaches 40 dB only while the flows are small (the *_fh015 fixtures below).
+F_DEFAULT_BOUNDS = (40.0, 0.25, 0.15, 13.0)
+F_FAST_BOUNDS = {
+    "demo_864x736": (37.5, 0.14, 0.50, 14.5),      # measured 39.0 dB, 0.11, 0.41 px, 12.6 px
+    "2k_ds050": (38.3, 0.25, 0.26, 9.6),           # 39.8 dB, 0.20, 0.21 px, 8.3 px
+    "demo2k_ds050": (31.0, 0.36, 0.50, 14.4),      # 32.3-32.5 dB, 0.31, 0.42 px, 12.5 px
+    "4k_ds025": (33.4, 0.52, 0.27, 9.9),           # 34.6-35.0 dB, 0.45, 0.22 px, 8.6 px
+    "demo2k_ds050_fh015": (48.0, 0.06, 0.04, 0.12),    # 52.1 dB, 0.037, 0.028 px, 0.088 px   (flows <= 9.2 px)
+    "4k_ds025_fh015": (50.0, 0.01, 0.03, 0.09),        # 53.9 dB, 0.0016, 0.018 px, 0.060 px  (flows <= 6.8 px)
+}
+
+
+def _model_f(sd_, mode):
+    from gimmvfi_hip.model import GIMMVFI_F
+
+    m = GIMMVFI_F(precision="fp32" if mode == "fp32" else "bf16", flow_precision="bf16" if mode == "bf16-fast" else None)
+    if mode == "bf16":
+        assert m.flow_precision == "dec"          # the model's default policy
+    m.load_state_dict(sd_, strict=True)
+    return m.to(DEV).eval()
+
+
+def _sd_for(meta, sd_f):
+    sc = meta.get("flow_head_scale", 1.0)
+    if sc == 1.0:
+        return sd_f
+    from gimmvfi_hip.params import random_state_dict_f
+
+    return random_state_dict_f(0, flow_head_scale=sc)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-fast"])
 @pytest.mark.parametrize("name", ["demo_864x736", "2k_ds050", "demo2k_ds050", "4k_ds025"])
-def test_hires_f_matches_reference_fixture(sd_f, name, prec):
+def test_hires_f_matches_reference_fixture(sd_f, name, mode):
     """GIMM-VFI-F (FlowFormer flow estimator, BASELINE.json configs[3]/[4]) on the same hi-res cases, against fixtures of
     the reference's GIMMVFI_F (oracle/make_golden_hires.py --model f; Twins from the reference's vendored class, see
-    README 'timm')."""
+    README 'timm'): float mode, bf16 with the default precision policy of the flow estimator, and the all-bf16 fast mode."""
     meta, z = load_hr(name, "f")
     x = hr_inputs(meta, z)
-    m = _model(sd_f, prec, "f")
+    m = _model_f(sd_f, mode)
     out = run_hr(m, meta, x)
-    check_hr(out, meta, z, prec, "F " + name, "f")
+    check_hr(out, meta, z, "fp32" if mode == "fp32" else "bf16", f"F {name} [{mode}]", "f",
+             bounds=F_DEFAULT_BOUNDS if mode == "bf16" else F_FAST_BOUNDS[name])
     del out, m
     torch.cuda.empty_cache()
 
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-fast"])
+@pytest.mark.parametrize("name", ["demo2k_ds050_fh015", "4k_ds025_fh015"])
+def test_hires_f_small_flows_separate_conditioning_from_arithmetic(sd_f, name, mode):
+    """The same reference model with the decoder's flow head damped by 0.15 (params.random_state_dict_f(0,
+    flow_head_scale=0.15); fixtures from the reference run with those weights): flows of <= 9 px instead of 40-50 px of
+    folds.  Here the ALL-bf16 path is 52-54 dB from the reference with a p99.9 flow error below 0.1 px -- the 32-40 dB of
+    the large-flow fixtures are the conditioning of the un-trained recurrence, not an arithmetic fault of the bf16 path."""
+    meta, z = load_hr(name, "f")
+    assert meta["flow_head_scale"] == 0.15 and meta["flow_absmax"] < 10.0
+    x = hr_inputs(meta, z)
+    m = _model_f(_sd_for(meta, sd_f), mode)
+    out = run_hr(m, meta, x)
+    check_hr(out, meta, z, "fp32" if mode == "fp32" else "bf16", f"F {name} [{mode}]", "f",
+             bounds=(52.0, 0.01, 0.02, 0.09) if mode == "bf16" else F_FAST_BOUNDS[name])
+    del out, m
+    torch.cuda.empty_cache()

@@ -207,3 +207,31 @@ def test_flow_to_image_matches_the_cli_colour_coding(rt):
     if rt.precision != "fp32":
         pytest.skip("type-independent kernel: once is enough")
     kc.flow_to_image_case(rt)
+
+
+F16_CONVS = [
+    # IEEE-half operands (GVFI_F16: the decoder of GIMM-VFI-F's flow estimator): LDS-DMA 4-wave tiles, weights-direct
+    # variant (both column tiles, every tail case of its ring), generic kernel, two sources, float output, residual
+    (1, 9, 12, 64, 130, 3, 3, dict(act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
+    (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
+    (1, 9, 11, 128, 24, 3, 3, dict(out_f32=True)),
+    (1, 9, 12, 64, 40, 3, 3, dict(act1=L.ACT_LRELU)),
+    (1, 8, 10, 128, 130, 1, 5, dict(algo=6, split=64, act1=L.ACT_RELU)),
+    (1, 6, 20, 128, 96, 1, 1, dict(algo=6, act1=L.ACT_GELU)),
+    (1, 7, 9, 64, 200, 1, 5, dict(algo=6, tile=256, act1=L.ACT_RELU)),
+    (1, 7, 9, 64, 160, 3, 3, dict(algo=6, tile=256, with_res=True)),
+    (1, 6, 10, 40, 130, 1, 5, dict(act1=L.ACT_TANH)),                 # generic kernel (40 channels)
+    (1, 1, 200, 24, 40, 1, 1, dict(act1=L.ACT_GELU, with_res=True, out_f32=True)),
+]
+
+
+def test_fp16_convolutions_and_gru():
+    rt16 = SimRuntime("fp16", emulate_conv=True)
+    for *a, kw in F16_CONVS:
+        kc.conv_case(rt16, *a, **kw)
+    kc.gru_case(rt16, kh=1, kw=5)                                                            # generic kernel
+    kc.gru_case(rt16, N=1, H=5, W=7, C=64, kh=1, kw=5, seed=2)                                # LDS-DMA kernel, slim GRU loops
+    kc.gru_case(rt16, N=1, H=5, W=7, C=64, kh=5, kw=1, seed=3, ctx_split=True, wdir=True)     # weights-direct + context term
+    kc.tap_split_conv_case(rt16)
+    kc.patch_conv_case(rt16)
+    kc.corr_volume_case(rt16)

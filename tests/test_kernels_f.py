@@ -8,14 +8,14 @@ import kernel_cases_f as kf
 from gimmvfi_hip import lib as L
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16"])
+@pytest.fixture(scope="module", params=["fp32", "bf16", "fp16"])
 def rt_sim(request):
     from sim_runtime import SimRuntime
 
     return SimRuntime(request.param, emulate_conv=True)
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16"])
+@pytest.fixture(scope="module", params=["fp32", "bf16", "fp16"])
 def rt_gpu(request):
     from gimmvfi_hip.ops import Runtime
 
