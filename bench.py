@@ -88,8 +88,9 @@ def main():
                     help="r = GIMM-VFI-R (RAFT flow estimator, BASELINE.json configs[1], the default bench line); "
                          "f = GIMM-VFI-F (FlowFormer flow estimator, configs[3])")
     ap.add_argument("--flow-precision", default=None,
-                    help="(--model f) precision policy of the flow estimator: 'dec' (model default: decoder in float, >= 40 dB "
-                         "against the reference everywhere), 'bf16' (fast mode), 'fp32', or a stage list -- GIMMVFI_F.__init__")
+                    help="(--model f) precision policy of the flow estimator: 'dec:f16' (model default: decoder with IEEE-half operands, "
+                         ">= 40 dB against the reference everywhere), 'bf16', 'dec' (float decoder), 'fp32', or a stage list -- "
+                         "GIMMVFI_F.__init__")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default=None, help="write a per-conv-shape time table (markdown) to this path")
     ap.add_argument("--stub", action="store_true",

@@ -112,6 +112,128 @@ extern "C" int gvfi_corr_lookup(const float* l0, const float* l1, const float* l
     return (int)hipGetLastError();
 }
 
+// LDS-staged variant (BASELINE.json north_star: "correlation volume staged through LDS for coalesced HBM reads"; A/B'd
+// against the kernel above in round 3, profiles/r3_lookup_ab.txt).  A workgroup owns LQ queries.  Phase 1: the (2r+4)^2
+// window of every level of every query -- rows of 12 consecutive floats, zero outside the map -- is copied to LDS by
+// consecutive lanes (48-byte row segments; the one-column-per-thread kernel reads every float of the window twice).  Phase
+// 2: the outputs, consecutive lanes = consecutive channels of a query (coalesced 2-byte stores), each with exactly the
+// per-tap float expression of the kernel above, its four taps read from LDS.  Note: a query's window lies in its OWN
+// correlation map (row q of the volume), so there is no reuse across queries for LDS to exploit -- the bytes that cross
+// the fabric are the same 128-byte lines either way; what staging changes is the number of load instructions.
+#define LQ 8
+#define LWIN 12     // staged rows / columns per level: 2r+2 taps + one spare on either side (rounding of the round trip)
+template <typename T>
+__global__ void __launch_bounds__(256) corr_lookup_lds_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
+                                                              const float* __restrict__ l2, const float* __restrict__ l3,
+                                                              const float* __restrict__ coords, T* __restrict__ out, int ldo,
+                                                              long long nq, int h2, int w2, int radius) {
+    __shared__ float win[LQ][4][LWIN][LWIN];
+    __shared__ int org[LQ][4][2];          // map coordinates of the staged window's corner (x, y)
+    const int tid = threadIdx.x;
+    const long long q0 = (long long)blockIdx.x * LQ;
+    const int nwin = 2 * radius + 1;
+    auto level_geom = [&](int l, long long q, int& hl, int& wl, float& qx, float& qy) {
+        hl = h2 >> l;
+        wl = w2 >> l;
+        const float sc = 1.0f / (float)(1 << l);
+        qx = coords[q * 2 + 0] * sc;
+        qy = coords[q * 2 + 1] * sc;
+    };
+    // the window corner: the cell of tap (0, 0) minus the spare row / column
+    auto tap_cell = [&](float c0, int n) {
+        const float xn = 2.f * c0 / (float)(n - 1) - 1.f;
+        const float ix = ((xn + 1.f) * 0.5f) * (float)(n - 1);
+        return floorf(ix);
+    };
+    if (tid < LQ * 4) {
+        const int ql = tid >> 2, l = tid & 3;
+        const long long q = q0 + ql;
+        if (q < nq) {
+            int hl, wl;
+            float qx, qy;
+            level_geom(l, q, hl, wl, qx, qy);
+            // (clamped far outside the map: the whole window is zeros there and int conversion must not overflow)
+            const float fx = fminf(fmaxf(tap_cell(qx - (float)radius, wl), -1.0e6f), 1.0e6f);
+            const float fy = fminf(fmaxf(tap_cell(qy - (float)radius, hl), -1.0e6f), 1.0e6f);
+            org[ql][l][0] = (int)fx - 1;
+            org[ql][l][1] = (int)fy - 1;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < LQ * 4 * LWIN * LWIN; idx += 256) {
+        const int c = idx % LWIN, r = (idx / LWIN) % LWIN, l = (idx / (LWIN * LWIN)) & 3, ql = idx / (4 * LWIN * LWIN);
+        const long long q = q0 + ql;
+        float v = 0.f;
+        if (q < nq) {
+            const int hl = h2 >> l, wl = w2 >> l;
+            const int x = org[ql][l][0] + c, y = org[ql][l][1] + r;
+            if (x >= 0 && x < wl && y >= 0 && y < hl) {
+                const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + q * (long long)hl * wl;
+                v = base[(long long)y * wl + x];
+            }
+        }
+        win[ql][l][r][c] = v;
+    }
+    __syncthreads();
+    const int per_q = 4 * nwin * nwin;
+    for (int o = tid; o < LQ * per_q; o += 256) {
+        const int ql = o / per_q, ch = o - ql * per_q;
+        const long long q = q0 + ql;
+        if (q >= nq) continue;
+        const int l = ch / (nwin * nwin), i = (ch / nwin) % nwin, j = ch % nwin;
+        int hl, wl;
+        float qx, qy;
+        level_geom(l, q, hl, wl, qx, qy);
+        const float cx = qx + (float)(i - radius);
+        const float xn = 2.f * cx / (float)(wl - 1) - 1.f;
+        const float ix = ((xn + 1.f) * 0.5f) * (float)(wl - 1);
+        const float x0f = floorf(ix);
+        const float ax = ix - x0f;
+        const float cy = qy + (float)(j - radius);
+        const float yn = 2.f * cy / (float)(hl - 1) - 1.f;
+        const float iy = ((yn + 1.f) * 0.5f) * (float)(hl - 1);
+        const float y0f = floorf(iy);
+        const float ay = iy - y0f;
+        // cells relative to the staged corner; far outside the map everything is zero
+        const float rxf = x0f - (float)org[ql][l][0], ryf = y0f - (float)org[ql][l][1];
+        float v = 0.f;
+        if (rxf >= 0.f && rxf <= (float)(LWIN - 2) && ryf >= 0.f && ryf <= (float)(LWIN - 2)) {
+            const int rx = (int)rxf, ry = (int)ryf;
+            const int x0 = org[ql][l][0] + rx, y0 = org[ql][l][1] + ry;
+            const bool xin0 = x0 >= 0 && x0 < wl, xin1 = x0 + 1 >= 0 && x0 + 1 < wl;
+            const bool yin0 = y0 >= 0 && y0 < hl, yin1 = y0 + 1 >= 0 && y0 + 1 < hl;
+            const float v00 = win[ql][l][ry][rx], v01 = win[ql][l][ry][rx + 1];
+            const float v10 = win[ql][l][ry + 1][rx], v11 = win[ql][l][ry + 1][rx + 1];
+            // same accumulation order as the per-tap statement of corr_lookup_kernel; absent taps add nothing
+            if (xin0 && yin0) v += (1.f - ax) * (1.f - ay) * v00;
+            if (xin1 && yin0) v += ax * (1.f - ay) * v01;
+            if (xin0 && yin1) v += (1.f - ax) * ay * v10;
+            if (xin1 && yin1) v += ax * ay * v11;
+        } else if (x0f > -2.f && x0f < (float)wl && y0f > -2.f && y0f < (float)hl) {
+            // (a tap whose cell left the staged window through rounding: direct reads, same expression)
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + q * (long long)hl * wl;
+            const bool xin0 = x0 >= 0 && x0 < wl, xin1 = x0 + 1 >= 0 && x0 + 1 < wl;
+            const bool yin0 = y0 >= 0 && y0 < hl, yin1 = y0 + 1 >= 0 && y0 + 1 < hl;
+            if (xin0 && yin0) v += (1.f - ax) * (1.f - ay) * base[(long long)y0 * wl + x0];
+            if (xin1 && yin0) v += ax * (1.f - ay) * base[(long long)y0 * wl + x0 + 1];
+            if (xin0 && yin1) v += (1.f - ax) * ay * base[(long long)(y0 + 1) * wl + x0];
+            if (xin1 && yin1) v += ax * ay * base[(long long)(y0 + 1) * wl + x0 + 1];
+        }
+        Elem<T>::st(out + q * ldo + ch, v);
+    }
+}
+extern "C" int gvfi_corr_lookup_lds(const float* l0, const float* l1, const float* l2, const float* l3,
+                                    const float* coords, void* out, int ldo, int dtype, int N, int h, int w, int h2,
+                                    int w2, int radius, void* stream) {
+    const long long nq = (long long)N * h * w;
+    if ((h2 >> 3) < 2 || (w2 >> 3) < 2 || radius != 4) return -2;
+    const unsigned grid = (unsigned)((nq + LQ - 1) / LQ);
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((corr_lookup_lds_kernel<T>), dim3(grid), dim3(256), (hipStream_t)stream, l0,
+                                            l1, l2, l3, coords, (T*)out, ldo, nq, h2, w2, radius));
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ coords grid   raft/utils/utils.py:83-88
 __global__ void coords_init_kernel(float* __restrict__ coords, long long total, int h, int w) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -264,16 +264,18 @@ class GIMMVFI_F(GIMMVFI_R):
 
     def __init__(self, config=None, precision=None, flow_precision=None):
         """flow_precision (with precision "bf16"): precision policy of the FlowFormer flow estimator only -- a comma list
-        of the stages that run in float (exact-f32 MFMA) while everything else stays bf16: enc (Twins encoders), cost (cost
-        volume + latent cost encoder), tok / upd (flow-token path / GMA update block of the 32-iteration decoder; dec =
-        both), "fp32" = all of them, "bf16" = none.  Default: config.flow_precision, $GIMMVFI_F_FLOW_PRECISION, else
-        "dec": measured against the reference's own outputs (profiles/r3_f_policy.md), the update block is the one stage
-        whose bf16 operand rounding shows in the frames when the flows are large (32-40 dB at 2K / 4K with 40-50 px flows;
-        42.9-51.9 dB with "dec"; >= 52 dB in pure bf16 when the flows stay below 10 px) -- the default meets the 40 dB
-        tolerance everywhere, "bf16" is the fast mode (174 vs 91 frames/s at 448x256, B = 8).  DESIGN.md section 9."""
+        of stage[:type] entries for the stages that leave bf16: enc (Twins encoders), cost (cost volume + latent cost
+        encoder), tok / upd (flow-token path / GMA update block of the 32-iteration decoder; dec = both); type f16 = IEEE
+        half operands (same MFMA rate as bf16, 11 instead of 8 significand bits) or fp32 (exact-f32 MFMA, the default
+        type); "fp32" alone = all stages in float, "bf16" = none.  Default: config.flow_precision,
+        $GIMMVFI_F_FLOW_PRECISION, else "dec:f16".  Measured against the reference's own outputs
+        (profiles/r3_f_policy.md): the update block is the one stage whose bf16 operand rounding shows in the frames when
+        the flows are large -- all-bf16 32.3-39.8 dB at 2K / 4K with 40-50 px flows (>= 52 dB once the flows stay below
+        10 px), "dec:f16" 41.4-50.7 dB at the same speed (177.9 vs 179.7 frames/s at 448x256, B = 8), "dec" (float)
+        42.9-51.9 dB at half the speed (90 frames/s).  DESIGN.md section 9."""
         super().__init__(config, precision)
         cfg_fp = _cfg_get(config, "flow_precision")
-        self.flow_precision = flow_precision or cfg_fp or os.environ.get("GIMMVFI_F_FLOW_PRECISION", "dec")
+        self.flow_precision = flow_precision or cfg_fp or os.environ.get("GIMMVFI_F_FLOW_PRECISION", "dec:f16")
 
     def _make_engine(self, runtime):
         return self._engine_cls(runtime, self.state_dict(), flow_precision=self.flow_precision)

@@ -210,6 +210,7 @@ class Runtime:
         self.on_gpu = self.device.type == "cuda"
         self.n_launch = 0
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
+        self.lookup_lds = os.environ.get("GVFI_LOOKUP_LDS", "0") == "1"   # A/B switch: LDS-staged correlation look-up
         self.use_p3x3 = os.environ.get("GVFI_P3X3", "1") != "0"   # A/B switch: 0 keeps the LDS-DMA kernel on the hot 3x3 layers
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
         self._lanes = {}         # stream id -> extra streams for lanes()
@@ -433,7 +434,8 @@ class Runtime:
 
     def corr_lookup(self, pyr, coords, out, n, h, w, h2, w2, radius=4):
         out = V(out)
-        self._chk(self.lib.corr_lookup(pyr[0].data_ptr(), pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(),
+        fn = self.lib.corr_lookup_lds if (self.lookup_lds and radius == 4) else self.lib.corr_lookup
+        self._chk(fn(pyr[0].data_ptr(), pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(),
                                        coords.data_ptr(), out.ptr, out.ld, self.dtype, n, h, w, h2, w2, radius,
                                        self.stream()), "corr_lookup")
 

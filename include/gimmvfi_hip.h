@@ -169,6 +169,11 @@ int gvfi_avgpool2_f32(const float* src, float* dst, long long maps, int h, int w
 int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3,
                      const float* coords /*[N,h,w,2] (x,y)*/, void* out, int ldo, int dtype,
                      int N, int h, int w, int h2, int w2, int radius, void* stream);
+/* the same look-up with the windows staged through LDS (one workgroup per 8 queries; identical results); which of the two
+ * the engine launches is decided by measurement (GVFI_LOOKUP_LDS, profiles/r3_lookup_ab.txt) */
+int gvfi_corr_lookup_lds(const float* l0, const float* l1, const float* l2, const float* l3,
+                     const float* coords /*[N,h,w,2] (x,y)*/, void* out, int ldo, int dtype,
+                     int N, int h, int w, int h2, int w2, int radius, void* stream);
 
 /* patch matrix of a stride-1 zero-padded KHxKW convolution over c (tiny) channels: out[n,oy,ox, (kh*KW+kw)*c + ch],
  * zero-filled up to ldo (a whole K chunk); turns raft/update.py:100,107 (convf1, 2 -> 128, 7x7) and

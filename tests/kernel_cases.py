@@ -373,6 +373,24 @@ def corr_lookup_case(rt, B=2, h=16, w=24):
     rt.corr_lookup(dp, coords.permute(0, 2, 3, 1).contiguous().to(dev), View(out, 8, 324), B, h, w, h, w)
     o = out.float().cpu().permute(0, 3, 1, 2)[:, 8:8 + 324]
     assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max())) + 1e-4
+    # the LDS-staged variant (gvfi_corr_lookup_lds): bit-identical outputs, also for coordinates exactly on cell borders
+    # and windows partly / fully outside the map
+    cd = coords.permute(0, 2, 3, 1).contiguous()
+    cd[1, 2, 3] = torch.tensor([5.0, 7.0])
+    cd[1, 3, 4] = torch.tensor([-3.0, h + 2.5])
+    cd[1, 4, 5] = torch.tensor([1.0e9, -1.0e9])
+    cd = cd.to(dev)
+    a_ = rt.act(B, h, w, 324 + 8, zero=True)
+    b_ = rt.act(B, h, w, 324 + 8, zero=True)
+    keep = rt.lookup_lds
+    try:
+        rt.lookup_lds = False
+        rt.corr_lookup(dp, cd, View(a_, 8, 324), B, h, w, h, w)
+        rt.lookup_lds = True
+        rt.corr_lookup(dp, cd, View(b_, 8, 324), B, h, w, h, w)
+    finally:
+        rt.lookup_lds = keep
+    assert torch.equal(a_.cpu(), b_.cpu())
 
 
 def convex_upsample_case(rt, N=2, h=6, w=9):

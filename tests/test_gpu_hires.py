@@ -114,18 +114,21 @@ def bench_oracle_f(sd_f):
 
 
 # GIMM-VFI-F at the size its metric is quoted on (BASELINE.json configs[3]); gates per mode: (min PSNR, max mean flow error)
-F448 = {"fp32": (80.0, 2e-3), "bf16": (40.0, 0.25), "bf16+dec": (40.0, 0.25)}
+# measured (round 3): float 77.6 dB / 7e-5 px (31 px flows of an un-trained recurrence: a 1e-4 px difference already flips
+# fold-overs); all-bf16 45.3-47.6 dB / 0.16-0.25 px over the 8 samples; decoder in float 58.5 dB / 0.067 px
+F448 = {"fp32": (70.0, 2e-3), "bf16-fast": (40.0, 0.30), "bf16": (50.0, 0.12), "bf16+dec": (50.0, 0.12)}
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16+dec"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-fast", "bf16+dec"])
 def test_448x256_f_b1_vs_live_oracle(sd_f, bench_oracle_f, mode):
     """GIMM-VFI-F 448x256, one pair, against the CPU oracle of the FlowFormer model (bit-exact with the reference,
-    tests/test_oracle_pin.py) run live: float mode, bf16 mode, and bf16 with the decoder of the flow estimator in float
-    (flow_precision="dec")."""
+    tests/test_oracle_pin.py) run live: float mode, bf16 with the default precision policy of the flow estimator (decoder
+    on IEEE-half operands), the all-bf16 fast mode, and bf16 with the decoder in float."""
     from gimmvfi_hip.model import GIMMVFI_F
 
     x, refs = bench_oracle_f
-    m = GIMMVFI_F(precision="fp32" if mode == "fp32" else "bf16", flow_precision="dec" if mode.endswith("dec") else "bf16")
+    m = GIMMVFI_F(precision="fp32" if mode == "fp32" else "bf16",
+                  flow_precision={"bf16+dec": "dec", "bf16-fast": "bf16"}.get(mode))     # None = the default policy (dec:f16)
     m.load_state_dict(sd_f, strict=True)
     m = m.to(DEV).eval()
     c = [(m.sample_coord_input(1, (256, 448), [0.5], device=DEV), None)]
@@ -145,7 +148,8 @@ def test_448x256_f_b8_bench_batch_bf16_all_samples_vs_live_oracle(sd_f, bench_or
     for _ in range(2):
         out = m(x.to(DEV), c, t=t)
     torch.cuda.synchronize()
-    _check_batch(out, refs, "F 448x256 B=8 bf16", *F448["bf16"])
+    assert m.flow_precision == "dec:f16"
+    _check_batch(out, refs, "F 448x256 B=8 bf16 (dec:f16)", *F448["bf16"])
 
 
 # ------------------------------------------------------------------------------------------------ (b) reference fixtures
@@ -285,7 +289,7 @@ def test_hires_matches_reference_fixture(sd, name, prec):
     torch.cuda.empty_cache()
 
 
-# GIMM-VFI-F in bf16 against the reference fixtures.  Default policy (flow_precision = "dec"): the 40 dB tolerance of
+# GIMM-VFI-F in bf16 against the reference fixtures.  Default policy (flow_precision = "dec:f16"): the 40 dB tolerance of
 # every other bf16 test.  Fast mode (flow_precision = "bf16"): per-case pins = measured value + margin (three calls of
 # round 3 agree within 0.3 dB): it reaches 40 dB only while the flows are small (the *_fh015 fixtures below).
 F_DEFAULT_BOUNDS = (40.0, 0.25, 0.15, 13.0)
@@ -304,7 +308,7 @@ def _model_f(sd_, mode):
 
     m = GIMMVFI_F(precision="fp32" if mode == "fp32" else "bf16", flow_precision="bf16" if mode == "bf16-fast" else None)
     if mode == "bf16":
-        assert m.flow_precision == "dec"          # the model's default policy
+        assert m.flow_precision == "dec:f16"      # the model's default policy
     m.load_state_dict(sd_, strict=True)
     return m.to(DEV).eval()
 
@@ -347,6 +351,6 @@ def test_hires_f_small_flows_separate_conditioning_from_arithmetic(sd_f, name, m
     m = _model_f(_sd_for(meta, sd_f), mode)
     out = run_hr(m, meta, x)
     check_hr(out, meta, z, "fp32" if mode == "fp32" else "bf16", f"F {name} [{mode}]", "f",
-             bounds=(52.0, 0.01, 0.02, 0.09) if mode == "bf16" else F_FAST_BOUNDS[name])
+             bounds=(50.0, 0.01, 0.03, 0.10) if mode == "bf16" else F_FAST_BOUNDS[name])
     del out, m
     torch.cuda.empty_cache()
