@@ -102,10 +102,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 
     const int tid = threadIdx.x;
     // profiling only (algo bit 8+7): wave 0 of every workgroup stamps s_memtime at the phase boundaries into
-    // aux1[bid*8 + k] (k: 0 start, 1 prologue done, 2 first chunk landed, 3 K loop done, 4 staged, 5 stores issued)
+    // aux1[bid*16 + k] (k: 0 start, 7 rows decoded, 8 offsets + accumulators ready, 9 ring prologue issued, 1 prologue done,
+    // 2 first chunk landed, 3 K loop done, 4 staged, 5 stores issued, 6 stores acknowledged)
     auto stamp = [&](int k) {
 #ifndef GVFI_HOSTSIM
-        if ((a.dbg & 128) && tid == 0) ((unsigned long long*)p.aux1)[(long long)bid * 8 + k] = __builtin_readcyclecounter();
+        if ((a.dbg & 128) && tid == 0) ((unsigned long long*)p.aux1)[(long long)bid * 16 + k] = __builtin_readcyclecounter();
 #endif
     };
     stamp(0);
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
 
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
+    stamp(8);
 
     int kh = 0, kw = 0, ck = 0, tap = 0;   // wave-uniform K walker of the NEXT chunk to stage
     // The three buffer descriptors are constant for the kernel (source 0 / source 1 at the tile's reference pixel, the
@@ -322,6 +324,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         }
     }
     }
+    stamp(9);
     if (GC_EARLY) load_gc();   // behind the first chunk's DMA, in its shadow
     // MFMAs of chunk kt; when DMA is true the pieces of chunk kt+AHEAD are issued behind the MFMA groups (every wave
     // of the workgroup is at the same point after the barrier; a burst of issues would idle the matrix pipe)
@@ -945,8 +948,8 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
         // (slices of 64; tile_hint 256), register / LDS ring of 4 chunks
         if (kb != 128 || p.dtype == GVFI_F32 || groups != 1) return -5;
         plan[0] = 6;
-        plan[1] = 64;
         plan[2] = (p.tile_hint & 1023) == 256 ? 256 : 128;
+        plan[1] = (((p.tile_hint >> 10) & 1023) == 128 && plan[2] == 128) ? 128 : 64;     // 128-row tiles on request
         plan[3] = 128;
         plan[4] = 4;
         return 0;
@@ -996,9 +999,11 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (plan[0] == 6) {
         if (p.dtype == GVFI_F16) {
             if (plan[2] == 256) return launch_glds<f16_t, 64, 256, 1, 4, 128, 4, false, 1, true>(p, st);
+            if (plan[1] == 128) return launch_glds<f16_t, 128, 128, 1, 4, 128, 4, false, 1, true>(p, st);
             return launch_glds<f16_t, 64, 128, 1, 4, 128, 4, false, 1, true>(p, st);
         }
         if (plan[2] == 256) return launch_glds<bf16_t, 64, 256, 1, 4, 128, 4, false, 1, true>(p, st);
+        if (plan[1] == 128) return launch_glds<bf16_t, 128, 128, 1, 4, 128, 4, false, 1, true>(p, st);
         return launch_glds<bf16_t, 64, 128, 1, 4, 128, 4, false, 1, true>(p, st);
     }
     const int bm = plan[1], tile = plan[2], k = plan[3], ns = plan[4];

@@ -61,6 +61,8 @@ CONV_SHAPES = [
     (1, 7, 9, 128, 64, 3, 1, dict(algo=6, bf16_only=True)),                                            # KT = 6
     (1, 7, 9, 64, 32, 7, 1, dict(algo=6, bf16_only=True)),                                             # KT = 7
     (1, 7, 9, 64, 160, 3, 3, dict(algo=6, tile=256, with_res=True, bf16_only=True)),                   # KT = 9
+    (2, 9, 12, 64, 130, 3, 3, dict(algo=6, tile=128 | (128 << 10), act1=L.ACT_RELU, with_res=True, bf16_only=True)),   # 128-row tiles, ragged
+    (1, 8, 20, 128, 64, 1, 5, dict(algo=6, tile=128 | (128 << 10), split=64, out_f32=True, bf16_only=True)),
     (1, 9, 12, 96, 40, 3, 3, dict(act1=L.ACT_LRELU)),
     (1, 18, 20, 32, 32, 3, 3, dict(tile=32 | (256 << 10), act1=L.ACT_LRELU, with_res=True)),
     (1, 18, 20, 64, 24, 3, 3, dict(tile=32 | (256 << 10), out_f32=True)),

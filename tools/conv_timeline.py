@@ -31,7 +31,7 @@ def main():
         stamps.zero_()
         rt.conv(lay, View(x, 0, Cin), out, act1=L.ACT_RELU, algo=2 + 256 * 128, tile=tile, aux1=stamps)
         torch.cuda.synchronize()
-        s = stamps.cpu().view(-1, 8)
+        s = stamps.cpu().view(-1, 16)
         used = s[:, 0] != 0
         s = s[used].double()
         t0 = s[:, 0].min()

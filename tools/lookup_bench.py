@@ -42,7 +42,7 @@ def main():
                 us = e0.elapsed_time(e1) / 50 * 1e3
                 outs[lds] = out.clone()
                 alg = n * P * (4 * 100 * 4 + 324 * 2) / 1e6
-                line += f"{'lds   ' if lds else 'global'} {us:6.1f} us ({alg / us * 1e-3:5.2f} TB/s of {alg:.0f} MB algorithmic) | "
+                line += f"{'lds   ' if lds else 'global'} {us:6.1f} us ({alg / us:5.2f} TB/s of {alg:.0f} MB algorithmic) | "
             print(line + ("identical" if torch.equal(outs[False], outs[True]) else "DIFFERENT"), flush=True)
 
 

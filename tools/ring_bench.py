@@ -33,10 +33,10 @@ SHAPES = [
 def variants(cout):
     """(bm, bn, ring depth); depth 0 = the weights-direct variant (w_layout 2, register ring of 4)"""
     if cout > 64:
-        return [(64, 128, 2), (64, 128, 3), (128, 128, 2), (64, 128, 0), (64, 256, 0)]
+        return [(64, 128, 2), (64, 128, 0), (128, 128, 0)]
     if cout > 32:
-        return [(128, 64, 2), (128, 64, 3), (64, 128, 0)]
-    return [(128, 32, 2), (128, 32, 3), (64, 128, 0)]
+        return [(128, 64, 2), (64, 128, 0), (128, 128, 0)]
+    return [(128, 32, 2), (64, 128, 0)]
 
 
 def main():
@@ -83,11 +83,11 @@ def main():
                 st = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
                 rt.conv(lay, x0, out, x1=x1, act1=L.ACT_RELU, algo=algo + 256 * 128, tile=tile, aux1=st)
                 torch.cuda.synchronize()
-                s = st.cpu().view(-1, 8)
+                s = st.cpu().view(-1, 16)
                 s = s[s[:, 0] != 0].double()
                 us_ = (s - s[:, 0].min()) / 100.0
                 kt = KH * KW * (Cin // 64)
-                cells[-1] += (f" [wg {s.shape[0]}: decode {float((us_[:, 7] - us_[:, 0]).mean()):.2f}, prologue {float((us_[:, 1] - us_[:, 0]).mean()):.2f}, chunk0 +{float((us_[:, 2] - us_[:, 1]).mean()):.2f}, "
+                cells[-1] += (f" [wg {s.shape[0]}: decode {float((us_[:, 7] - us_[:, 0]).mean()):.2f}, offs {float((us_[:, 8] - us_[:, 7]).mean()):.2f}, issue {float((us_[:, 9] - us_[:, 8]).mean()):.2f}, gc {float((us_[:, 1] - us_[:, 9]).mean()):.2f}, prologue {float((us_[:, 1] - us_[:, 0]).mean()):.2f}, chunk0 +{float((us_[:, 2] - us_[:, 1]).mean()):.2f}, "
                               f"K loop {float((us_[:, 3] - us_[:, 2]).mean()):.2f} = {float((us_[:, 3] - us_[:, 2]).mean()) / kt:.3f}/step x {kt}, "
                               f"epilogue {float((us_[:, 5] - us_[:, 3]).mean()):.2f}, span {float(us_[:, 5].max()):.1f} us]")
         print(f"{name:34s} " + " | ".join(cells), flush=True)
