@@ -146,6 +146,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         pix_ref = (n * p.H + oy * p.stride - p.pad_h) * p.W + ox * p.stride - p.pad_w;
     }
     unsigned a_off0[A_INSTR], a_off1[A_INSTR], a_mask[A_INSTR];
+    unsigned rowsum = 0u;      // wave-uniform: bit t*KW set for every filter row t
+    for (int th = 0; th < p.KH; ++th) rowsum |= 1u << (th * p.KW);
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const int row = (i * NW + wave) * RPI + lrow;
@@ -158,12 +160,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         const int koff = (lslot ^ swz(row)) * VE;
         a_off0[i] = (unsigned)(dpix * p.ld0 + koff) * esz;
         a_off1[i] = (unsigned)(dpix * p.ld1 + koff) * esz;
-        // bit t of the mask = filter tap t reads inside the image for this output pixel (separable: KH + KW tests)
-        unsigned xbits = 0, mask = 0;
-        for (int tw = 0; tw < p.KW; ++tw)
-            if ((unsigned)(ix0 + tw) < (unsigned)p.W) xbits |= 1u << tw;
-        for (int th = 0; th < p.KH; ++th)
-            if ((unsigned)(iy0 + th) < (unsigned)p.H) mask |= xbits << (th * p.KW);
+        // bit t of the mask = filter tap t reads inside the image for this output pixel.  Closed form (the prologue is
+        // instruction-count bound: ~6 cycles per instruction for a wave alone on its SIMD, tools/microbench/icache.hip):
+        // the valid taps of a row are a contiguous range [lo, hi) in x and in y, so
+        //   xbits = 2^hi_x - 2^lo_x,   mask = xbits * (rowsum & (2^(hi_y KW) - 2^(lo_y KW))),   rowsum = sum_t 2^(t KW)
+        // (xbits < 2^KW: the product has no carries between rows; KH*KW <= 32 is checked on the host)
+        const int lox = ix0 < 0 ? -ix0 : 0, hix = p.W - ix0 < p.KW ? p.W - ix0 : p.KW;
+        const int loy = iy0 < 0 ? -iy0 : 0, hiy = p.H - iy0 < p.KH ? p.H - iy0 : p.KH;
+        unsigned mask = 0u;
+        if (lox < hix && loy < hiy) {
+            const unsigned xbits = (unsigned)((1ull << hix) - (1ull << lox));
+            const unsigned yr = (unsigned)((1ull << (hiy * p.KW)) - (1ull << (loy * p.KW)));
+            mask = xbits * (rowsum & yr);
+        }
         a_mask[i] = ok ? mask : 0u;
     }
     stamp(7);   // (profiling) per-row decode + tap masks done
@@ -368,6 +377,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     stamp(1);
     int kt = (a.dbg & 16) ? a.KT : 0;   // profiling only: skip the K loop
     if constexpr (BDIR) {
+        stamp(2);      // (the first chunk's landing is part of the first K step in this variant's timeline)
         constexpr int OPS = A_INSTR + NBL;             // vector-memory operations per chunk and wave
         static_assert((AHEAD - 1) * OPS <= 63, "vmcnt range");
         // Unrolled by the ring depth: the register slot of a chunk is a compile-time index (U = c % NSTAGE), and so is
@@ -380,18 +390,21 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             constexpr int YOUNGER = decltype(younger_tag)::value;
             glds_wait_n<YOUNGER * OPS>();     // chunk c (A pieces of this wave + its weight fragments) has landed
             __syncthreads();      // every wave's A pieces of chunk c visible; every wave is done with chunk c-1's slot
-            if (c == 0) stamp(2);
+            // the first fragment reads go out BEFORE the scalar work of the next issue: their LDS round trip (~150
+            // cycles, once per chunk, otherwise exposed in front of the first MFMA) runs under it
+            const unsigned char* sa = smem + U * STAGE;
+            uint4 fa[2][MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[0][i] = *(const uint4*)(sa + a_rd[0] + i * 32 * RB);
+            GVFI_SCHED_BARRIER();
             if constexpr (ISSUE) {
                 stage_begin(c + AHEAD);
+                st_sa = smem_lds + ((U + AHEAD) % NSTAGE) * STAGE;     // (compile-time slot: no run-time modulo)
 #pragma unroll
                 for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc);
                 load_b(c + AHEAD, (U + AHEAD) % NSTAGE);
             }
             GVFI_SCHED_BARRIER();
-            const unsigned char* sa = smem + U * STAGE;
-            uint4 fa[2][MI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) fa[0][i] = *(const uint4*)(sa + a_rd[0] + i * 32 * RB);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 if (kk + 1 < KK) {
