@@ -22,6 +22,14 @@
 #include "conv_mma.h"
 #include <type_traits>
 
+// Measured and not kept (round 3, profiles/r3_occupancy_ab.txt): budgeting the 64 x 128 weights-direct tile for three
+// workgroups per CU (amdgpu_waves_per_eu(3,3): 167 registers, bias / slopes fetched after the K loop, 36 spilled registers
+// in the tail sequences) so that the other launch sequence's next kernel could start under this one's K loop: 328.5 against
+// 332.8 frames/s (R) and 172.8 against 178.3 (F).  -DGVFI_WDIR_OCC3=1 rebuilds that variant.
+#ifndef GVFI_WDIR_OCC3
+#define GVFI_WDIR_OCC3 0
+#endif
+
 struct ConvArgs2 {
     gvfi_conv_params p;
     int chunks0;     // K chunks per tap that come from source 0  (c0 / BKE)
@@ -53,7 +61,15 @@ struct ConvArgs2 {
 // s_waitcnt); the counted waits of the A pieces include them (every wave issues A_INSTR + NI*KK operations per chunk, in
 // that order, fenced by the asm statements around them).
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE, int PPS = 1, bool BDIR = false>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel(ConvArgs2 a) {
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
+#ifndef GVFI_HOSTSIM
+    // the 64 x 128 weights-direct tile is budgeted for three workgroups per CU (<= 168 registers per wave): the recurrence
+    // runs two independent launch sequences, and a free slot lets the other sequence's next kernel start its prologue
+    // under this one's K loop
+    __attribute__((amdgpu_waves_per_eu((GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 1,
+                                       (GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 8)))
+#endif
+    conv_igemm_glds_kernel(ConvArgs2 a) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int VE = Elem<T>::VE;
     constexpr int RB = KB;                         // LDS row bytes = one K chunk of one tile row
@@ -260,7 +276,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     constexpr int NT = 64 * NW;
     constexpr int GROUPS_PER_ROW = BN / 8;
     static_assert(NT % GROUPS_PER_ROW == 0, "group index must be loop invariant");
-    constexpr bool GC_EARLY = NW <= 4;
+    // (GVFI_WDIR_OCC3 variant of the weights-direct tile: fetched after the K loop -- 24 registers less across it; the
+    // loads are issued ahead of the accumulator staging and awaited behind its barrier)
+    constexpr bool GC_LATE_WDIR = BDIR && GVFI_WDIR_OCC3;
+    constexpr bool GC_EARLY = NW <= 4 && !GC_LATE_WDIR;
     const int my_cg = tid % GROUPS_PER_ROW;
     const int my_cout0 = n0 + my_cg * 8;
     const int my_valid = (p.Cout - my_cout0) >= 8 ? 8 : (p.Cout - my_cout0 > 0 ? p.Cout - my_cout0 : 0);
@@ -557,8 +576,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
     // launches spent more in the epilogue than in the contraction
     const bool gelu1 = p.act1 == GVFI_ACT_GELU;
     if (!GC_EARLY && !direct16) load_gc();
+    auto gc_wait = [&]() {
 #ifndef GVFI_HOSTSIM
-    if (GC_EARLY || !direct16)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(gc.bias[e]), "v"(gc.s1[e]), "v"(gc.s2[e]));
+#endif
+    };
+#ifndef GVFI_HOSTSIM
+    if (!GC_LATE_WDIR && (GC_EARLY || !direct16))
     // Make the compiler wait for the bias / slope loads HERE.  Their first real use is inside the store loop; the
     // s_waitcnt vmcnt(0) it would put there also waits, in every iteration, for the previous iteration's global
     // store to be acknowledged (stores share the counter): ~1500 cycles x 8-16 iterations per tile, 15 % of the
@@ -637,6 +662,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
         }
         __syncthreads();
         if (ps == 0) stamp(4);
+        if (GC_LATE_WDIR && ps == 0) gc_wait();     // (see GC_EARLY)
         if (fast) {
             // ---- slim store loop of the common case (bf16 in/out, bias, none/ReLU/LeakyReLU/PReLU, optional bf16
             // residual + second activation, scale): ~40 VALU instructions per 8 channels instead of the ~150 of the
@@ -762,7 +788,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_igemm_glds_kernel
             // pass with bf16 state, two iterations with float state (twice the registers per row)
             auto gru_rows = [&](auto sf_tag) {
                 constexpr bool SF = decltype(sf_tag)::value;
-                constexpr int PF = SF ? (ITERS < 2 ? ITERS : 2) : ITERS;
+                constexpr int PF = (SF || GC_LATE_WDIR) ? (ITERS < 2 ? ITERS : 2) : ITERS;
                 static_assert(ITERS % PF == 0, "prefetch groups");
 #pragma unroll
                 for (int c = 0; c < ITERS / PF; ++c) {

@@ -108,7 +108,8 @@ def get() -> HipLib:
     """The product library.  Fails loudly without the gfx950 build or without a GPU."""
     global _LIB
     if _LIB is None:
-        lib = HipLib(LIB_PATH)
+        # (GVFI_LIB_PATH: another BUILD of the same library, for A/B measurements of compile-time variants)
+        lib = HipLib(os.environ.get("GVFI_LIB_PATH", LIB_PATH))
         if lib.device_ok() != 1:
             raise RuntimeError("libgimmvfi_hip.so loaded but no usable gfx950 (MI355X) device is visible")
         _LIB = lib
