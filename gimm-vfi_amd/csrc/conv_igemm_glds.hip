@@ -591,7 +591,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
 #pragma unroll
     for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(gc.bias[e]), "v"(gc.s1[e]), "v"(gc.s2[e]));
 #endif
-    const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && my_valid == 8 && !p.y_f32 &&
+    // (a ragged last channel group with an even number of channels -- RAFT's 126-channel motion features -- takes the slim
+    // loop too, with dword stores: on the generic loop its lanes kept every wave of the tile in a 3x longer epilogue,
+    // 14.7 k instead of 4.8 k cycles per workgroup.  Its 16-byte residual read stays inside the row pitch.)
+    const bool ragged_ok = my_valid >= 2 && !(my_valid & 1) && (p.res == nullptr || my_cout0 + 8 <= p.ldr) && p.stats == nullptr;
+    const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && (my_valid == 8 || ragged_ok) && !p.y_f32 &&
                       !(p.res && p.res_f32) && (p.act1 <= GVFI_ACT_PRELU || p.act1 == GVFI_ACT_GELU) && p.act2 <= GVFI_ACT_PRELU;
     // (the 8-wave tile is never used for the GRU convolutions and has no registers for their operands)
     const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8 &&
@@ -732,7 +736,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
                     u.y = pack16x2<T>(vv[2], vv[3]);
                     u.z = pack16x2<T>(vv[4], vv[5]);
                     u.w = pack16x2<T>(vv[6], vv[7]);
-                    *(uint4*)(yp + (long long)tr * p.ldy) = u;
+                    if (my_valid == 8) *(uint4*)(yp + (long long)tr * p.ldy) = u;
+                    else {
+                        uint32_t* yd = (uint32_t*)(yp + (long long)tr * p.ldy);
+                        yd[0] = u.x;
+                        if (my_valid > 2) yd[1] = u.y;
+                        if (my_valid > 4) yd[2] = u.z;
+                    }
                     if constexpr (STATS) {
                         if (do_stats) {   // statistics of the values as stored (bf16-rounded), like gvfi_instnorm_stats
                             float sv[8];

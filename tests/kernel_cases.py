@@ -34,7 +34,10 @@ def tol(rt, scale):
 
 
 def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.ACT_NONE, with_res=False,
-              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0, pad=None, pad16=False):
+              act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0, pad=None, pad16=False,
+              coff=2):
+    """coff: channel offset of the output slice inside a wider tensor (2 = unaligned: vector store paths fall back;
+    0 or 8 = 16-byte aligned rows: the slim store loops run; channels outside the slice must stay untouched)."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
@@ -81,9 +84,15 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
         assert float((got[..., cpad:] - 7.0).abs().max()) == 0.0
         out = torch.cat([torch.zeros(N, Ho, Wo, 2), got[..., :Cout], torch.zeros(N, Ho, Wo, 1)], -1)
     else:
-        out = (rt.f32(N, Ho, Wo, Cout + 3, zero=True) if out_f32 else rt.act(N, Ho, Wo, Cout + 3, zero=True))
-        rt.conv(lay, x0, View(out, 2, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
+        wide = Cout + coff + (1 if coff == 2 else 8 + (-Cout) % 8)
+        out = (rt.f32(N, Ho, Wo, wide, zero=True) if out_f32 else rt.act(N, Ho, Wo, wide, zero=True, pitch=wide))
+        out.fill_(3.0)
+        rt.conv(lay, x0, View(out, coff, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
                 slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile, algo=algo)
+        got = out.float().cpu()
+        assert float((got[..., :coff] - 3.0).abs().max()) == 0.0 if coff else True
+        assert float((got[..., coff + Cout:] - 3.0).abs().max()) == 0.0        # nothing beyond the slice is written
+        out = torch.cat([torch.zeros(N, Ho, Wo, 2), got[..., coff:coff + Cout], torch.zeros(N, Ho, Wo, 1)], -1)
     xi = F.pad(x, (pw, pw, ph, ph), mode="reflect") if reflect else x
     ref = F.conv2d(xi, w, b, stride=stride, padding=0 if reflect else (ph, pw))
 

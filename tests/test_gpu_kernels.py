@@ -50,6 +50,12 @@ CONV_SHAPES = [
     (4, 32, 56, 384, 128, 1, 5, dict(split=128, act1=L.ACT_RELU, tile=128 | (64 << 10) | (3 << 20))),   # 3-deep ring
     (4, 32, 56, 256, 256, 3, 3, dict(act1=L.ACT_RELU, tile=128 | (64 << 10) | (4 << 20))),            # 4-deep ring
     (4, 32, 56, 128, 64, 3, 3, dict(act1=L.ACT_RELU, tile=64 | (4 << 20))),
+    # weights-direct variant on the recurrence shapes; ragged 126-channel output on the slim store loop (aligned slice)
+    (8, 32, 56, 256, 126, 3, 3, dict(algo=6, act1=L.ACT_RELU, coff=8, bf16_only=True)),
+    (8, 32, 56, 256, 126, 3, 3, dict(act1=L.ACT_RELU, with_res=True, act2=L.ACT_LRELU, coff=0, tile=128 | (64 << 10), bf16_only=True)),
+    (8, 32, 56, 256, 256, 1, 5, dict(algo=6, split=128, act1=L.ACT_RELU, coff=0, bf16_only=True)),
+    (8, 32, 56, 384, 256, 1, 1, dict(algo=6, act1=L.ACT_RELU, bf16_only=True)),
+    (1, 1, 14336, 192, 128, 1, 1, dict(algo=6, split=64, act1=L.ACT_GELU, with_res=True, coff=0, bf16_only=True)),
     (1, 40, 56, 96, 96, 3, 3, dict(act1=L.ACT_RELU)),                                         # 64-byte chunks, 4-deep ring (counted vmcnt)
     # halo-staged 3x3 kernel (conv_p3x3.hip)
     (1, 17, 19, 64, 256, 3, 3, dict(algo=4, act1=L.ACT_PRELU, pad16=True, bf16_only=True)),

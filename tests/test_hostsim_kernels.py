@@ -41,6 +41,12 @@ CONV_SHAPES = [
     (1, 9, 40, 64, 70, 3, 3, dict(tile=128 | (64 << 10), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
     (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
     (1, 9, 12, 64, 130, 3, 3, dict(algo=2 + 128, tile=128)),
+    # ragged last channel group with an even count on the slim store loop (dword stores): 126 = 15 x 8 + 6, with residual
+    (1, 9, 12, 64, 126, 3, 3, dict(act1=L.ACT_RELU, coff=0, bf16_only=True)),
+    (1, 9, 12, 64, 126, 3, 3, dict(algo=6, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_LRELU, coff=8, bf16_only=True)),
+    (1, 6, 10, 64, 68, 1, 1, dict(tile=128 | (64 << 10), out_scale=0.5, coff=0, bf16_only=True)),        # 4 valid channels
+    (1, 6, 10, 64, 66, 1, 1, dict(algo=6, act1=L.ACT_GELU, coff=0, bf16_only=True)),                      # 2 valid channels
+    (1, 6, 10, 64, 128, 1, 1, dict(algo=6, act1=L.ACT_RELU, with_res=True, coff=8, bf16_only=True)),      # aligned, full groups
     # deeper rings at 128-byte chunks (tile_hint bits 20..23): 3 / 4 stages in flight, counted vmcnt, KT < / > ring depth
     (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10) | (3 << 20), split=64, act1=L.ACT_RELU)),
     (1, 9, 12, 64, 130, 3, 3, dict(tile=128 | (64 << 10) | (4 << 20), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
