@@ -595,8 +595,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
     // loop too, with dword stores: on the generic loop its lanes kept every wave of the tile in a 3x longer epilogue,
     // 14.7 k instead of 4.8 k cycles per workgroup.  Its 16-byte residual read stays inside the row pitch.)
     const bool ragged_ok = my_valid >= 2 && !(my_valid & 1) && (p.res == nullptr || my_cout0 + 8 <= p.ldr) && p.stats == nullptr;
-    const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && (my_valid == 8 || ragged_ok) && !p.y_f32 &&
-                      !(p.res && p.res_f32) && (p.act1 <= GVFI_ACT_PRELU || p.act1 == GVFI_ACT_GELU) && p.act2 <= GVFI_ACT_PRELU;
+    // (float outputs without a residual -- the decoder head, the flow head's per-tap sums -- take it as well: float4 stores)
+    // and a FLOAT residual (the float residual streams of GIMM-VFI-F's transformer blocks: every attention / MLP output
+    // linear) on the 4-wave tiles, which have the registers for two vectors per row.
+    constexpr bool F32RES = NT <= 256;
+    const bool fast = sizeof(T) == 2 && p.epi_mode == GVFI_EPI_STD && vec_all && (my_valid == 8 || ragged_ok) &&
+                      (p.res == nullptr || !p.res_f32 || F32RES) &&
+                      (p.act1 <= GVFI_ACT_PRELU || p.act1 == GVFI_ACT_GELU) && p.act2 <= GVFI_ACT_PRELU;
     // (the 8-wave tile is never used for the GRU convolutions and has no registers for their operands)
     const bool fast_gru = sizeof(T) == 2 && NT <= 256 && p.epi_mode != GVFI_EPI_STD && vec_all && my_valid == 8 &&
                           (p.res == nullptr || p.res_f32);
@@ -678,6 +683,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
             const long long pix0 = (long long)g * a.Mg + m_tile0;
             bf16_t* yp = (bf16_t*)p.y + pix0 * p.ldy + my_cout0;
             const bf16_t* rp = (const bf16_t*)p.res + pix0 * p.ldr + my_cout0;
+            const float* rpf = (const float*)p.res + pix0 * p.ldr + my_cout0;
+            const bool res32 = F32RES && p.res_f32 != 0;
             const float* cp = cs + row_a * BN + my_cg * 8;
             const bool has_res = p.res != nullptr, has_a2 = p.act2 != GVFI_ACT_NONE, has_sc = p.out_scale != 1.0f;
             const bool do_stats = STATS && p.stats != nullptr;
@@ -687,13 +694,20 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
             static_assert(ITERS % PF == 0, "prefetch chunks");
 #pragma unroll
             for (int c = 0; c < ITERS / PF; ++c) {
-                uint4 rpre[PF];
+                uint4 rpre[PF], rpre2[F32RES ? PF : 1];
                 if (has_res) {
 #pragma unroll
                     for (int q = 0; q < PF; ++q) {
                         const int it = c * PF + q;
                         const int tr = tile_row(ps, row_a + it * ROWS_PER_IT);
-                        if (m_tile0 + tr < a.Mg) rpre[q] = *(const uint4*)(rp + (long long)tr * p.ldr);
+                        if (m_tile0 + tr >= a.Mg) continue;
+                        if (res32) {
+                            if constexpr (F32RES) {
+                                const uint4* r4 = (const uint4*)(rpf + (long long)tr * p.ldr);
+                                rpre[q] = r4[0];
+                                rpre2[q] = r4[1];
+                            }
+                        } else rpre[q] = *(const uint4*)(rp + (long long)tr * p.ldr);
                     }
                 }
 #pragma unroll
@@ -719,7 +733,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
                     }
                     if (has_res) {
                         float r[8];
-                        unpack16x8<T>(rpre[q], r);
+                        if (res32) {
+                            if constexpr (F32RES) {
+                                r[0] = __builtin_bit_cast(float, rpre[q].x); r[1] = __builtin_bit_cast(float, rpre[q].y);
+                                r[2] = __builtin_bit_cast(float, rpre[q].z); r[3] = __builtin_bit_cast(float, rpre[q].w);
+                                r[4] = __builtin_bit_cast(float, rpre2[q].x); r[5] = __builtin_bit_cast(float, rpre2[q].y);
+                                r[6] = __builtin_bit_cast(float, rpre2[q].z); r[7] = __builtin_bit_cast(float, rpre2[q].w);
+                            }
+                        } else unpack16x8<T>(rpre[q], r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) vv[e] += r[e];
                     }
@@ -736,7 +757,17 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
                     u.y = pack16x2<T>(vv[2], vv[3]);
                     u.z = pack16x2<T>(vv[4], vv[5]);
                     u.w = pack16x2<T>(vv[6], vv[7]);
-                    if (my_valid == 8) *(uint4*)(yp + (long long)tr * p.ldy) = u;
+                    if (p.y_f32) {
+                        float* yf = (float*)p.y + (pix0 + tr) * p.ldy + my_cout0;
+                        if (my_valid == 8) {
+                            *(float4*)yf = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                            *(float4*)(yf + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 6; e += 2)
+                                if (e < my_valid) *(float2*)(yf + e) = make_float2(vv[e], vv[e + 1]);
+                        }
+                    } else if (my_valid == 8) *(uint4*)(yp + (long long)tr * p.ldy) = u;
                     else {
                         uint32_t* yd = (uint32_t*)(yp + (long long)tr * p.ldy);
                         yd[0] = u.x;

@@ -35,7 +35,7 @@ def tol(rt, scale):
 
 def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.ACT_NONE, with_res=False,
               act2=L.ACT_NONE, out_f32=False, split=None, seed=0, out_scale=1.0, tile=0, algo=0, pad=None, pad16=False,
-              coff=2):
+              coff=2, res_f32=False):
     """coff: channel offset of the output slice inside a wider tensor (2 = unaligned: vector store paths fall back;
     0 or 8 = 16-byte aligned rows: the slim store loops run; channels outside the slice must stay untouched)."""
     g = torch.Generator().manual_seed(seed)
@@ -63,8 +63,12 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     res = None
     r = None
     if with_res:
-        r = _rounded(rt, torch.randn(N, Cout, Ho, Wo, generator=g))
-        res = _to_act(rt, r).to(dev)
+        r = torch.randn(N, Cout, Ho, Wo, generator=g)
+        if res_f32:      # float residual stream: not rounded
+            res = r.permute(0, 2, 3, 1).contiguous().to(dev)
+        else:
+            r = _rounded(rt, r)
+            res = _to_act(rt, r).to(dev)
     if pad16:
         # the destination is a tensor of its own whose pad channels (up to the next 16-byte unit) belong to this call:
         # they are pre-filled with garbage and must come back as zeros; nothing beyond them may be touched

@@ -55,6 +55,8 @@ CONV_SHAPES = [
     (8, 32, 56, 256, 126, 3, 3, dict(act1=L.ACT_RELU, with_res=True, act2=L.ACT_LRELU, coff=0, tile=128 | (64 << 10), bf16_only=True)),
     (8, 32, 56, 256, 256, 1, 5, dict(algo=6, split=128, act1=L.ACT_RELU, coff=0, bf16_only=True)),
     (8, 32, 56, 384, 256, 1, 1, dict(algo=6, act1=L.ACT_RELU, bf16_only=True)),
+    (2, 64, 112, 256, 24, 3, 3, dict(out_f32=True, coff=0, bf16_only=True)),          # float output on the slim store loop
+    (8, 32, 56, 256, 18, 1, 1, dict(out_f32=True, coff=0, bf16_only=True)),
     (1, 1, 14336, 192, 128, 1, 1, dict(algo=6, split=64, act1=L.ACT_GELU, with_res=True, coff=0, bf16_only=True)),
     (1, 40, 56, 96, 96, 3, 3, dict(act1=L.ACT_RELU)),                                         # 64-byte chunks, 4-deep ring (counted vmcnt)
     # halo-staged 3x3 kernel (conv_p3x3.hip)

@@ -47,6 +47,14 @@ CONV_SHAPES = [
     (1, 6, 10, 64, 68, 1, 1, dict(tile=128 | (64 << 10), out_scale=0.5, coff=0, bf16_only=True)),        # 4 valid channels
     (1, 6, 10, 64, 66, 1, 1, dict(algo=6, act1=L.ACT_GELU, coff=0, bf16_only=True)),                      # 2 valid channels
     (1, 6, 10, 64, 128, 1, 1, dict(algo=6, act1=L.ACT_RELU, with_res=True, coff=8, bf16_only=True)),      # aligned, full groups
+    # float outputs on the slim store loop (decoder head 256->24, per-tap sums of the flow head 256->18)
+    (1, 9, 11, 128, 24, 3, 3, dict(out_f32=True, coff=0, bf16_only=True)),
+    (1, 6, 10, 64, 18, 1, 1, dict(out_f32=True, coff=0, act1=L.ACT_RELU, bf16_only=True)),
+    (1, 6, 10, 128, 130, 1, 1, dict(algo=6, out_f32=True, coff=8, bf16_only=True)),
+    # ... with a float residual (the transformer blocks' residual streams) and a 16-bit residual into a float output
+    (1, 1, 200, 128, 128, 1, 1, dict(out_f32=True, with_res=True, res_f32=True, coff=0, bf16_only=True)),
+    (1, 1, 200, 64, 70, 1, 1, dict(algo=6, act1=L.ACT_GELU, out_f32=True, with_res=True, res_f32=True, coff=8, bf16_only=True)),
+    (1, 1, 200, 64, 64, 1, 1, dict(out_f32=True, with_res=True, coff=0, bf16_only=True)),
     # deeper rings at 128-byte chunks (tile_hint bits 20..23): 3 / 4 stages in flight, counted vmcnt, KT < / > ring depth
     (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10) | (3 << 20), split=64, act1=L.ACT_RELU)),
     (1, 9, 12, 64, 130, 3, 3, dict(tile=128 | (64 << 10) | (4 << 20), act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU)),
