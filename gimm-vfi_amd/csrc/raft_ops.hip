@@ -309,6 +309,122 @@ extern "C" int gvfi_tap_sum(const float* P, int ldp, int C, int KH, int KW, cons
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------ fused iteration seam of the recurrence (round 3)
+// Between two update iterations three small launches ran back to back on every image: gvfi_tap_sum (coords1 += flow-head
+// output of iteration i, raft/update.py:6-14 + raft/raft.py:158-159), gvfi_flow_pack (flow = coords1 - coords0 as an
+// activation, raft/raft.py:150) and gvfi_im2col (the 7x7 patch of that flow for convf1, raft/update.py:100): 19 us of
+// ~200 us per iteration, all latency.  One workgroup per 8x8 pixel tile: the updated coordinates of the tile and its
+// 3-pixel halo are (re)computed from the per-tap partial sums P (9 x 2 floats per pixel; halo pixels redundantly -- same
+// values, the data is L2 resident), the flow tile goes to LDS in the activation type, the centre pixels write coords1 /
+// flow / the flow slot of the GRU input, and the 98 (+ zero padded) patch entries of every pixel are gathered from LDS.
+// Arithmetic and rounding are those of the three kernels in sequence (bit-identical: flow_step_case).
+// P == nullptr: no pending update (first iteration): coords1 is read as it is.  With an update the new coordinates go to a
+// SECOND tensor (coords_out != coords_in): neighbouring workgroups read each other's centre pixels as halo, an in-place
+// update would race with them.
+#define FS_T 8
+#define FS_HALO 3
+#define FS_W (FS_T + 2 * FS_HALO)
+template <typename T>
+__global__ void __launch_bounds__(256) flow_step_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ bias,
+                                                        const float* __restrict__ coords, float* __restrict__ coords_out,
+                                                        T* __restrict__ fl, int ldf, int padf,
+                                                        T* __restrict__ xb, int ldx, T* __restrict__ col, int ldc, int N, int H,
+                                                        int W, int tiles_x, int tiles_y) {
+    constexpr int VE = Elem<T>::VE;
+    __shared__ T flow[FS_W][FS_W][2];
+    __shared__ float cnew[FS_T][FS_T][2];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int x0 = tx * FS_T, y0 = ty * FS_T;
+    const long long img = (long long)n * H * W;
+    // phase 1: updated coordinates (-> flow) of the tile + halo; zero flow outside the image (im2col's zero padding)
+    for (int i = tid; i < FS_W * FS_W * 2; i += 256) {
+        const int c = i & 1, px = (i >> 1) % FS_W, py = (i >> 1) / FS_W;
+        const int x = x0 + px - FS_HALO, y = y0 + py - FS_HALO;
+        float f = 0.f;
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+            const long long pix = img + (long long)y * W + x;
+            float v = coords[pix * 2 + c];
+            if (P != nullptr) {
+                // gvfi_tap_sum: v = bias + sum of the in-image taps (row-major tap order) + res
+                float acc = bias ? bias[c] : 0.f;
+                int tap = 0;
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int yy = y + kh - 1;
+                    for (int kw = 0; kw < 3; ++kw, ++tap) {
+                        const int xx = x + kw - 1;
+                        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                            acc += P[(pix + (long long)(kh - 1) * W + (kw - 1)) * ldp + tap * 2 + c];
+                    }
+                }
+                v = acc + v;
+            }
+            const int cx = px - FS_HALO, cy = py - FS_HALO;
+            if ((unsigned)cx < (unsigned)FS_T && (unsigned)cy < (unsigned)FS_T) cnew[cy][cx][c] = v;
+            f = v - (float)(c == 0 ? x : y);       // gvfi_flow_pack
+        }
+        Elem<T>::st(&flow[py][px][c], f);
+    }
+    __syncthreads();
+    // phase 2: centre pixels -> coords1 (float), flow activation (2 channels + zero pad), flow slot of the GRU input
+    if (tid < FS_T * FS_T) {
+        const int cx = tid % FS_T, cy = tid / FS_T;
+        const int x = x0 + cx, y = y0 + cy;
+        if (x < W && y < H) {
+            const long long pix = img + (long long)y * W + x;
+            if (P != nullptr) {
+                coords_out[pix * 2 + 0] = cnew[cy][cx][0];
+                coords_out[pix * 2 + 1] = cnew[cy][cx][1];
+            }
+            T* d0 = fl + pix * ldf;
+            d0[0] = flow[cy + FS_HALO][cx + FS_HALO][0];
+            d0[1] = flow[cy + FS_HALO][cx + FS_HALO][1];
+            for (int c = 2; c < padf; ++c) Elem<T>::st(d0 + c, 0.f);
+            if (xb != nullptr) {
+                xb[pix * ldx + 0] = d0[0];
+                xb[pix * ldx + 1] = d0[1];
+            }
+        }
+    }
+    // phase 3: 7x7x2 patch of every centre pixel, K order (kh, kw, c), zero padded to ldc: one 16-byte vector per step
+    const int G = ldc / VE;
+    for (int i = tid; i < FS_T * FS_T * G; i += 256) {
+        const int g = i % G, cp = i / G;
+        const int cx = cp % FS_T, cy = cp / FS_T;
+        const int x = x0 + cx, y = y0 + cy;
+        if (x >= W || y >= H) continue;
+        struct alignas(16) V16 { T e[VE]; } o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const int k = g * VE + e;
+            T v;
+            Elem<T>::st(&v, 0.f);
+            if (k < 98) {
+                const int tap = k >> 1, kh = tap / 7, kw = tap - kh * 7;
+                v = flow[cy + kh][cx + kw][k & 1];
+            }
+            o.e[e] = v;
+        }
+        *(V16*)(col + (img + (long long)y * W + x) * ldc + g * VE) = o;
+    }
+}
+extern "C" int gvfi_flow_step(const float* P, int ldp, const float* bias, const float* coords, float* coords_out, void* fl,
+                              int ldf, int padf, void* xb, int ldx, void* col, int ldc, int N, int h, int w, int dtype,
+                              void* stream) {
+    const int ve = dtype == GVFI_F32 ? 4 : 8;
+    if ((ldc % ve) || ldc < 98 || ((uintptr_t)col & 15) || (P != nullptr && ldp < 18) || padf < 2 || padf > ldf) return -2;
+    if (P != nullptr && (coords_out == nullptr || coords_out == coords)) return -3;     // the update is not in place
+    const int tiles_x = (w + FS_T - 1) / FS_T, tiles_y = (h + FS_T - 1) / FS_T;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((flow_step_kernel<T>), dim3((unsigned)(N * tiles_x * tiles_y)), dim3(256),
+                                            (hipStream_t)stream, P, ldp, bias, coords, coords_out, (T*)fl, ldf, padf, (T*)xb, ldx, (T*)col,
+                                            ldc, N, h, w, tiles_x, tiles_y));
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ convex upsampling   raft/raft.py:86-97
 // out[n, 8y+i, 8x+j, c] = sum_k softmax_k(mask[n,y,x, k*64+i*8+j]) * 8*flow[n, y+k/3-1, x+k%3-1, c]
 template <typename T>

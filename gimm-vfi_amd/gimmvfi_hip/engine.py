@@ -322,6 +322,7 @@ class Engine:
             taps["r01_corr_l0"] = pyr_a[0]
             taps["r01_corr_l3"] = pyr_a[3]
         coords = rt.coords_init(n, h8, w8)
+        coords_alt = rt.f32(n, h8, w8, 2)
         corrf = rt.act(n, h8, w8, 324, zero=True, pitch=rt.cp64(324), zero_pad_only=True)
         flow8 = rt.act(n, h8, w8, 2, zero=True)
         c1 = rt.act(n, h8, w8, 256)
@@ -351,15 +352,26 @@ class Engine:
             ha, hb, fc, fp = hA[a:b], hB[a:b], fcol[a:b], fpart[a:b]
             h32 = (h32A[a:b], h32B[a:b]) if sf else (None, None)
             cx = {k: v[a:b] for k, v in ctx.items()}
+            fused = rt.fuse_seam and taps is None
+            co_home, co_alt = co, coords_alt[a:b]     # (the fused seam updates the coordinates out of place: ping-pong)
+            tapl, patl = Ls[u + ".flow_head.conv2"], Ls[u + ".encoder.convf1"]
             for it in range(iters):
+                if fused:
+                    # one launch: coords1 += flow-head output of the previous iteration, flow activation, 7x7 patch of it
+                    co, co_alt = (rt.flow_step(tapl, patl, fp, co, fl, View(xb, 254, 2), fc, coords_out=co_alt), co) if it > 0 else \
+                        (rt.flow_step(tapl, patl, None, co, fl, View(xb, 254, 2), fc), co_alt)
                 rt.corr_lookup(pyr_s, co, cf, m, h8, w8, h8, w8)
-                rt.flow_pack(co, fl, View(xb, 254, 2))
+                if not fused:
+                    rt.flow_pack(co, fl, View(xb, 254, 2))
                 # (measured r2: running the flow branch of the motion encoder as a parallel graph branch is worth
                 # nothing -- the CUs already hold the 2 workgroups their LDS admits -- and forks nested inside lanes()
                 # crash hipStreamEndCapture on ROCm 7.0, so the branches are launched in sequence)
                 rt.conv(Ls[u + ".encoder.convc1"], cf, c1_, act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
-                rt.patch_conv(Ls[u + ".encoder.convf1"], View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
+                if fused:
+                    rt.conv(patl.inner, fc, f1_, act1=A.ACT_RELU)
+                else:
+                    rt.patch_conv(patl, View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.conv"], cfl, View(xb, 128, 126), act1=A.ACT_RELU)
                 hc, hn = ha, hb
@@ -374,7 +386,10 @@ class Engine:
                     sc, sn = sn, sc
                 # after two passes the state is back in hA
                 rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)
-                rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh_, View(co), res=View(co), scratch=fp)   # coords1 += delta
+                if fused and it + 1 < iters:
+                    rt.conv(tapl.inner, fh_, View(fp, 0, 18))      # per-tap partial sums; summed by the next flow_step
+                else:
+                    rt.tap_split_conv(tapl, fh_, View(co_home), res=View(co), scratch=fp)   # coords1 += delta (-> home tensor)
                 if taps is not None and it in (0, iters - 1):
                     taps[f"r01_corr_it{it}"] = corrf[:B, ..., :324].clone()
                     taps[f"r01_net_it{it}"] = hA[:B].clone()

@@ -525,6 +525,7 @@ class EngineF(Engine):
         ca = md + ".decoder_layer.cross_attend"
         kvm = tok._linear(ca + ".kv", mem_tok)                      # [n*K*P8, 128] = [key(64) | value(64)]
         coords = rt.coords_init(n, h8, w8)
+        coords_alt = rt.f32(n, h8, w8, 2)
         corr = rt.act(n, h8, w8, 145, zero=True, pitch=max(rt.cp64(145), 192))    # [cost_global(64) | cost_forward(81) | 0 ...]
         # (mixed policy: the token path fills its own copy in its activation type, converted once per iteration)
         corr_t = corr if tok is self else rtt.act(n, h8, w8, 145, zero=True, pitch=max(rtt.cp64(145), 192))
@@ -566,7 +567,14 @@ class EngineF(Engine):
             h32 = (h32A[a:b], h32B[a:b]) if sf else (None, None)
             cx = {k_: v[a:b] for k_, v in ctxg.items()}
             cr_rows = cr.view(rows, cr.shape[-1])
+            fused = rt.fuse_seam and taps is None
+            co_home, co_alt = co, coords_alt[a:b]     # (the fused seam updates the coordinates out of place: ping-pong)
+            tapl, patl = Ls[u + ".flow_head.conv2"], Ls[u + ".encoder.convf1"]
             for it in range(iters):
+                if fused:
+                    # one launch: coords1 += flow-head output of the previous iteration, flow activation, 7x7 patch of it
+                    co, co_alt = (rt.flow_step(tapl, patl, fp, co, fl, View(Xs, 126, 2), fc, coords_out=co_alt), co) if it > 0 else \
+                        (rt.flow_step(tapl, patl, None, co, fl, View(Xs, 126, 2), fc), co_alt)
                 # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
                 rtt.cost_lookup(vol_s, co, View(crt, 64, 81), rows, h8, w8)
                 t1 = tok._linear(md + ".flow_token_encoder.0", View(crt_rows, 64, 128), act=A.ACT_GELU)   # 81 taps + zeros
@@ -583,10 +591,14 @@ class EngineF(Engine):
                 if tok is not self:
                     cvt(View(crt_rows, 0, 145), View(cr_rows, 0, 145), 145)
                 # GMAUpdateBlock   gru.py:130-160
-                rt.flow_pack(co, fl, View(Xs, 126, 2))
+                if not fused:
+                    rt.flow_pack(co, fl, View(Xs, 126, 2))
                 rt.conv(Ls[u + ".encoder.convc1"], cr, c1_, act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
-                rt.patch_conv(Ls[u + ".encoder.convf1"], View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
+                if fused:
+                    rt.conv(patl.inner, fc, f1_, act1=A.ACT_RELU)
+                else:
+                    rt.patch_conv(patl, View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.conv"], cfl, View(Xs, 0, 126), act1=A.ACT_RELU)
                 # global motion aggregation: X[128:256] = mf + gamma * attn @ (mf Wv^T)   gma.py:101-115
@@ -605,7 +617,10 @@ class EngineF(Engine):
                     hc, hn = hn, hc
                     sc, sn = sn, sc
                 rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)
-                rt.tap_split_conv(Ls[u + ".flow_head.conv2"], fh_, View(co), res=View(co), scratch=fp)
+                if fused and it + 1 < iters:
+                    rt.conv(tapl.inner, fh_, View(fp, 0, 18))      # per-tap partial sums; summed by the next flow_step
+                else:
+                    rt.tap_split_conv(tapl, fh_, View(co_home), res=View(co), scratch=fp)    # (-> home tensor)
                 if taps is not None and it in (0, iters - 1):
                     taps[f"f01_cost_fwd_it{it}"] = corr[:B, ..., 64:145].clone()
                     taps[f"f01_cost_global_it{it}"] = corr[:B, ..., 0:64].clone()

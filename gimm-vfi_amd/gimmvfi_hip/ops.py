@@ -211,6 +211,7 @@ class Runtime:
         self.n_launch = 0
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
         self.lookup_lds = os.environ.get("GVFI_LOOKUP_LDS", "0") == "1"   # A/B switch: LDS-staged correlation look-up
+        self.fuse_seam = os.environ.get("GVFI_FUSE_SEAM", "1") != "0"     # A/B switch: gvfi_flow_step between iterations
         self.use_p3x3 = os.environ.get("GVFI_P3X3", "1") != "0"   # A/B switch: 0 keeps the LDS-DMA kernel on the hot 3x3 layers
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
         self._lanes = {}         # stream id -> extra streams for lanes()
@@ -470,6 +471,21 @@ class Runtime:
                                    None if r is None else r.ptr, 0 if r is None else r.ld, out.ptr, out.ld, n, h, w,
                                    self.stream()), "tap_sum")
         return out
+
+    def flow_step(self, tap_layer, patch_layer, pending, coords1, fl, xb, col, coords_out=None):
+        """The seam between two update iterations as one launch (gvfi_flow_step): coords_out = coords1 + tap sum of `pending`
+        (the per-tap partial sums the flow head's 1x1 convolution of the PREVIOUS iteration wrote; None: no update), flow ->
+        fl / xb, 7x7 im2col of the flow -> col (the input of patch_layer.inner).  Returns the tensor that now holds coords1."""
+        fl, xb = V(fl), (None if xb is None else V(xb))
+        n, h, w = coords1.shape[:3]
+        assert (patch_layer.kh, patch_layer.kw, patch_layer.cin) == (7, 7, 2) and col.shape[-1] == patch_layer.kpad
+        assert (tap_layer.kh, tap_layer.kw, tap_layer.cout) == (3, 3, 2)
+        self._chk(self.lib.flow_step(None if pending is None else pending.data_ptr(), 0 if pending is None else pending.shape[-1],
+                                     None if tap_layer.b is None else tap_layer.b.data_ptr(), coords1.data_ptr(),
+                                     None if pending is None else coords_out.data_ptr(), fl.ptr, fl.ld,
+                                     fl.ld, None if xb is None else xb.ptr, 0 if xb is None else xb.ld, col.data_ptr(),
+                                     col.shape[-1], n, h, w, self.dtype, self.stream()), "flow_step")
+        return coords1 if pending is None else coords_out
 
     def inr_mlp(self, mlp, lat, coord, out):
         """out[B,H,W,2] (f32) = hypo-network(lat[..., :32], coord[B,1,H,W,3])."""

@@ -202,6 +202,13 @@ int gvfi_flow_pack(const float* coords1, void* dst0, int ld0, int pad0, void* ds
  * out[n,y,x,c] = res + bias[c] + sum over taps of P at the tap's source pixel (zero padding).  res may alias out. */
 int gvfi_tap_sum(const float* P, int ldp, int C, int KH, int KW, const float* bias, const float* res, int ldr,
                  float* out, int ldo, int N, int H, int W, void* stream);
+/* the seam between two update iterations as ONE launch: coords_out = coords + tap sum of the 3x3x2 partial sums P (a second
+ * tensor: workgroups read their neighbours' pixels; with P == NULL there is no update and coords_out is not written),
+ * flow = coords1 - coords0 -> fl [N,h,w,ldf] (2 channels + zeros up to padf) and xb (2 channels at pitch ldx, may be
+ * NULL), and the 7x7x2 im2col of that flow -> col [N,h,w,ldc] (98 entries, K order (kh, kw, c), zero padded).  Bit-identical
+ * to gvfi_tap_sum + gvfi_flow_pack + gvfi_im2col in sequence (raft/raft.py:150,158-159; raft/update.py:6-14,100). */
+int gvfi_flow_step(const float* P, int ldp, const float* bias, const float* coords, float* coords_out, void* fl, int ldf,
+                   int padf, void* xb, int ldx, void* col, int ldc, int N, int h, int w, int dtype, void* stream);
 int gvfi_convex_upsample(const float* coords1, const void* mask, int ldm, int mask_f32, float* flow_up,
                          int N, int h, int w, int dtype, void* stream);
 

@@ -406,6 +406,39 @@ def corr_lookup_case(rt, B=2, h=16, w=24):
     assert torch.equal(a_.cpu(), b_.cpu())
 
 
+def flow_step_case(rt, N=2, h=11, w=21, first=False):
+    """gvfi_flow_step == gvfi_tap_sum + gvfi_flow_pack + gvfi_im2col in sequence, bit for bit (ragged tiles, image borders;
+    first: no pending update)."""
+    g = torch.Generator().manual_seed(21)
+    dev = _dev(rt)
+    w2 = torch.randn(2, 64, 3, 3, generator=g) * 0.1
+    b2 = torch.randn(2, generator=g)
+    tapl = TapSplitConvLayer(rt, w2, b2)
+    patl = PatchConvLayer(rt, torch.randn(16, 2, 7, 7, generator=g), torch.randn(16, generator=g))
+    coords0 = (orc.coords_grid(N, h, w) + torch.randn(N, 2, h, w, generator=g) * 3).permute(0, 2, 3, 1).contiguous()
+    P = torch.randn(N, h, w, 20, generator=g)
+    outs = []
+    for fused in (False, True):
+        co = coords0.clone().to(dev)
+        fp = P.clone().to(dev)
+        fl = rt.act(N, h, w, 2, zero=True)
+        xb = rt.act(N, h, w, 16, zero=True)
+        col = torch.full((N, h, w, patl.kpad), 5.0, dtype=rt.tdtype, device=dev)
+        if fused:
+            co = rt.flow_step(tapl, patl, None if first else fp, co, fl, View(xb, 8, 2), col, coords_out=torch.empty_like(co))
+        else:
+            if not first:
+                rt._chk(rt.lib.tap_sum(fp.data_ptr(), 20, 2, 3, 3, tapl.b.data_ptr(), co.data_ptr(), 2, co.data_ptr(), 2, N, h, w,
+                                       rt.stream()), "tap_sum")
+            rt.flow_pack(co, fl, View(xb, 8, 2))
+            rt._chk(rt.lib.im2col(fl.data_ptr(), fl.shape[-1], 2, N, h, w, 7, 7, 3, 3, col.data_ptr(), patl.kpad, rt.dtype,
+                                  rt.stream()), "im2col")
+        outs.append([t.cpu().clone() for t in (co, fl, xb, col)])
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_.view(torch.uint8) if a_.dtype != torch.float32 else a_, b_.view(torch.uint8) if b_.dtype != torch.float32 else b_)
+    return True
+
+
 def convex_upsample_case(rt, N=2, h=6, w=9):
     g = torch.Generator().manual_seed(4)
     dev = _dev(rt)

@@ -198,6 +198,12 @@ def test_corr_lookup(rt):
     kc.corr_lookup_case(rt)
 
 
+def test_flow_step_equals_tap_sum_flow_pack_im2col(rt):
+    kc.flow_step_case(rt)
+    kc.flow_step_case(rt, N=1, h=8, w=16, first=True)
+    kc.flow_step_case(rt, N=3, h=5, w=7)
+
+
 def test_convex_upsample(rt):
     kc.convex_upsample_case(rt)
 
