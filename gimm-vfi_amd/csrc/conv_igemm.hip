@@ -294,11 +294,16 @@ template <typename T> static int dispatch_conv(const gvfi_conv_params& p, hipStr
     }
 }
 
-// Which kernel gvfi_conv2d would launch for *pp: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch, 4 halo-staged 3x3, 5 its mid-channel sibling), BM, BN, K-chunk bytes, LDS stages}.
+// Which kernel gvfi_conv2d would launch for *pp: plan[5] = {algo (1 generic, 2 LDS-DMA, 3 patch, 4 halo-staged 3x3, 5 its mid-channel sibling, 7 column kernel of the 7x7 few-channel layers), BM, BN, K-chunk bytes, LDS stages}.
 // the patch kernel (conv_patch.hip) takes what the LDS-DMA kernel cannot: few channels / reflect padding at full resolution
 static bool use_patch(const gvfi_conv_params& p) {
     if ((p.algo & 15) == 3) return true;
     return (p.algo & 15) == 0 && !gvfi_conv2d_glds_eligible(&p) && gvfi_conv2d_patch_eligible(&p) == 1;
+}
+
+static bool use_col7(const gvfi_conv_params& p) {
+    if ((p.algo & 15) == 7) return true;
+    return (p.algo & 15) == 0 && gvfi_conv2d_col7_eligible(&p) == 1;
 }
 
 static bool use_p3x3(const gvfi_conv_params& p) {
@@ -322,6 +327,10 @@ extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
         return 0;
     }
     if ((p.algo & 15) == 2 || ((p.algo & 15) == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds_plan(pp, plan);
+    if (use_col7(p)) {
+        plan[0] = 7; plan[1] = 1024; plan[2] = p.Cout > 16 ? 32 : 16; plan[3] = 16; plan[4] = 1;
+        return 0;
+    }
     if (use_patch(p)) {
         plan[0] = 3; plan[1] = 512; plan[2] = p.Cout > 32 ? 64 : 32; plan[3] = 16; plan[4] = 1;
         return 0;
@@ -336,6 +345,7 @@ extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {
     if (use_p3x3s(p)) return gvfi_conv2d_p3x3s(pp, stream);
     if (use_p3x3(p)) return gvfi_conv2d_p3x3(pp, stream);
     if ((p.algo & 15) == 2 || ((p.algo & 15) == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds(pp, stream);
+    if (use_col7(p)) return gvfi_conv2d_col7(pp, stream);
     if (use_patch(p)) return gvfi_conv2d_patch(pp, stream);
     if (p.w_layout != 0) return -5;   // the chunked weight image is only understood by the LDS-DMA kernel
     if (p.stats != nullptr) return -6;   // fused statistics exist only in the LDS-DMA kernel (gvfi_conv2d_stats_ok)

@@ -9,6 +9,12 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_bf16: A lane l holds A[m = l&15][8 k-values of group l>>4], B lane l holds B[same k group][n = l&15];
+// C/D: col n = l&15, rows m = 4*(l>>4) + r, r = 0..3
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_f16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -94,8 +100,10 @@ template <int N> static inline void glds_wait_n() {}
 // instruction-scheduling fence: nothing is moved across it (keeps hand-written software pipelining in place)
 #ifndef GVFI_HOSTSIM
 #define GVFI_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define GVFI_OPAQUE_V(x) asm volatile("" : "+v"(x))      /* the compiler may not derive anything about x across this point */
 #else
 #define GVFI_SCHED_BARRIER() ((void)0)
+#define GVFI_OPAQUE_V(x) ((void)0)
 #endif
 
 template <typename T> struct Mma2;

@@ -785,9 +785,9 @@ class Engine:
                                      st()), "combine_warps_up")
         cb = rt.act(B, Hf, Wf, 18, zero=True)
         # (pad16: cb's channels 18..23 and o4's / mean4's channel 3 are padding owned here -> whole 16-byte stores)
-        rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU, pad16=True)
+        rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU, pad16=True, algo=rt.comb_algo)
         o4 = rt.f32(B, Hf, Wf, 4)
-        rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3), pad16=True)
+        rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3), pad16=True, algo=rt.comb_algo)
         pred = rt.f32(B, 3, Hf, Wf)
         rt._chk(lib.finalize_image(o4.data_ptr(), 4, pred.data_ptr(), B, Hf, Wf, st()), "finalize_image")
         f04 = rt.nhwc_to_nchw(View(st4, 0, 2), 2)

@@ -183,11 +183,13 @@ class VideoSink:
 
     ``put(index, frame_hwc_bgr_u8)`` may be called from any thread in any order; ``close()`` returns the path that was
     written.  With OpenCV (and frames the mp4v writer accepts) frames are encoded in index order by one writer thread --
-    out-of-order frames wait in a dict whose size the producers bound (ResultDrain depth); otherwise every frame is saved
-    at once as PNG ``<stem>_frames/<index>.png`` (compression level 1; zlib releases the GIL) and ffmpeg, when present,
-    encodes them at close.  ``total``: number of frames, known up front."""
+    out-of-order frames wait in a dict whose size the producers bound (ResultDrain depth); otherwise every frame becomes
+    a PNG ``<stem>_frames/<index>.png`` (compression level 1; zlib releases the GIL) written by a pool of threads -- the
+    files are independent, and one thread encodes a 2K side-by-side frame in ~0.15 s, a tenth of what the GPU delivers;
+    ``put`` blocks once 2 x workers frames are waiting (bounded memory) -- and ffmpeg, when present, encodes them at
+    close.  ``total``: number of frames, known up front."""
 
-    def __init__(self, path, fps, total, frame_hw, use_cv2=None):
+    def __init__(self, path, fps, total, frame_hw, use_cv2=None, png_workers=None):
         import os
 
         self.path, self.fps, self.total = path, fps, total
@@ -210,16 +212,31 @@ class VideoSink:
         else:
             self.frame_dir = os.path.splitext(path)[0] + "_frames"
             os.makedirs(self.frame_dir, exist_ok=True)
+            nw = png_workers if png_workers is not None else max(1, min(32, (os.cpu_count() or 4) // 2))
+            self.png_pool = ThreadPoolExecutor(max_workers=nw)
+            self.png_slots = threading.BoundedSemaphore(2 * nw)
+
+    def _save_png(self, index, frame):
+        import os
+
+        from PIL import Image
+
+        try:
+            Image.fromarray(np.ascontiguousarray(frame[:, :, ::-1])).save(os.path.join(self.frame_dir, f"{index:04d}.png"), compress_level=1)
+            with self._lock:
+                self.written += 1
+        except Exception as e:          # surfaced by close()
+            self.err = self.err or e
+        finally:
+            self.png_slots.release()
 
     def put(self, index, frame):
         assert 0 <= index < self.total
         if self.cv2 is None:
-            from PIL import Image
-            import os
-
-            Image.fromarray(np.ascontiguousarray(frame[:, :, ::-1])).save(os.path.join(self.frame_dir, f"{index:04d}.png"), compress_level=1)
-            with self._lock:
-                self.written += 1
+            if self.err is not None:
+                raise self.err
+            self.png_slots.acquire()
+            self.png_pool.submit(self._save_png, index, frame)
             return
         with self._lock:
             self._pending[index] = frame
@@ -259,6 +276,9 @@ class VideoSink:
                 raise self.err
             assert self.written == self.total, (self.written, self.total)
             return self.path
+        self.png_pool.shutdown(wait=True)
+        if self.err is not None:
+            raise self.err
         assert self.written == self.total, (self.written, self.total)
         if shutil.which("ffmpeg"):
             subprocess.run(["ffmpeg", "-y", "-framerate", f"{self.fps}", "-i", f"{self.frame_dir}/%04d.png", "-c:v", "libx264",

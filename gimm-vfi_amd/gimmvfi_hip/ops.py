@@ -212,6 +212,8 @@ class Runtime:
         self.ev_log = None   # list => conv launches are bracketed by HIP events (bench.py)
         self.lookup_lds = os.environ.get("GVFI_LOOKUP_LDS", "0") == "1"   # A/B switch: LDS-staged correlation look-up
         self.fuse_seam = os.environ.get("GVFI_FUSE_SEAM", "1") != "0"     # A/B switch: gvfi_flow_step between iterations
+        # A/B switch: 0 keeps the combination block (7x7, 9 -> 18 -> 3) on the patch kernel instead of conv_col7.hip
+        self.comb_algo = 0 if os.environ.get("GVFI_COL7", "1") != "0" else 3
         self.use_p3x3 = os.environ.get("GVFI_P3X3", "1") != "0"   # A/B switch: 0 keeps the LDS-DMA kernel on the hot 3x3 layers
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
         self._lanes = {}         # stream id -> extra streams for lanes()
@@ -388,7 +390,7 @@ class Runtime:
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
             kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel",
-                     6: "conv_igemm_glds_kernel[wdir]"}[plan[0]]
+                     6: "conv_igemm_glds_kernel[wdir]", 7: "conv_col7_kernel"}[plan[0]]
             tag = f"{kname}<{ {L.F32: 'float', L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"

@@ -98,6 +98,8 @@ typedef struct {
                                          * 3 = patch kernel (few channels, see gvfi_conv2d_patch); *
                                          * 4 = halo-staged 3x3 kernel (gvfi_conv2d_p3x3);           *
                                          * 5 = its mid-channel sibling (gvfi_conv2d_p3x3s);         *
+                                         * 7 = column kernel of the 7x7 few-channel layers          *
+                                         * (gvfi_conv2d_col7);                                       *
                                          * bit 4 "pad16": the caller owns the channel padding of   *
                                          * y and res up to the next 16-byte boundary -- a ragged   *
                                          * last channel group may be accessed in whole 16-byte     *
@@ -132,6 +134,15 @@ int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
  * algo = 3. */
 int gvfi_conv2d_patch_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_patch(const gvfi_conv_params* p, void* stream);
+/* 7x7 stride-1 zero-padded (pad 3) bf16 convolution over <= 32 input and <= 32 output channels with the "pad16" contract
+ * (algo bit 4), activation none / ReLU / LeakyReLU / PReLU, optional FLOAT residual into a float y: the combination block
+ * of multi_flow_combine, 9 -> 18 -> 3 (gimmvfi_r.py:60-64,305-308) (csrc/conv_col7.hip).  Lanes run down a column of
+ * pixels, so one LDS fragment of an input column feeds the MFMAs of all seven horizontal taps; v_mfma_f32_16x16x32_bf16
+ * with the weights as the 16-row operand (Cout padded to 16, not 32).  gvfi_conv2d routes here when
+ * gvfi_conv2d_col7_eligible == 1 (algo 0; >= 65536 output pixels, image >= 32 x 32) or with algo = 7 (eligible == 2:
+ * runnable); algo = 3 keeps the patch kernel.  fp32 accumulation order differs from the patch kernel (not bit-identical). */
+int gvfi_conv2d_col7_eligible(const gvfi_conv_params* p);
+int gvfi_conv2d_col7(const gvfi_conv_params* p, void* stream);
 /* 3x3 stride-1 zero-padded bf16 convolution with Cout % 256 == 0, channel counts % 64 == 0, w_layout 1 and >= 65536
  * output pixels -- the ResBlocks of NewMultiFlowDecoder (fi_components.py:97-154,279-340), the path's FLOP-dominant
  * layers (csrc/conv_p3x3.hip): 16 x 16-pixel output tile whose 18 x 18 input halo is staged once per 64-channel chunk

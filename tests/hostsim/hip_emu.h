@@ -147,6 +147,33 @@ static inline f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4& b, f32x16 c
     emu::wave_sync();
     return c;
 }
+// v_mfma_f32_16x16x32_bf16: A lane l holds A[m=l&15][k=8*(l>>4)+0..7]; B lane l holds B[k=8*(l>>4)+0..7][n=l&15];
+// C/D: col n = l&15, row m = 4*(l>>4) + r.
+struct f32x4 {
+    float v[4];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
+static inline f32x4 mfma_bf16_16x16x32(const uint4& a, const uint4& b, f32x4 c) {
+    uint32_t* s = emu::wave_scratch();
+    const int l = emu::tl_lane;
+    std::memcpy(&s[l * 16], &a, 16);
+    std::memcpy(&s[l * 16 + 4], &b, 16);
+    emu::wave_sync();
+    const int n = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            const uint16_t* pa = reinterpret_cast<const uint16_t*>(&s[(m + 16 * (k >> 3)) * 16]);
+            const uint16_t* pb = reinterpret_cast<const uint16_t*>(&s[(n + 16 * (k >> 3)) * 16 + 4]);
+            acc += emu_bf2f(pa[k & 7]) * emu_bf2f(pb[k & 7]);
+        }
+        c[r] = acc;
+    }
+    emu::wave_sync();
+    return c;
+}
 // v_mfma_f32_32x32x16_f16: the same layouts with IEEE half operands
 static inline float emu_h2f(uint16_t v) {
     const uint32_t sg = (uint32_t)(v & 0x8000u) << 16, e = (v >> 10) & 31u, m = v & 0x3ffu;

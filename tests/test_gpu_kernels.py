@@ -75,6 +75,18 @@ CONV_SHAPES = [
     (1, 9, 64, 2, 16, 3, 3, dict(algo=3)),
     (1, 10, 70, 9, 18, 7, 7, dict(algo=3, act1=L.ACT_PRELU, pad16=True)),                     # whole 16-byte stores incl. pad channels
     (1, 9, 40, 18, 3, 7, 7, dict(algo=3, out_f32=True, with_res=True, pad16=True, bf16_only=True)),
+    # column kernel of the 7x7 few-channel layers (conv_col7.hip, algo 7): 32 x 32 tiles (ragged, several tiles, two images),
+    # every (channel blocks, 16-byte groups per pixel) instantiation the combination block uses and the generic ones,
+    # PReLU / LeakyReLU / none, output scale, float output + float residual, pad channels written as zeros
+    (1, 10, 70, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True)),
+    (1, 9, 40, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True)),
+    (2, 37, 45, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=3)),
+    (1, 33, 34, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=4)),
+    (1, 12, 40, 3, 16, 7, 7, dict(algo=7, act1=L.ACT_LRELU, out_scale=0.5, pad16=True, bf16_only=True)),
+    (1, 100, 104, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=5)),       # interior tiles: constant DMA offsets
+    (2, 97, 70, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=6)),
+    (1, 8, 33, 8, 32, 7, 7, dict(algo=7, act1=L.ACT_RELU, pad16=True, bf16_only=True)),
+    (1, 6, 36, 24, 12, 7, 7, dict(algo=7, pad16=True, bf16_only=True)),
     (1, 256, 448, 9, 18, 7, 7, dict(act1=L.ACT_PRELU)),                                       # auto -> patch kernel (comb block)
     (1, 256, 448, 18, 3, 7, 7, dict(out_f32=True, with_res=True)),
     (2, 256, 448, 3, 64, 7, 7, dict(stride=2, act1=L.ACT_RELU)),                              # encoder stem

@@ -70,6 +70,8 @@ def main():
         resid = rt.act(N, H // stride, W // stride, Cout) if with_res else None
         if Cin < 32:
             variants = ((1, 0), (3, 0))
+            if KH == 7 and stride == 1:      # + the column kernel (conv_col7.hip); PAD16=1 gives the patch kernel the same store contract
+                variants = ((1, 0), (3, 0), (7, 0), (3, 1 << 20), (7, 1 << 20))
         if os.environ.get("P3S"):        # LDS-DMA kernel against the mid-channel halo-staged kernel (conv_p3x3s.hip)
             variants = ((2, 0), (5, 0), (2, 1 << 20), (5, 1 << 20))
         if os.environ.get("PATCH64"):    # LDS-DMA kernel against the patch kernel on the <= 64-channel layers
@@ -88,7 +90,7 @@ def main():
             if (tile & 1023) == 128 and Cout <= 64:
                 tile = 0
             try:
-                kw = dict(pad16=True) if (algo == 3 and os.environ.get("PAD16")) else {}
+                kw = dict(pad16=True) if ((algo == 3 and os.environ.get("PAD16")) or algo == 7) else {}
                 if with_res:
                     kw.update(res=resid, act2=L.ACT_LRELU)
                 for _ in range(2):

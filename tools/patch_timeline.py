@@ -1,5 +1,6 @@
 """Per-phase cycles of the patch convolution (conv_patch.hip profiling stamps, algo bit 15).
-usage: python tools/patch_timeline.py <shape filter of tools/conv_bench.py SHAPES>"""
+usage: [ALGO=7] python tools/patch_timeline.py <shape filter of tools/conv_bench.py SHAPES>
+ALGO=7: the column kernel (conv_col7.hip; same four phases: patch staging, K loop, epilogue to LDS, stores)"""
 import os
 import sys
 
@@ -13,6 +14,8 @@ from gimmvfi_hip import lib as L  # noqa: E402
 from gimmvfi_hip.ops import ConvLayer, Runtime, View  # noqa: E402
 
 rt = Runtime(L.get(), "bf16", "cuda:0")
+ALGO = int(os.environ.get("ALGO", "3"))
+PAD16 = bool(os.environ.get("PAD16")) or ALGO == 7
 for name, N, H, W, Cin, Cout, KH, KW, split in SHAPES:
     if sys.argv[1] not in name:
         continue
@@ -23,11 +26,11 @@ for name, N, H, W, Cin, Cout, KH, KW, split in SHAPES:
     out = rt.act(N, H // stride, W // stride, Cout)
     st = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
     for _ in range(2):
-        rt.conv(lay, View(x, 0, Cin), out, act1=L.ACT_RELU, algo=3, pad16=bool(os.environ.get("PAD16")))
+        rt.conv(lay, View(x, 0, Cin), out, act1=L.ACT_RELU, algo=ALGO, pad16=PAD16)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    rt.conv(lay, View(x, 0, Cin), out, act1=L.ACT_RELU, algo=3 + 256 * 128, aux1=st, pad16=bool(os.environ.get("PAD16")))
+    rt.conv(lay, View(x, 0, Cin), out, act1=L.ACT_RELU, algo=ALGO + 256 * 128, aux1=st, pad16=PAD16)
     e1.record()
     torch.cuda.synchronize()
     s = st.cpu().view(-1, 4).double()
