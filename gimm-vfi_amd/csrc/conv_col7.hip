@@ -15,15 +15,17 @@
 //     = ceil(7 * groups / 4) -- 9 -> 18: 4 steps x 2 channel blocks, 18 -> 3: 6 steps x 1 -- and the accumulator layout is
 //     "lane = pixel, 4 registers = 4 consecutive channels", so the epilogue applies bias / PReLU in registers and
 //     transposes through LDS with 8- / 16-byte writes;
-//   * the seven weight fragments of a K step stay in registers for the step (reloaded in place from LDS right after their
-//     last use), the 28 pixel fragments of a step likewise: every LDS read is issued a whole step ahead of its use;
+//   * the seven weight fragments of a K step stay in registers for the step (each reloaded in place from LDS right after
+//     its last use), the pixel fragments go through a ring of seven registers sets, column xi + 7 read into the slot of
+//     column xi right after its MFMAs: every LDS read is issued 28 or more MFMAs ahead of its use;
 //   * tile = 32 x 32 output pixels per 4-wave workgroup (patch 38 x 38, row pitch an odd multiple of 16 B: the 16 lanes of
 //     a fragment read 16 different bank groups), persistent workgroups.  The WHOLE patch of the next tile is requested
 //     into registers (12-18 x 16 bytes per thread) before the K loop of the current one and written to LDS after it: with
 //     every CU in the same phase the 256 patches are an 18 MB burst that takes HBM ~6 k cycles -- behind 15-18 k cycles of
 //     MFMAs it costs nothing, in front of them (LDS-DMA after the K loop, measured) it cost a third of the tile time;
-//   * output rows leave LDS as whole 16-byte units of contiguous pixels (+ float residual); the (LDS offset, global
-//     offset) pair of every unit of a thread is tile-independent and computed once.
+//   * output rows leave LDS as whole 16-byte units of contiguous pixels (+ float residual) in a run-time loop of four
+//     units per thread (unrolled, hipcc kept every unit's values live and spilled the prefetched patch -- and a scratch
+//     reload waits for the HBM loads in flight, they share one counter: 1.0 instead of 0.5 ms).
 // Summation order differs from the patch kernel (K is walked kx-major per input column): results agree to fp32 rounding
 // of the accumulation, not bit for bit.
 #include "conv_mma.h"

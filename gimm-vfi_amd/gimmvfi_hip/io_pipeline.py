@@ -185,8 +185,8 @@ class VideoSink:
     written.  With OpenCV (and frames the mp4v writer accepts) frames are encoded in index order by one writer thread --
     out-of-order frames wait in a dict whose size the producers bound (ResultDrain depth); otherwise every frame becomes
     a PNG ``<stem>_frames/<index>.png`` (compression level 1; zlib releases the GIL) written by a pool of threads -- the
-    files are independent, and one thread encodes a 2K side-by-side frame in ~0.15 s, a tenth of what the GPU delivers;
-    ``put`` blocks once 2 x workers frames are waiting (bounded memory) -- and ffmpeg, when present, encodes them at
+    files are independent, and one thread encodes a 2K side-by-side frame in ~0.5 s, a hundredth of what the GPU delivers;
+    ``put`` blocks once workers + 32 frames are waiting (bounded memory) -- and ffmpeg, when present, encodes them at
     close.  ``total``: number of frames, known up front."""
 
     def __init__(self, path, fps, total, frame_hw, use_cv2=None, png_workers=None):
@@ -212,9 +212,10 @@ class VideoSink:
         else:
             self.frame_dir = os.path.splitext(path)[0] + "_frames"
             os.makedirs(self.frame_dir, exist_ok=True)
-            nw = png_workers if png_workers is not None else max(1, min(32, (os.cpu_count() or 4) // 2))
+            # (one thread encodes ~2 side-by-side 2K frames per second; the GPU delivers ~200 output + flow frames per second)
+            nw = png_workers if png_workers is not None else max(1, min(96, (os.cpu_count() or 4) // 2))
             self.png_pool = ThreadPoolExecutor(max_workers=nw)
-            self.png_slots = threading.BoundedSemaphore(2 * nw)
+            self.png_slots = threading.BoundedSemaphore(nw + 32)
 
     def _save_png(self, index, frame):
         import os
