@@ -121,6 +121,20 @@ def test_convolution_routing_table_of_the_product_library():
     assert plan(_conv_params(8, 32, 56, 256, 256, k=(1, 5), w_layout=1))[:3] == [2, 64, 128]
     assert plan(_conv_params(16, 32, 56, 256, 256, k=(1, 5), w_layout=1))[:3] == [2, 128, 128]
     # few-channel layers at full resolution and reflect padding: patch kernel; everything else: generic kernel
-    assert plan(_conv_params(1, 2176, 4096, 16, 18, k=(7, 7)))[0] == 3
+    assert plan(_conv_params(1, 2176, 4096, 16, 18, k=(7, 7)))[0] == 3                          # (no pad16 contract: patch kernel)
+    # combination block (gimmvfi_r.py:60-64): with the pad16 store contract -> column kernel (conv_col7.hip), both layers
+    def comb(N, H, W, c0, Cout, **kw):
+        q = _conv_params(N, H, W, c0, Cout, k=(7, 7), **kw)
+        q.algo = 16
+        return q
+    assert plan(comb(1, 2176, 4096, 16, 18))[:3] == [7, 1024, 32]
+    q = comb(1, 2176, 4096, 24, 3, res=True, res_f32=True, y_f32=True)
+    q.act1, q.ldy, q.ldr = L.ACT_NONE, 4, 4
+    assert plan(q)[:3] == [7, 1024, 16]
+    assert plan(comb(8, 256, 448, 16, 18))[0] == 7
+    assert plan(comb(1, 160, 200, 16, 18))[0] == 3                                             # < 65536 pixels: patch kernel
+    assert plan(comb(1, 2176, 4096, 16, 18, dtype=L.F32))[0] in (1, 3)                          # float validation mode
+    q = comb(1, 2176, 4096, 32, 32)
+    assert plan(q)[0] != 7                                                                     # patch + weight fragments + staging > 160 KB
     assert plan(_conv_params(1, 544, 1024, 64, 32, pad_mode=L.PAD_REFLECT))[0] == 3
     assert plan(_conv_params(8, 256, 448, 64, 64, dtype=L.F32))[0] in (1, 2)                    # float validation mode never takes 4 / 5
