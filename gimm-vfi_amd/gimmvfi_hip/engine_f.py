@@ -22,7 +22,7 @@ import torch
 
 from . import lib as L
 from .engine import Engine
-from .ops import PatchConvLayer, TapSplitConvLayer, View
+from .ops import PatchConvLayer, S2DConvLayer, TapSplitConvLayer, View
 
 A = L
 K_LAT = 8          # cost_latent_token_num   configs/submission.py:30
@@ -108,11 +108,29 @@ class EngineF(Engine):
     def _f32(self, t):
         return t.detach().float().contiguous().to(self.rt.device)
 
+    def _add_s2d(self, k, sd, ksz, ld):
+        """filter size == stride, no padding: the same layer as a k x 1 convolution over k * ld contiguous values per patch
+        row (ops.S2DConvLayer) when that makes whole K chunks of the LDS-DMA kernel -- a 4 x 4 filter over 3 (8) channels is
+        4 taps of 32, an 8 x 8 filter (64 taps: beyond the LDS-DMA kernel's 32-tap masks) 8 taps of 1024."""
+        if os.environ.get("GVFI_S2D", "1") != "0" and (ksz * ld) % (4 * self.rt.VE) == 0 and ksz * ksz > 4:
+            self.layers[k + ".s2d"] = S2DConvLayer(self.rt, sd[k + ".weight"], sd[k + ".bias"], ld)
+
+    def _conv_k_eq_s(self, k, x, out):
+        """x: [N, H, W, ld] tensor (a View of its first channels); the space-to-depth form when the layer has one and the
+        tensor is the contiguous whole-pitch tensor it was built for."""
+        lay = self.layers.get(k + ".s2d")
+        xv = x if isinstance(x, View) else View(x)
+        if (lay is not None and xv.coff == 0 and xv.t.is_contiguous() and xv.t.shape[-1] == lay.ld
+                and xv.t.shape[1] % lay.k == 0 and xv.t.shape[2] % lay.k == 0):      # (ragged grids: the strided form floors)
+            return self.rt.s2d_conv(lay, xv.t, out)
+        return self.rt.conv(self.layers[k], xv, out)
+
     def _build_twins(self, sd, p):
         cin = 3
         for i, (c, patch, heads, sr) in enumerate(TWINS):
             k = f"{p}.svt.patch_embeds.{i}.proj"
             self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=patch, pad=(0, 0))
+            self._add_s2d(k, sd, patch, self.rt.cp(sd[k + ".weight"].shape[1]))
             self._ln(sd, f"{p}.svt.patch_embeds.{i}.norm")
             for j in (0, 1):
                 b = f"{p}.svt.blocks.{i}.{j}"
@@ -129,6 +147,7 @@ class EngineF(Engine):
                     self._lin(sd, b + ".attn.kv")
                     k = b + ".attn.sr"
                     self._add(k, sd[k + ".weight"], sd[k + ".bias"], stride=sr, pad=(0, 0))
+                    self._add_s2d(k, sd, sr, c)
                     self._ln(sd, b + ".attn.norm")
                 self._lin(sd, b + ".attn.proj")
                 self._lin(sd, b + ".mlp.fc1")
@@ -293,7 +312,7 @@ class EngineF(Engine):
             hd = c // heads
             rows = n * h * w
             emb = rt.act(n, h, w, c)
-            rt.conv(Ls[f"{p}.svt.patch_embeds.{i}.proj"], src, emb)
+            self._conv_k_eq_s(f"{p}.svt.patch_embeds.{i}.proj", src, emb)
             t = rt.layernorm(emb.view(rows, c), self.ln[f"{p}.svt.patch_embeds.{i}.norm"], 1e-5)
             # ---- block 0: locally-grouped attention (ws 7)   twins.py:814-867
             b = f"{p}.svt.blocks.{i}.0"
@@ -314,7 +333,7 @@ class EngineF(Engine):
             hs, ws_ = h // sr, w // sr
             m = hs * ws_
             s = rt.act(n, hs, ws_, c)
-            rt.conv(Ls[b + ".attn.sr"], y.view(n, h, w, c), s)
+            self._conv_k_eq_s(b + ".attn.sr", y.view(n, h, w, c), s)
             s = rt.layernorm(s.view(n * m, c), self.ln[b + ".attn.norm"], 1e-5)
             kv = self._linear(b + ".attn.kv", s)
             a = self._tok(rows, c)

@@ -109,6 +109,25 @@ class PatchConvLayer:
         self.inner.cin = kh * kw * cin      # real products per output (FLOP accounting)
 
 
+class S2DConvLayer:
+    """A convolution whose filter size equals its stride, without padding (patch embeddings, sub-sampling convolutions of
+    the Twins encoder: twins.py:720-745, 870-925): non-overlapping k x k patches.  In NHWC the k pixels of one patch row
+    are ONE contiguous run of k * ld values, so the input [N, H, W, ld] IS the tensor [N * H/k, k, W/k, k * ld] and the
+    layer is a k x 1 stride-1 convolution over k * ld "channels" with ONE output row per image -- no data moves, and a
+    filter with more than 32 taps (8 x 8: the generic kernel at 12 TFLOP/s) becomes 8 taps of the LDS-DMA kernel.
+    ld = channel pitch of the input tensor (whole pitch: the view must start at channel 0)."""
+
+    def __init__(self, rt, w, b, ld):
+        cout, cin, kh, kw = w.shape
+        assert kh == kw and cin <= ld
+        self.k, self.ld, self.cin, self.cout = kh, ld, cin, cout
+        w2 = torch.zeros(cout, kw * ld, kh, 1, dtype=torch.float32, device=w.device)
+        # w2[o, kx * ld + c, ky, 0] = w[o, c, ky, kx]
+        w2.view(cout, kw, ld, kh)[:, :, :cin, :] = w.detach().float().permute(0, 3, 1, 2)
+        self.inner = ConvLayer(rt, w2, b, stride=1, pad=(0, 0))
+        self.inner.cin = kh * kw * cin      # real products per output (FLOP accounting)
+
+
 class TapSplitConvLayer:
     """A KHxKW zero-padded stride-1 convolution with very few output channels, run as a 1x1 convolution to the
     KH*KW*Cout per-tap partial sums + gvfi_tap_sum (Runtime.tap_split_conv)."""
@@ -446,6 +465,17 @@ class Runtime:
         c = self.f32(n, h, w, 2)
         self._chk(self.lib.coords_init(c.data_ptr(), n, h, w, self.stream()), "coords_init")
         return c
+
+    def s2d_conv(self, layer, x, out, **kw):
+        """x: contiguous [N, H, W, ld] activation tensor (H, W multiples of layer.k), out: [N, H/k, W/k, cout]."""
+        k = layer.k
+        n, h, w_, ld = x.shape
+        assert x.is_contiguous() and ld == layer.ld and h % k == 0 and w_ % k == 0, (x.shape, layer.ld, k)
+        out = V(out)
+        assert out.t.is_contiguous() and out.t.shape[:3] == (n, h // k, w_ // k)
+        xv = x.view(n * (h // k), k, w_ // k, k * ld)
+        ov = View(out.t.view(n * (h // k), 1, w_ // k, out.t.shape[-1]), out.coff, out.c)
+        return self.conv(layer.inner, View(xv, 0, k * ld), ov, **kw)
 
     def patch_conv(self, layer, src, out, scratch=None, **kw):
         """conv of a PatchConvLayer: im2col into `scratch` [N,H,W,kpad] then a 1x1 convolution."""

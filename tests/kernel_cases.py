@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 import gimmvfi_r_oracle as orc
 from gimmvfi_hip import lib as L
-from gimmvfi_hip.ops import ConvLayer, InrMlp, PatchConvLayer, TapSplitConvLayer, View
+from gimmvfi_hip.ops import ConvLayer, InrMlp, PatchConvLayer, S2DConvLayer, TapSplitConvLayer, View
 
 
 def _dev(rt):
@@ -404,6 +404,28 @@ def corr_lookup_case(rt, B=2, h=16, w=24):
     finally:
         rt.lookup_lds = keep
     assert torch.equal(a_.cpu(), b_.cpu())
+
+
+def s2d_case(rt, N, H, W, Cin, Cout, k, seed=0):
+    """filter size == stride, no padding, as a k x 1 convolution over the space-to-depth VIEW of the input
+    (ops.S2DConvLayer / Runtime.s2d_conv) against torch's strided convolution; the launched kernel is reported."""
+    g = torch.Generator().manual_seed(seed)
+    x = _rounded(rt, torch.randn(N, Cin, H, W, generator=g))
+    w = _rounded(rt, torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    xa = _to_act(rt, x).to(_dev(rt))
+    lay = S2DConvLayer(rt, w, b, xa.shape[-1])
+    out = rt.act(N, H // k, W // k, Cout)
+    rt.s2d_conv(lay, xa, out)
+    ref = F.conv2d(x, w, b, stride=k).permute(0, 2, 3, 1)
+    got = out.float().cpu()[..., :Cout]
+    err = float((got - ref).abs().max())
+    assert err <= tol(rt, float(ref.abs().max())), (err, float(ref.abs().max()))
+    # the strided form of the same layer agrees too (what the engine falls back to on ragged grids)
+    lay0 = ConvLayer(rt, w, b, stride=k, pad=(0, 0))
+    out0 = rt.act(N, H // k, W // k, Cout)
+    rt.conv(lay0, View(xa, 0, Cin), out0)
+    assert float((out0.float().cpu()[..., :Cout] - got).abs().max()) <= tol(rt, float(ref.abs().max()))
 
 
 def flow_step_case(rt, N=2, h=11, w=21, first=False):

@@ -209,6 +209,12 @@ def test_flow_step_equals_tap_sum_flow_pack_im2col(rt):
     kc.flow_step_case(rt, N=8, h=32, w=56)
 
 
+def test_space_to_depth_form_of_the_filter_equals_stride_convolutions(rt):
+    kc.s2d_case(rt, 2, 16, 24, 3, 128, 4)        # Twins patch embedding (twins.py:720-745): 4 taps of 4 x 8 values
+    kc.s2d_case(rt, 1, 16, 24, 128, 128, 8, 1)   # sub-sampling convolution (twins.py:870-925): 8 taps of 1024
+    kc.s2d_case(rt, 2, 8, 12, 64, 40, 4, 2)
+
+
 def test_convex_upsample(rt):
     kc.convex_upsample_case(rt)
 

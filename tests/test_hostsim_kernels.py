@@ -216,6 +216,11 @@ def test_flow_step_equals_tap_sum_flow_pack_im2col(rt):
     kc.flow_step_case(rt, N=3, h=5, w=7)
 
 
+def test_space_to_depth_form_of_the_filter_equals_stride_convolutions(rt):
+    kc.s2d_case(rt, 2, 8, 12, 3, 64, 4)          # Twins patch embedding (twins.py:720-745): 4 taps of 4 x 8 values
+    kc.s2d_case(rt, 1, 8, 16, 32, 32, 8, 1)      # sub-sampling convolution (twins.py:870-925; there 8 taps of 1024): 8 taps of 256
+
+
 def test_convex_upsample(rt):
     kc.convex_upsample_case(rt)
 
