@@ -22,7 +22,7 @@ import torch
 
 from . import lib as L
 from .engine import Engine
-from .ops import PatchConvLayer, S2DConvLayer, TapSplitConvLayer, View
+from .ops import PatchConvLayer, S2DConvLayer, TapSplitConvLayer, TokenChain, View
 
 A = L
 K_LAT = 8          # cost_latent_token_num   configs/submission.py:30
@@ -229,6 +229,21 @@ class EngineF(Engine):
         self._add("ff.proj_inp", w[128:], b[128:])     # relu half
         self._build_attn_layer(sd, md + ".decoder_layer.cross_attend", False, wdir=True)
         u = md + ".update_block"
+        # the two halves of the flow-token path around its cross-attention as ONE launch each (csrc/token_chain.hip; 16-bit
+        # operand types): [flow_token_encoder.0 GELU, .2 (= query), norm1 + position code, q] and [proj + query, norm2,
+        # ffn.0 GELU, ffn.3 + x]   decoder.py:84-120, 237-255.  GVFI_F_TOKCHAIN=0 keeps the 5 + 4 separate launches.
+        self.chain_a = self.chain_c = None
+        if self.rt.precision in ("bf16", "fp16") and os.environ.get("GVFI_F_TOKCHAIN", "1") != "0":
+            ca_ = md + ".decoder_layer.cross_attend"
+            w2 = lambda k: sd[k + ".weight"].reshape(sd[k + ".weight"].shape[0], -1)
+            fe0, fe2 = md + ".flow_token_encoder.0", md + ".flow_token_encoder.2"
+            self.chain_a = TokenChain(self.rt, [w2(fe0), w2(fe2), w2(ca_ + ".q")],
+                                      [sd[fe0 + ".bias"], sd[fe2 + ".bias"], sd[ca_ + ".q.bias"]],
+                                      (sd[ca_ + ".norm1.weight"], sd[ca_ + ".norm1.bias"]), 1e-5, 1, act0=A.ACT_GELU)
+            self.chain_c = TokenChain(self.rt, [w2(ca_ + ".proj"), w2(ca_ + ".ffn.0"), w2(ca_ + ".ffn.3")],
+                                      [sd[ca_ + ".proj.bias"], sd[ca_ + ".ffn.0.bias"], sd[ca_ + ".ffn.3.bias"]],
+                                      (sd[ca_ + ".norm2.weight"], sd[ca_ + ".norm2.bias"]), 1e-5, 0, act1=A.ACT_GELU,
+                                      res2_from0=True)
         # wdir: the layers of the 32-iteration recurrence take the weights-direct variant of the LDS-DMA kernel
         self._conv(sd, u + ".encoder.convc1", cin_pad=max(self.rt.cp64(145), 192), wdir=True)     # = the pitch of the cost tensor
         self.layers[u + ".encoder.convf1"] = PatchConvLayer(self.rt, sd[u + ".encoder.convf1.weight"],
@@ -596,17 +611,23 @@ class EngineF(Engine):
                         (rt.flow_step(tapl, patl, None, co, fl, View(Xs, 126, 2), fc), co_alt)
                 # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
                 rtt.cost_lookup(vol_s, co, View(crt, 64, 81), rows, h8, w8)
-                t1 = tok._linear(md + ".flow_token_encoder.0", View(crt_rows, 64, 128), act=A.ACT_GELU)   # 81 taps + zeros
-                query = tok._linear(md + ".flow_token_encoder.2", t1)
-                # cross-attention of the one query against the map's 8 latent tokens   decoder.py:84-120
-                qn = rtt.layernorm(query, tok.ln[ca + ".norm1"], 1e-5)
-                rtt.pos_embed(co, rows, 1.0, 0.0, 64, qn, rows, True)
-                q = tok._linear(ca + ".q", qn)
-                a_ = tok._tok(rows, 64)
-                rtt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)
-                x = tok._linear(ca + ".proj", a_, x1=query, res=query)
-                y = rtt.layernorm(x, tok.ln[ca + ".norm2"], 1e-5)
-                tok._linear(ca + ".ffn.3", tok._linear(ca + ".ffn.0", y, act=A.ACT_GELU), out=View(crt_rows, 0, 64), res=x)
+                if tok.chain_a is not None and taps is None:
+                    query, q, a_ = tok._tok(rows, 64), tok._tok(rows, 64), tok._tok(rows, 64)
+                    rtt.token_chain(tok.chain_a, View(crt_rows, 64, 128), q, out1=query, coords=co, period=rows)
+                    rtt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)
+                    rtt.token_chain(tok.chain_c, a_, View(crt_rows, 0, 64), in1=query, res0=query)
+                else:
+                    t1 = tok._linear(md + ".flow_token_encoder.0", View(crt_rows, 64, 128), act=A.ACT_GELU)   # 81 taps + zeros
+                    query = tok._linear(md + ".flow_token_encoder.2", t1)
+                    # cross-attention of the one query against the map's 8 latent tokens   decoder.py:84-120
+                    qn = rtt.layernorm(query, tok.ln[ca + ".norm1"], 1e-5)
+                    rtt.pos_embed(co, rows, 1.0, 0.0, 64, qn, rows, True)
+                    q = tok._linear(ca + ".q", qn)
+                    a_ = tok._tok(rows, 64)
+                    rtt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)
+                    x = tok._linear(ca + ".proj", a_, x1=query, res=query)
+                    y = rtt.layernorm(x, tok.ln[ca + ".norm2"], 1e-5)
+                    tok._linear(ca + ".ffn.3", tok._linear(ca + ".ffn.0", y, act=A.ACT_GELU), out=View(crt_rows, 0, 64), res=x)
                 if tok is not self:
                     cvt(View(crt_rows, 0, 145), View(cr_rows, 0, 145), 145)
                 # GMAUpdateBlock   gru.py:130-160

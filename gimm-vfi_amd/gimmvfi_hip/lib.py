@@ -53,6 +53,26 @@ class ConvParams(C.Structure):
     ]
 
 
+class TokenChainParams(C.Structure):
+    """Mirror of ``gvfi_token_chain_params`` (include/gimmvfi_hip.h)."""
+
+    _fields_ = [
+        ("in0", C.c_void_p), ("ld0", C.c_int),
+        ("in1", C.c_void_p), ("ld1", C.c_int),
+        ("k0a", C.c_int),
+        ("wfrag", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("eps", C.c_float), ("ln_after", C.c_int),
+        ("coords", C.c_void_p), ("period", C.c_longlong),
+        ("act0", C.c_int), ("act1", C.c_int),
+        ("res0", C.c_void_p), ("ldr0", C.c_int),
+        ("res2_from0", C.c_int),
+        ("out1", C.c_void_p), ("ldo1", C.c_int),
+        ("out2", C.c_void_p), ("ldo2", C.c_int),
+        ("rows", C.c_longlong), ("dtype", C.c_int),
+    ]
+
+
 _CTYPES = {
     "int": C.c_int,
     "float": C.c_float,
@@ -64,7 +84,7 @@ def parse_header(path=HEADER):
     """Returns {name: (restype, [argtypes])} for every prototype in the header."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
-    src = re.sub(r"typedef struct \{.*?\} gvfi_conv_params;", " ", src, flags=re.S)
+    src = re.sub(r"typedef struct \{.*?\} gvfi_\w+_params;", " ", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"(const char\*|int)\s+(gvfi_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()

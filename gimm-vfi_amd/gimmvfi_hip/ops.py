@@ -128,6 +128,29 @@ class S2DConvLayer:
         self.inner.cin = kh * kw * cin      # real products per output (FLOP accounting)
 
 
+class TokenChain:
+    """Three linears 128 -> 64 -> 64 -> 64 (+ LayerNorm parameters) packed for gvfi_token_chain (csrc/token_chain.hip):
+    weights in MFMA-fragment order, fragment (layer, 32-row block mb, k-step kk) = 64 lanes x 8 values with lane l holding
+    W[32 mb + (l & 31)][16 kk + 8 (l >> 5) .. +8]; biases [3][64]; gamma / beta [64].  ws[0]: [64, K0 <= 128] (zero-padded
+    to 128 input features), ws[1], ws[2]: [64, 64]."""
+
+    def __init__(self, rt, ws, bs, ln, eps, ln_after, act0=L.ACT_NONE, act1=L.ACT_NONE, res2_from0=False):
+        assert rt.precision in ("bf16", "fp16") and len(ws) == 3
+        frs = []
+        for li, w in enumerate(ws):
+            k = 128 if li == 0 else 64
+            wp = torch.zeros(64, k, dtype=torch.float32)
+            assert w.shape[0] == 64 and w.shape[1] <= k, w.shape
+            wp[:, :w.shape[1]] = w.detach().float().cpu()
+            # [mb][row 32][kk][half][8] -> [mb][kk][half][row][8]
+            frs.append(wp.view(2, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1))
+        self.wfrag = torch.cat(frs).to(rt.tdtype).contiguous().to(rt.device)
+        self.bias = torch.stack([(torch.zeros(64) if b is None else b.detach().float().cpu()) for b in bs]).contiguous().to(rt.device)
+        self.ln_g = ln[0].detach().float().contiguous().to(rt.device)
+        self.ln_b = ln[1].detach().float().contiguous().to(rt.device)
+        self.eps, self.ln_after, self.act0, self.act1, self.res2_from0 = eps, ln_after, act0, act1, res2_from0
+
+
 class TapSplitConvLayer:
     """A KHxKW zero-padded stride-1 convolution with very few output channels, run as a 1x1 convolution to the
     KH*KW*Cout per-tap partial sums + gvfi_tap_sum (Runtime.tap_split_conv)."""
@@ -465,6 +488,43 @@ class Runtime:
         c = self.f32(n, h, w, 2)
         self._chk(self.lib.coords_init(c.data_ptr(), n, h, w, self.stream()), "coords_init")
         return c
+
+    def token_chain(self, ch, in0, out2, in1=None, res0=None, out1=None, coords=None, period=0):
+        """in0 / in1 / res0 / out1 / out2: Views of [rows, ld] token matrices (activation type); see gvfi_token_chain."""
+        p = L.TokenChainParams()
+        in0, out2 = V(in0), V(out2)
+        rows = in0.npix
+        p.in0, p.ld0, p.k0a = in0.ptr, in0.ld, in0.c
+        if in1 is not None:
+            in1 = V(in1)
+            assert in0.c + in1.c == 128 and in1.npix == rows
+            p.in1, p.ld1 = in1.ptr, in1.ld
+        else:
+            assert in0.c == 128
+            p.in1, p.ld1 = None, 0
+        p.wfrag, p.bias = ch.wfrag.data_ptr(), ch.bias.data_ptr()
+        p.ln_g, p.ln_b, p.eps, p.ln_after = ch.ln_g.data_ptr(), ch.ln_b.data_ptr(), ch.eps, ch.ln_after
+        if coords is not None:
+            assert coords.dtype == torch.float32 and coords.is_contiguous()
+            p.coords, p.period = coords.data_ptr(), period
+        else:
+            p.coords, p.period = None, 0
+        p.act0, p.act1, p.res2_from0 = ch.act0, ch.act1, int(ch.res2_from0)
+        if res0 is not None:
+            res0 = V(res0)
+            assert res0.c == 64 and not res0.is_f32
+            p.res0, p.ldr0 = res0.ptr, res0.ld
+        else:
+            p.res0, p.ldr0 = None, 0
+        if out1 is not None:
+            out1 = V(out1)
+            p.out1, p.ldo1 = out1.ptr, out1.ld
+        else:
+            p.out1, p.ldo1 = None, 0
+        assert out2.c == 64 and out2.npix == rows
+        p.out2, p.ldo2 = out2.ptr, out2.ld
+        p.rows, p.dtype = rows, self.dtype
+        self._chk(self.lib.token_chain(C.byref(p), self.stream()), "token_chain")
 
     def s2d_conv(self, layer, x, out, **kw):
         """x: contiguous [N, H, W, ld] activation tensor (H, W multiples of layer.k), out: [N, H/k, W/k, cout]."""

@@ -378,6 +378,34 @@ int gvfi_flow_to_image(const float* flow, long long img_stride, int n_img, int h
 const char* gvfi_version(void);
 int gvfi_device_ok(void);   /* 1 if a gfx950 device is present and usable */
 
+/* Per-token chain of three small linear layers (<= 128 -> 64 -> 64 -> 64 features) with a LayerNorm after layer
+ * `ln_after`, an optional LinearPositionEmbeddingSine of `coords` added behind it, GELUs and residuals: the two halves of
+ * the flow-token path of FlowFormer's MemoryDecoder iteration around its cross-attention (decoder.py:237-255 flow-token
+ * encoder + decoder.py:84-120 CrossAttentionLayer norm1 / q;  proj / norm2 / ffn) in ONE launch each instead of 5 + 4
+ * (csrc/token_chain.hip; GVFI_BF16 / GVFI_F16 only).  Row r of the first layer's input = [in0[r][0:k0a] | in1[r][0:128-k0a]].
+ *   y0 = act0(W0 x + b0) (+ res0[r]);  [ln_after == 0: LN + position code]
+ *   y1 = act1(W1 y0' + b1) -> out1 (optional);  [ln_after == 1: LN + position code]
+ *   y2 = W2 y1' + b2 (+ y0 when res2_from0) -> out2.
+ * Every intermediate is rounded to the activation type where the unfused sequence stores a tensor.  wfrag: the three weight
+ * matrices in MFMA order, fragment (layer, 32-row block mb, k-step kk) = 64 lanes x 8 values, lane l holds
+ * W[32 mb + (l & 31)][16 kk + 8 (l >> 5) .. +8]; layer 0 has 2 x 8 fragments (K = 128), layers 1 / 2 have 2 x 4. */
+typedef struct {
+    const void* in0; int ld0;
+    const void* in1; int ld1;
+    int k0a;
+    const void* wfrag;
+    const float* bias;                  /* [3][64] */
+    const float* ln_g; const float* ln_b; float eps; int ln_after;
+    const float* coords; long long period;      /* position code of coords[(r % period)] (x, y), or NULL */
+    int act0, act1;                     /* GVFI_ACT_NONE or GVFI_ACT_GELU */
+    const void* res0; int ldr0;
+    int res2_from0;
+    void* out1; int ldo1;
+    void* out2; int ldo2;
+    long long rows; int dtype;
+} gvfi_token_chain_params;
+int gvfi_token_chain(const gvfi_token_chain_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

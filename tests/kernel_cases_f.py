@@ -5,7 +5,8 @@ import torch
 import torch.nn.functional as F
 
 import gimmvfi_f_oracle as forc
-from gimmvfi_hip.ops import View
+from gimmvfi_hip import lib as L
+from gimmvfi_hip.ops import TokenChain, View
 from kernel_cases import tol
 
 
@@ -204,3 +205,57 @@ def tile_softmax_case(rt):
     got = y.float().cpu()
     assert float((got[:, :ncol] - x.softmax(-1)).abs().max()) <= tol(rt, 1.0)
     assert float(got[:, ncol:].abs().max()) == 0.0
+
+
+def token_chain_case(rt, rows=75):
+    """gvfi_token_chain (csrc/token_chain.hip) against the unfused arithmetic in torch, rounding to the activation type where
+    the separate launches store a tensor: (A) flow-token encoder + norm1 + position code + q, (C) proj + residual, norm2, ffn
+    + residual (decoder.py:84-120, 237-255).  Ragged last wave (rows % 32 != 0), inputs / outputs that are channel slices
+    of wider tensors."""
+    if rt.precision == "fp32":
+        return      # 16-bit operand types only (the float engine keeps the separate launches)
+    g = _g(7)
+    dev = rt.device
+    rd = lambda t: _r(rt, t)
+    W0, W1, W2 = rd(torch.randn(64, 81, generator=g) / 9), rd(torch.randn(64, 64, generator=g) / 8), rd(torch.randn(64, 64, generator=g) / 8)
+    Wp = rd(torch.randn(64, 128, generator=g) / 11)
+    b = [torch.randn(64, generator=g) * 0.1 for _ in range(3)]
+    gam, bet = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    x = torch.zeros(rows, 192)
+    x[:, 64:145] = torch.randn(rows, 81, generator=g)
+    xa = x.to(rt.tdtype).to(dev)
+    coords = (torch.rand(rows, 2, generator=g) * 40).contiguous()
+    # ---- (A)
+    ch = TokenChain(rt, [W0, W1, W2], b, (gam, bet), 1e-5, 1, act0=L.ACT_GELU)
+    q = torch.full((rows, 72), 3.0, dtype=rt.tdtype, device=dev)
+    query = torch.zeros(rows, 64, dtype=rt.tdtype, device=dev)
+    rt.token_chain(ch, View(xa, 64, 128), View(q, 8, 64), out1=query, coords=coords.to(dev), period=rows)
+    xin = xa.float().cpu()[:, 64:192]
+    W0p = torch.zeros(64, 128)
+    W0p[:, :81] = W0
+    t1 = rd(F.gelu(xin @ W0p.t() + b[0]))
+    qr = rd(t1 @ W1.t() + b[1])
+    qn = rd(F.layer_norm(qr, (64,), gam, bet, 1e-5))
+    c = torch.arange(64)
+    part, f = c // 16, (c % 16).float()
+    ang = 3.14 * torch.where(part[None] < 2, coords[:, 0:1], coords[:, 1:2]) * f[None] / 200.0
+    qn = rd(qn + torch.where((part % 2 == 1)[None], torch.cos(ang), torch.sin(ang)))
+    qq = rd(qn @ W2.t() + b[2])
+    got_q = q.float().cpu()
+    assert float((got_q[:, :8] - 3.0).abs().max()) == 0.0          # nothing outside the slice is written
+    t = tol(rt, float(qq.abs().max()))
+    assert float((query.float().cpu() - qr).abs().max()) <= t
+    assert float((got_q[:, 8:] - qq).abs().max()) <= 2 * t, float((got_q[:, 8:] - qq).abs().max())
+    # ---- (C)
+    ch2 = TokenChain(rt, [Wp, W1, W2], b, (gam, bet), 1e-5, 0, act1=L.ACT_GELU, res2_from0=True)
+    a_ = rd(torch.randn(rows, 64, generator=g)).to(rt.tdtype).to(dev)
+    out = torch.full((rows, 192), 5.0, dtype=rt.tdtype, device=dev)
+    rt.token_chain(ch2, a_, View(out, 0, 64), in1=query, res0=query)
+    qy = query.float().cpu()
+    xx = rd(torch.cat([a_.float().cpu(), qy], 1) @ Wp.t() + b[0] + qy)
+    y = rd(F.layer_norm(xx, (64,), gam, bet, 1e-5))
+    ff = rd(F.gelu(y @ W1.t() + b[1]))
+    ref = rd(ff @ W2.t() + b[2] + xx)
+    go = out.float().cpu()
+    assert float((go[:, 64:] - 5.0).abs().max()) == 0.0
+    assert float((go[:, :64] - ref).abs().max()) <= 2 * tol(rt, float(ref.abs().max())), float((go[:, :64] - ref).abs().max())

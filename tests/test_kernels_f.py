@@ -44,6 +44,8 @@ def _all(rt):
     kf.attn_global_mfma_case(rt, hd=32)
     kf.xqk_case(rt)
     kf.tile_softmax_case(rt)
+    kf.token_chain_case(rt)
+    kf.token_chain_case(rt, rows=32)
 
 
 def test_flowformer_kernels_emulated(rt_sim, monkeypatch):
