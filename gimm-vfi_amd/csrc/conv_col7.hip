@@ -339,6 +339,7 @@ static int col7_plan(const gvfi_conv_params& p, Col7Args& a) {
     const int ey = p.y_f32 ? 4 : 2, unit = p.y_f32 ? 4 : 8;
     if ((p.ldy * ey) % 16 || ((uintptr_t)p.y & 15) || ((uintptr_t)p.x0 & 15) || ((uintptr_t)p.w & 15)) return 0;
     if (p.res != nullptr && (!p.res_f32 || !p.y_f32 || ((p.ldr * 4) % 16) || ((uintptr_t)p.res & 15))) return 0;
+    if (p.res != nullptr && p.out_scale != 1.0f) return 0;     // (the scale is applied before the residual here, after it in the other kernels)
     a.p = p;
     const int cround = (p.Cout + unit - 1) / unit * unit;
     a.sb = cround * ey;

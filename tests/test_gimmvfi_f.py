@@ -96,7 +96,10 @@ def test_engine_f_sim_flow_precision_policy(sd_f):
     assert maxabs(mixed["raft_flow"], gold["raft_flow"]) < 2e-3          # the float flow estimator
     p_mixed = psnr(mixed["imgt_pred"][0], gold["imgt_pred_0"])
     assert p_mixed > 50.0, p_mixed                                       # bf16 synthesis on exact flows
-    for pol in ("tok", "upd", "enc", "dec:f16", "upd:f16,tok"):      # every stage-boundary conversion of the launch list
+    # every stage-boundary conversion of the launch list: float encoder, the default (half decoder), a float token path feeding a
+    # half update block (the single-stage policies "tok" / "upd" exercise the same conversions; they ran here until the CPU
+    # suite needed trimming)
+    for pol in ("enc", "dec:f16", "upd:f16,tok"):
         part = EngineF(SimRuntime("bf16"), sd_f, flow_precision=pol).forward(x, coords, ts, iters=None)
         assert psnr(part["imgt_pred"][0], gold["imgt_pred_0"]) > 40.0, pol
     # an fp32 engine ignores the policy (everything is float already)
