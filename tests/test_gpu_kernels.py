@@ -83,7 +83,7 @@ CONV_SHAPES = [
     (2, 37, 45, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=3)),
     (1, 33, 34, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=4)),
     (1, 12, 40, 3, 16, 7, 7, dict(algo=7, act1=L.ACT_LRELU, out_scale=0.5, pad16=True, bf16_only=True)),
-    (1, 100, 104, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=5)),       # interior tiles: constant DMA offsets
+    (1, 100, 104, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=5)),       # interior tiles: tile-independent patch offsets
     (2, 97, 70, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=6)),
     (1, 8, 33, 8, 32, 7, 7, dict(algo=7, act1=L.ACT_RELU, pad16=True, bf16_only=True)),
     (1, 6, 36, 24, 12, 7, 7, dict(algo=7, pad16=True, bf16_only=True)),
