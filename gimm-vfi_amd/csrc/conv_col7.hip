@@ -50,15 +50,12 @@ template <int GPT> struct Col7Geom {
     static constexpr int G = 7 * GPT;                                    // K groups of 16 bytes: (ky, channel group)
     static constexpr int NS = (G + 3) / 4;                               // MFMA steps of four groups
     static constexpr int UNITS = C7_P * RU;                              // the patch is ONE contiguous run of 16-byte units
-    static constexpr int NCHUNK = (UNITS + 63) / 64;                     // ... = this many 1 KiB LDS-DMA instructions
-    static constexpr int NJ = (NCHUNK + 3) / 4;                          // per wave
-    static constexpr int PATCH_BYTES = NCHUNK * 1024;
 };
 
 template <int MB, int GPT>
 __global__ void __launch_bounds__(256) conv_col7_kernel(Col7Args a) {
     typedef Col7Geom<GPT> GE;
-    constexpr int PITCH = GE::PITCH, ROW = GE::ROW, G = GE::G, NS = GE::NS, RU = GE::RU, NJ = GE::NJ;
+    constexpr int PITCH = GE::PITCH, ROW = GE::ROW, G = GE::G, NS = GE::NS, RU = GE::RU;
     GVFI_DYN_SMEM(smem);
     const gvfi_conv_params& p = a.p;
     const int tid = threadIdx.x;
@@ -350,7 +347,7 @@ static int col7_plan(const gvfi_conv_params& p, Col7Args& a) {
     const int gpt = p.c0 / 8, mb = p.Cout > 16 ? 2 : 1;
     const int units = C7_P * (C7_P * gpt + 1);
     const int ns = (7 * gpt + 3) / 4;
-    const int patch = (units + 63) / 64 * 1024;             // whole 1 KiB LDS-DMA chunks
+    const int patch = (units * 16 + 1023) & ~1023;          // (16-byte units, rounded up to 1 KiB)
     if ((long long)C7_P * p.W * p.ld0 * 2 >= 0x7fff0000ll || (long long)C7_T * p.Wo * (p.ldy * ey > p.ldr * 4 ? p.ldy * ey : p.ldr * 4) >= 0x7fff0000ll) return 0;   // 32-bit offsets inside a tile
     a.off_w = patch;
     a.off_s = a.off_w + ns * 7 * mb * 1024;
