@@ -77,6 +77,26 @@ def test_engine_f_sim_bf16(sd_f):
     assert float(d.mean()) < 0.5
 
 
+def test_engine_f_sim_token_chains_equal_the_separate_launches(sd_f, monkeypatch):
+    """The fused flow-token chains (gvfi_token_chain, default) against the 5 + 4 separate launches they replace
+    (GVFI_F_TOKCHAIN=0), same emulated engine, three decoder iterations: the flows agree to the rounding of a few bf16
+    operands (both paths round to the activation type at the same points; only the LayerNorm reductions differ in order)."""
+    from gimmvfi_hip.engine_f import EngineF
+    from sim_runtime import SimRuntime
+
+    meta, _ = load_golden("f_128x192_t050")
+    x, coords, ts = golden_inputs(meta)
+    outs = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("GVFI_F_TOKCHAIN", sw)
+        eng = EngineF(SimRuntime("bf16"), sd_f)
+        assert (eng.chain_a is not None) == (sw == "1")
+        outs[sw] = eng.forward(x, coords, ts, iters=3)
+    d = (outs["1"]["raft_flow"].float() - outs["0"]["raft_flow"].float()).abs()
+    assert float(d.max()) < 5e-2 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
+    assert psnr(outs["1"]["imgt_pred"][0], outs["0"]["imgt_pred"][0]) > 55.0
+
+
 def test_engine_f_sim_flow_precision_policy(sd_f):
     """bf16 engine with the flow estimator's stages in float (GIMMVFI_F(flow_precision=...)): with all three stages in
     float the flows are those of the fp32 engine, the frames those of bf16 synthesis; a single float stage still runs the
