@@ -12,6 +12,10 @@ multi-GPU = frame pairs shard across ranks (weak scaling: 8 pairs per rank), no 
 roofline     : dominant kernel = the convolution kernel with the largest total time per step (since round 2 the
                halo-staged 3x3 kernel conv_p3x3.hip of the decoder ResBlocks) -- algorithmic FLOPs of its launches /
                their HIP-event durations, measured on the launch stream in an eager pass right after the timed steps.
+configs      : with the default workload the run then times the other BASELINE.json configurations the same way (fewer
+               steps) and reports them under "configs": R 2K DS 0.5 8x, R 4K DS 0.25 8x, F 448x256 B=8, F 4K DS 0.25 8x and
+               R 448x256 in fp32 mode (the reference's own arithmetic); N > 1: the two configurations BASELINE.json defines on
+               8 GPUs (R 2K, F 4K), pair-sharded with the same result gather.  `--configs none` = headline only.
 cpu_baseline : the CPU oracle (port of the reference algorithm, oracle/gimmvfi_r_oracle.py) timed on the
                host cores on a bounded sample (B=1 pair of the same workload; thread-count sweep + median), rank 0,
                N=1 only.
@@ -44,7 +48,7 @@ def _free_port():
 def self_launch(args, argv):
     """`python bench.py --gpus N` (N > 1) outside a torchrun world: start N ranks of this script on this node and pass
     rank 0's JSON line through.  Returns the launcher's exit code."""
-    if not args.stub:
+    if not (args.stub or args.dry):
         have = torch.cuda.device_count()
         if have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node", file=sys.stderr)
@@ -73,6 +77,176 @@ def stub_step_factory(world, rank):
     return step
 
 
+GF_PER_FRAME = {
+    # whole-path figure SURVEY.md 8(d) asks for: MINIMAL algorithmic FLOPs per interpolated frame (redundant
+    # reference work removed).  R 448x256 T=1: 2 065 GF; R 2K DS 0.5 T=7: 7 917 GF/frame; R 4K DS 0.25 T=7:
+    # 8 272 - 213 (the same per-pair redundancies as at 2K: duplicate fnet pass, 19/20 mask heads, transposed-volume GEMM,
+    # hoisted up-sample stacks) = 8 059 GF/frame.  F 448x256: 2 729 GF measured with FlopCounterMode on the reference
+    # (oracle/ref_harness.py, B=1) minus the duplicate feature-encoder pass (24.9), the mask heads of decoder iterations
+    # 1..31 (98.3) and the transposed-volume GEMM (1.6) = 2 604 GF
+    ("r", 256, 448, 2, None): 2065, ("f", 256, 448, 2, None): 2604,
+    ("r", 1088, 2048, 8, 0.5): 7917, ("r", 2176, 4096, 8, 0.25): 8059,
+}
+
+# The BASELINE.json configurations besides the headline (configs[1]); "id" = index into BASELINE.json's list
+EXTRA_CONFIGS = [
+    {"id": 2, "model": "r", "batch": 1, "height": 1088, "width": 2048, "ds": 0.5, "n_interp": 8, "precision": "bf16", "sharded": True},
+    {"id": 2.5, "model": "r", "batch": 1, "height": 2176, "width": 4096, "ds": 0.25, "n_interp": 8, "precision": "bf16", "sharded": False},
+    {"id": 3, "model": "f", "batch": 8, "height": 256, "width": 448, "ds": 1.0, "n_interp": 2, "precision": "bf16", "sharded": False},
+    {"id": 4, "model": "f", "batch": 1, "height": 2176, "width": 4096, "ds": 0.25, "n_interp": 8, "precision": "bf16", "sharded": True},
+    {"id": 1.5, "model": "r", "batch": 8, "height": 256, "width": 448, "ds": 1.0, "n_interp": 2, "precision": "fp32", "sharded": False},
+]
+
+
+def workload_name(c):
+    return (f"GIMM-VFI-{c['model'].upper()} {c['width']}x{c['height']} batch={c['batch']} pairs/GPU, {c['n_interp']}x interpolation "
+            f"(t=i/{c['n_interp']}), DS_SCALE={c['ds']:g}, seeded random-init weights")
+
+
+def event_overhead_ms(dev):
+    """What an event pair adds to a back-to-back launch (the two timestamp packets), calibrated in-process on a backlogged
+    stream: 200 small kernels inside ONE pair against the same 200 kernels each inside its own pair.  It is taken off
+    every launch: ~2.5 us is nothing for the 0.85 ms hot kernel but 12 % of the ~380 RAFT launches per step
+    (rocprofv3: 21.6 us average; uncorrected pairs read 24.5 us)."""
+    cal = torch.zeros(1 << 20, device=dev)
+    torch.cuda._sleep(30_000_000)
+    ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ca.record()
+    for _ in range(200):
+        cal.add_(1.0)
+    cb.record()
+    pairs = []
+    for _ in range(200):
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        cal.add_(1.0)
+        c1.record()
+        pairs.append((c0, c1))
+    torch.cuda.synchronize()
+    return max(sum(c0.elapsed_time(c1) for c0, c1 in pairs) / 200 - ca.elapsed_time(cb) / 200, 0.0)
+
+
+def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None, ev_over_ms=None):
+    """One workload c (model / batch / frame size / ds / n_interp / precision): the timed region of the driver contract
+    (timed_steps), then -- rank 0 -- an instrumented eager pass for the per-kernel roofline figures.  Returns the result
+    dict on rank 0 (None elsewhere)."""
+    from gimmvfi_hip.model import GIMMVFI_F, GIMMVFI_R
+    from gimmvfi_hip.params import random_state_dict, random_state_dict_f
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    B, H, W, NI = c["batch"], c["height"], c["width"], c["n_interp"]
+    ds = None if c["ds"] == 1.0 else c["ds"]
+    if c["model"] == "f":
+        model = GIMMVFI_F(precision=c["precision"], flow_precision=flow_precision)
+        model.load_state_dict(random_state_dict_f(0), strict=True)
+    else:
+        model = GIMMVFI_R(precision=c["precision"])
+        model.load_state_dict(random_state_dict(0), strict=True)
+    model = model.to(dev).eval()
+    x = synthetic_pairs(B, H, W, seed=100 + rank).to(dev)
+    # src/video_Nx.py:164-181: one coordinate grid / timestep per inserted frame, flow at ds x resolution
+    coords = [(model.sample_coord_input(B, (H, W), [i / NI], device=dev, upsample_ratio=c["ds"]), None) for i in range(1, NI)]
+    ts = [(i / NI) * torch.ones(B, device=dev) for i in range(1, NI)]
+    rt = model.engine(dev).rt
+    gather_buf = None
+    if world > 1 and rank == 0:
+        shp = (B, H, W, 3) if NI == 2 else (B, NI - 1, H, W, 3)
+        gather_buf = [torch.empty(shp, dtype=torch.uint8, device=dev) for _ in range(world)]
+
+    def step():
+        out = model(x, coords, t=ts, ds_factor=ds)
+        frames = rt.frames_to_u8(out["imgt_pred"][0]) if NI == 2 else torch.stack([rt.frames_to_u8(f) for f in out["imgt_pred"]], 1)
+        if world > 1:
+            dist.gather(frames, gather_buf, dst=0)   # the path's only collective: result gather to rank 0
+        return frames
+
+    dt = timed_steps(step, steps, warmup, world, torch.cuda.synchronize)
+    dt_rank = dt
+    # Roofline pass: the timed steps above replay a hipGraph (no host work between kernels), and HIP events cannot
+    # be recorded per launch inside a graph replay, so the per-launch durations of the dominant kernel come from
+    # an instrumented eager pass of the same step right after the timed region (rank 0, same inputs, same stream).
+    ev = []
+    ev_steps = max(1, min(steps, 3 if H * W <= 256 * 448 else 1))
+    if rank == 0:
+        rt.ev_log = ev
+        rt.ev_shapes = bool(shapes)
+        for _ in range(ev_steps):
+            # keep the stream backlogged: the host needs ~15 us per launch in this eager pass, the ~380 RAFT kernels of a step
+            # run ~20 us each -- without a head start the GPU drains the queue there and every event pair also brackets
+            # the host's submit latency (the 20 us kernels read 24 us; rocprofv3 says 21.6).  A 25 ms spin kernel in front of
+            # the step lets the host run ahead of the GPU for the whole step.
+            torch.cuda._sleep(50_000_000)
+            model(x, coords, t=ts, ds_factor=ds)
+        torch.cuda.synchronize()
+        rt.ev_log = None
+    per_rank = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [round(float(v.item()) / steps * 1e3, 3) for v in allt]
+        dt = max(float(v.item()) for v in allt)
+    res = None
+    if rank == 0:
+        frames = world * B * (NI - 1) * steps       # N-1 interpolated frames per pair per step
+        value = frames / dt
+        if ev_over_ms is None:
+            ev_over_ms = event_overhead_ms(dev)
+        agg = {}
+        for tag, fl, e0, e1 in ev:
+            a = agg.setdefault(tag, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += max(e0.elapsed_time(e1) - ev_over_ms, 1e-3) * 1e-3
+            a[2] += 1
+        if shapes:
+            rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+            with open(shapes, "w") as f:
+                f.write("| kernel / shape | launches/step | ms/step | avg_us | TFLOP/s |\n|---|---|---|---|---|\n")
+                for tg, (fl_, sec_, cnt_) in rows:
+                    f.write(f"| {tg} | {cnt_ // ev_steps} | {sec_ / ev_steps * 1e3:.3f} | {sec_ / cnt_ * 1e6:.1f} | {fl_ / sec_ / 1e12:.1f} |\n")
+            kagg = {}
+            for tg, v in agg.items():
+                a = kagg.setdefault(tg.split(" ")[0], [0.0, 0.0, 0])
+                for i in range(3):
+                    a[i] += v[i]
+            agg = kagg
+        peak = MFMA_PEAK_TFLOPS[c["precision"]]
+        ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        tag, (fl, sec, cnt) = ranked[0]
+        achieved = fl / sec / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": tag, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "launches_per_step": cnt // ev_steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+            "avg_launch_gflop": round(fl / cnt / 1e9, 3),
+            "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / ev_steps * 1e3, 3),
+            # the convolution kernel families behind the dominant one (the launch-bound recurrence is the second)
+            "next_kernels": [{"kernel": tg, "ms_per_step": round(s_ / ev_steps * 1e3, 3), "launches_per_step": n_ // ev_steps,
+                              "achieved": round(f_ / s_ / 1e12, 1), "frac": round(f_ / s_ / 1e12 / peak, 4)}
+                             for tg, (f_, s_, n_) in ranked[1:4]],
+        }
+        gf = GF_PER_FRAME.get((c["model"], H, W, NI, ds)) if c["precision"] == "bf16" else None
+        if gf is not None:
+            path_tf = gf * 1e9 * value / world / 1e12
+            roofline["path"] = {"minimal_gflop_per_frame": gf, "achieved": round(path_tf, 1), "unit": "TFLOP/s per GPU",
+                                "frac": round(path_tf / peak, 4)}
+        res = {"value": round(value, 3), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+               "dtype": c["precision"], "workload": workload_name(c), "roofline": roofline, "ev_over_ms": ev_over_ms,
+               "ev_steps": ev_steps, "flow_iters": 20 if c["model"] == "r" else 32,
+               "gather_bytes_per_rank_per_step": B * (NI - 1) * H * W * 3 if world > 1 else 0}
+        if per_rank is not None:
+            res["ms_per_step_per_rank"] = per_rank
+        if c["model"] == "f":
+            res["flow_precision"] = model.flow_precision
+    # captured graphs hold their intermediates in private pools (GBs at 2K / 4K): release them before the next workload
+    del model, step, x, coords, ts, gather_buf
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,10 +265,19 @@ def main():
                     help="(--model f) precision policy of the flow estimator: 'dec:f16' (model default: decoder with IEEE-half operands, "
                          ">= 40 dB against the reference everywhere), 'bf16', 'dec' (float decoder), 'fp32', or a stage list -- "
                          "GIMMVFI_F.__init__")
+    ap.add_argument("--configs", default="auto", choices=["auto", "all", "none"],
+                    help="the other BASELINE.json configurations, reported under 'configs' of the same JSON line: auto = with the "
+                         "default workload only (N = 1: all of them + an fp32-mode line; N > 1: the two 8-GPU configurations)")
+    ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--extra-warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default=None, help="write a per-conv-shape time table (markdown) to this path")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test: CPU + gloo, a stub step (tests/test_host_logic.py); never a measurement")
+    ap.add_argument("--dry", action="store_true",
+                    help="(N > 1) gather rehearsal on ONE GPU: rank 0 runs the real step on cuda:0, ranks 1..N-1 are CPU processes that "
+                         "contribute uint8 frames of the real shape over gloo -- exercises the sharded step's bookkeeping "
+                         "(gather buffers, max-over-ranks timing, the JSON line) with real frame shapes; never a scaling measurement")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -106,6 +289,8 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
     if args.stub:
         return stub_main(args, world, rank)
+    if args.dry:
+        return dry_main(args, world, rank)
     if torch.cuda.device_count() <= local:
         sys.exit(f"bench.py: rank {rank} needs GPU {local} but {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
@@ -115,167 +300,81 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
         assert dist.get_world_size() == world
 
-    from gimmvfi_hip.model import GIMMVFI_F, GIMMVFI_R
-    from gimmvfi_hip.params import random_state_dict, random_state_dict_f
-    from gimmvfi_hip.synth import synthetic_pairs
-
-    B, H, W = args.batch, args.height, args.width
-    if args.model == "f":
-        model = GIMMVFI_F(precision=args.precision, flow_precision=args.flow_precision)
-        model.load_state_dict(random_state_dict_f(0), strict=True)
-    else:
-        model = GIMMVFI_R(precision=args.precision)
-        model.load_state_dict(random_state_dict(0), strict=True)
-    model = model.to(dev).eval()
-    x = synthetic_pairs(B, H, W, seed=100 + rank).to(dev)
-    # src/video_Nx.py:164-181: one coordinate grid / timestep per inserted frame, flow at ds x resolution
-    NI = args.n_interp
-    ds = None if args.ds == 1.0 else args.ds
-    coords = [(model.sample_coord_input(B, (H, W), [i / NI], device=dev, upsample_ratio=args.ds), None) for i in range(1, NI)]
-    ts = [(i / NI) * torch.ones(B, device=dev) for i in range(1, NI)]
-    eng = model.engine(dev)
-    rt = eng.rt
-    gather_buf = None
-    if world > 1 and rank == 0:
-        shp = (B, H, W, 3) if NI == 2 else (B, NI - 1, H, W, 3)
-        gather_buf = [torch.empty(shp, dtype=torch.uint8, device=dev) for _ in range(world)]
-
-    def step():
-        out = model(x, coords, t=ts, ds_factor=ds)
-        frames = rt.frames_to_u8(out["imgt_pred"][0]) if NI == 2 else torch.stack([rt.frames_to_u8(f) for f in out["imgt_pred"]], 1)
-        if world > 1:
-            dist.gather(frames, gather_buf, dst=0)   # the path's only collective: result gather to rank 0
-        return frames
-
-    dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize)
-    # Roofline pass: the timed steps above replay a hipGraph (no host work between kernels), and HIP events cannot
-    # be recorded per launch inside a graph replay, so the per-launch durations of the dominant kernel come from
-    # an instrumented eager pass of the same step right after the timed region (rank 0, same inputs, same stream).
-    ev = []
-    if rank == 0:
-        rt.ev_log = ev
-        rt.ev_shapes = bool(args.shapes)
-        ev_steps = max(1, min(args.steps, 3))
-        for _ in range(ev_steps):
-            # keep the stream backlogged: the host needs ~15 us per launch in this eager pass, the ~380 RAFT kernels of a step
-            # run ~20 us each -- without a head start the GPU drains the queue there and every event pair also brackets
-            # the host's submit latency (the 20 us kernels read 24 us; rocprofv3 says 21.6).  A 25 ms spin kernel in front of
-            # the step lets the host run ahead of the GPU for the whole step.
-            torch.cuda._sleep(50_000_000)
-            model(x, coords, t=ts, ds_factor=ds)
-        torch.cuda.synchronize()
-        rt.ev_log = None
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    head = {"id": 1, "model": args.model, "batch": args.batch, "height": args.height, "width": args.width, "ds": args.ds,
+            "n_interp": args.n_interp, "precision": args.precision}
+    default_workload = (args.model, args.batch, args.height, args.width, args.ds, args.n_interp, args.precision) == \
+        ("r", 8, 256, 448, 1.0, 2, "bf16")
+    r = measure(head, args.steps, args.warmup, world, rank, dev, shapes=args.shapes, flow_precision=args.flow_precision)
+    extras = []
+    if args.configs == "all" or (args.configs == "auto" and default_workload and not args.shapes):
+        for c in EXTRA_CONFIGS:
+            if world > 1 and not c["sharded"]:
+                continue
+            try:
+                e = measure(c, args.extra_steps, args.extra_warmup, world, rank, dev, ev_over_ms=None if r is None else r["ev_over_ms"])
+            except Exception as ex:  # a failed extra must not cost the headline its line
+                e = {"error": f"{type(ex).__name__}: {ex}"[:300], "workload": workload_name(c)} if rank == 0 else None
+                torch.cuda.empty_cache()
+            if rank == 0:
+                e["baseline_config"] = {2: "configs[2]", 2.5: "configs[2]/[4] frame size: R at 4K DS 0.25", 3: "configs[3]", 4: "configs[4]",
+                                        1.5: "configs[1] in fp32 mode (the reference's own arithmetic)"}[c["id"]]
+                e.pop("ev_over_ms", None)
+                extras.append(e)
 
     if rank == 0:
-        frames = world * B * (NI - 1) * args.steps       # N-1 interpolated frames per pair per step
-        value = frames / dt
-        # ---- roofline of the dominant kernel from the event log of the timed steps
-        # What an event pair adds to a back-to-back launch (the two timestamp packets), calibrated in-process on a backlogged
-        # stream: 200 small kernels inside ONE pair against the same 200 kernels each inside its own pair.  It is taken off
-        # every launch: ~2.5 us is nothing for the 0.85 ms hot kernel but 12 % of the ~380 RAFT launches per step
-        # (rocprofv3: 21.6 us average; uncorrected pairs read 24.5 us).
-        cal = torch.zeros(1 << 20, device=dev)
-        torch.cuda._sleep(30_000_000)
-        ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ca.record()
-        for _ in range(200):
-            cal.add_(1.0)
-        cb.record()
-        pairs = []
-        for _ in range(200):
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            cal.add_(1.0)
-            c1.record()
-            pairs.append((c0, c1))
-        torch.cuda.synchronize()
-        ev_over_ms = max(sum(c0.elapsed_time(c1) for c0, c1 in pairs) / 200 - ca.elapsed_time(cb) / 200, 0.0)
-        agg = {}
-        for tag, fl, e0, e1 in ev:
-            a = agg.setdefault(tag, [0.0, 0.0, 0])
-            a[0] += fl
-            a[1] += max(e0.elapsed_time(e1) - ev_over_ms, 1e-3) * 1e-3
-            a[2] += 1
-        if args.shapes:
-            rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-            with open(args.shapes, "w") as f:
-                f.write("| kernel / shape | launches/step | ms/step | avg_us | TFLOP/s |\n|---|---|---|---|---|\n")
-                for tg, (fl_, sec_, cnt_) in rows:
-                    f.write(f"| {tg} | {cnt_ // ev_steps} | {sec_ / ev_steps * 1e3:.3f} | {sec_ / cnt_ * 1e6:.1f} | {fl_ / sec_ / 1e12:.1f} |\n")
-            kagg = {}
-            for tg, v in agg.items():
-                a = kagg.setdefault(tg.split(" ")[0], [0.0, 0.0, 0])
-                for i in range(3):
-                    a[i] += v[i]
-            agg = kagg
-        dom = max(agg.items(), key=lambda kv: kv[1][1])
-        tag, (fl, sec, cnt) = dom
-        peak = MFMA_PEAK_TFLOPS[args.precision]
-        achieved = fl / sec / 1e12
+        B, H, W, NI = args.batch, args.height, args.width, args.n_interp
+        ds = None if args.ds == 1.0 else args.ds
+        roofline = r["roofline"]
+        ev_over_ms = r.pop("ev_over_ms")
         # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
-        # figure is the committed measurement of tools/pmc_hotconv.sh (FETCH_SIZE doubled per the gfx950 note of
+        # figure is the committed measurement of tools/evidence.sh pmc (FETCH_SIZE doubled per the gfx950 note of
         # MI355X_MICROARCH.md + WRITE_SIZE), valid for the default workload's 256->256 3x3 layer only
         traffic, pmc = None, None
-        pmc_file = {"conv_igemm_glds_kernel<bf16,256,256": "r2_hotconv_pmc.json", "conv_p3x3_kernel<bf16,256,256": "r2_p3x3_pmc.json"}
-        pmc_name = next((v for k_, v in pmc_file.items() if tag.startswith(k_)), "none")
+        tag = roofline["kernel"]
+        pmc_file = {"conv_igemm_glds_kernel<bf16,256,256": ["r2_hotconv_pmc.json"],
+                    "conv_p3x3_kernel<bf16,256,256": ["r4_p3x3_pmc.json", "r2_p3x3_pmc.json"]}
+        cands = next((v for k_, v in pmc_file.items() if tag.startswith(k_)), [])
+        pmc_name = next((n_ for n_ in cands if os.path.isfile(os.path.join(ROOT, "profiles", n_))), "none")
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-        if os.path.isfile(pmc_path) and args.model == "r" and (B, H, W, NI, ds) == (8, 256, 448, 2, None):
+        if os.path.isfile(pmc_path) and default_workload:
             pmc = json.load(open(pmc_path))
             traffic = pmc["hbm_bytes_per_launch"]
-        roofline = {
-            "bound": "mfma", "kernel": tag, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": (f"HBM bytes/launch of the 256->256 layer from profiles/{pmc_name} (rocprofv3 PMC passes of "
-                             "tools/r2_call10.sh, FETCH_SIZE x2 + WRITE_SIZE); algorithmic 0.94 GB" if traffic is not None
-                             else "no PMC pass for this workload"),
-            "launches_per_step": cnt // ev_steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
-            "avg_launch_gflop": round(fl / cnt / 1e9, 3),
-            "all_conv_ms_per_step": round(sum(a[1] for a in agg.values()) / ev_steps * 1e3, 3),
-            "timing": f"HIP events around each launch, eager pass of {ev_steps} steps (each behind a 25 ms spin kernel, so the "
-                      "stream stays backlogged and a pair brackets only its kernel) after the timed graph-replay region; "
-                      f"{ev_over_ms * 1e3:.2f} us per pair (calibrated in-process: what a pair adds to a back-to-back launch) taken off",
-        }
-        # whole-path figure SURVEY.md 8(d) asks for: MINIMAL algorithmic FLOPs per interpolated frame (redundant
-        # reference work removed) x frames/s against the same dense peak.  R 448x256 T=1: 2 065 GF; R 2K DS 0.5 T=7:
-        # 7 917 GF/frame; R 4K DS 0.25 T=7: 8 272 - 213 (the same per-pair redundancies as at 2K: duplicate
-        # fnet pass, 19/20 mask heads, transposed-volume GEMM, hoisted up-sample stacks) = 8 059 GF/frame.
-        # F 448x256: 2 729 GF measured with FlopCounterMode on the reference (oracle/ref_harness.py, B=1) minus the
-        # duplicate feature-encoder pass (24.9), the mask heads of decoder iterations 1..31 (98.3) and the transposed-
-        # volume GEMM (1.6) = 2 604 GF
-        gf = {("r", 256, 448, 2, None): 2065, ("f", 256, 448, 2, None): 2604,
-              ("r", 1088, 2048, 8, 0.5): 7917, ("r", 2176, 4096, 8, 0.25): 8059}.get((args.model, H, W, NI, ds))
+        roofline["traffic"] = traffic
+        roofline["traffic_note"] = (f"HBM bytes/launch of the 256->256 layer from profiles/{pmc_name} (separate rocprofv3 PMC passes, "
+                                    "FETCH_SIZE x2 + WRITE_SIZE); algorithmic 0.94 GB" if traffic is not None
+                                    else "no PMC pass for this workload")
+        roofline["timing"] = (f"HIP events around each launch, eager pass of {r['ev_steps']} steps (each behind a 25 ms spin kernel, so the "
+                              "stream stays backlogged and a pair brackets only its kernel) after the timed graph-replay region; "
+                              f"{ev_over_ms * 1e3:.2f} us per pair (calibrated in-process: what a pair adds to a back-to-back launch) taken off")
         if pmc is not None:
             # MFMA pipe utilisation of the same kernel from the PMC pass: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
             # GRBM_GUI_ACTIVE / 8 XCDs).  achieved / peak ~= mfma_busy x effective clock / 2.4 GHz: the chip runs this kernel at
             # its power budget (1.5-1.9 GHz by the in-kernel cycle counter), not at the clock the peak is quoted for
             roofline["pmc"] = {"mfma_busy_frac": round(pmc["mfma_busy_frac"], 4),
                                "source": f"profiles/{pmc_name} (separate profiled run of the same layer)"}
-        if gf is not None:
-            path_tf = gf * 1e9 * value / world / 1e12
-            roofline["path"] = {"minimal_gflop_per_frame": gf, "achieved": round(path_tf, 1), "unit": "TFLOP/s per GPU",
-                                "frac": round(path_tf / peak, 4)}
         cpu = None
         # (the CPU oracle needs minutes per 2K / 4K pair -- reference README settings -- so the bounded CPU sample is
         # only taken at the 448x256 workloads; tests/golden/hr_*.npz record the reference's CPU seconds at 2K / 4K)
         if world == 1 and not args.no_cpu_baseline and H * W <= 256 * 448:
             cpu = cpu_baseline(H, W, args.model)
         line = {
-            "metric": "interpolated frames/sec", "value": round(value, 3), "unit": "frames/s",
+            "metric": "interpolated frames/sec", "value": r["value"], "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"GIMM-VFI-{args.model.upper()} {W}x{H} batch={B} pairs/GPU, {NI}x interpolation (t=i/{NI}), "
-                                   f"DS_SCALE={args.ds:g}, seeded random-init weights",
-                       "pairs_per_step_per_gpu": B, "flow_iters": 20 if args.model == "r" else 32,
-                       **({"flow_precision": model.flow_precision} if args.model == "f" else {}),
+            "config": {"workload": r["workload"],
+                       "pairs_per_step_per_gpu": B, "flow_iters": r["flow_iters"],
+                       **({"flow_precision": r["flow_precision"]} if args.model == "f" else {}),
                        "parallelism": f"pair-sharded x{world}",
-                       "world_size_rccl": dist.get_world_size() if world > 1 else 1},
+                       "world_size_rccl": dist.get_world_size() if world > 1 else 1,
+                       **({"ms_per_step_per_rank": r["ms_per_step_per_rank"],
+                           "gather_bytes_per_rank_per_step": r["gather_bytes_per_rank_per_step"]} if world > 1 else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if extras:
+            for e in extras:
+                e.pop("ev_steps", None)
+            line["configs"] = extras
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
@@ -296,6 +395,73 @@ def timed_steps(step, steps, warmup, world, sync):
         step()
     barrier()
     return time.perf_counter() - t0
+
+
+def dry_main(args, world, rank):
+    """`--gpus N --dry`: the sharded step's bookkeeping with REAL frame shapes on a one-GPU box.  Rank 0 runs the real step
+    on cuda:0; ranks 1..N-1 are CPU processes contributing uint8 frames of the same shape; the gather goes over gloo through
+    host memory (so its time says nothing about RCCL / xGMI -- DESIGN.md section 6 has the expected cost per configuration).
+    Checks: every rank's frames arrive in rank order with the right shape, max-over-ranks timing, one JSON line."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    B, H, W, NI = args.batch, args.height, args.width, args.n_interp
+    shp = (B, H, W, 3) if NI == 2 else (B, NI - 1, H, W, 3)
+    ds = None if args.ds == 1.0 else args.ds
+    if rank == 0:
+        from gimmvfi_hip.model import GIMMVFI_F, GIMMVFI_R
+        from gimmvfi_hip.params import random_state_dict, random_state_dict_f
+        from gimmvfi_hip.synth import synthetic_pairs
+
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        if args.model == "f":
+            model = GIMMVFI_F(precision=args.precision, flow_precision=args.flow_precision)
+            model.load_state_dict(random_state_dict_f(0), strict=True)
+        else:
+            model = GIMMVFI_R(precision=args.precision)
+            model.load_state_dict(random_state_dict(0), strict=True)
+        model = model.to(dev).eval()
+        x = synthetic_pairs(B, H, W, seed=100).to(dev)
+        coords = [(model.sample_coord_input(B, (H, W), [i / NI], device=dev, upsample_ratio=args.ds), None) for i in range(1, NI)]
+        ts = [(i / NI) * torch.ones(B, device=dev) for i in range(1, NI)]
+        rt = model.engine(dev).rt
+        host = torch.empty(shp, dtype=torch.uint8).pin_memory()
+        buf = [torch.empty(shp, dtype=torch.uint8) for _ in range(world)]
+
+        def step():
+            out = model(x, coords, t=ts, ds_factor=ds)
+            fr = rt.frames_to_u8(out["imgt_pred"][0]) if NI == 2 else torch.stack([rt.frames_to_u8(f) for f in out["imgt_pred"]], 1)
+            host.copy_(fr)
+            dist.gather(host, buf, dst=0)
+            return buf
+
+        sync = torch.cuda.synchronize
+    else:
+        mine = torch.full(shp, rank, dtype=torch.uint8)
+
+        def step():
+            dist.gather(mine, None, dst=0)
+
+        sync = lambda: None  # noqa: E731
+    dt = timed_steps(step, args.steps, args.warmup, world, sync)
+    tt = torch.tensor([dt], dtype=torch.float64)
+    allt = [torch.zeros_like(tt) for _ in range(world)]
+    dist.all_gather(allt, tt)
+    if rank == 0:
+        got = step()
+        ok = all(tuple(g.shape) == shp for g in got) and all(int(got[r_].flatten()[0]) == r_ and int(got[r_].max()) == r_ for r_ in range(1, world))
+        dtm = max(float(v.item()) for v in allt)
+        frames = world * B * (NI - 1) * args.steps
+        c = {"model": args.model, "batch": B, "height": H, "width": W, "ds": args.ds, "n_interp": NI}
+        print(json.dumps({"metric": "interpolated frames/sec", "value": round(frames / dtm, 3), "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dtm / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                          "data": "DRY gather rehearsal: 1 real GPU rank + CPU stub ranks over gloo -- not a scaling measurement",
+                          "config": {"workload": workload_name(c), "parallelism": f"pair-sharded x{world} (dry)",
+                                     "world_size_gloo": dist.get_world_size(), "gathered_in_rank_order": bool(ok),
+                                     "gather_bytes_per_rank_per_step": int(torch.Size(shp).numel()),
+                                     "ms_per_step_per_rank": [round(float(v.item()) / args.steps * 1e3, 3) for v in allt]}}))
+    dist.destroy_process_group()
 
 
 def stub_main(args, world, rank):
