@@ -73,8 +73,10 @@ __host__ __device__ __forceinline__ float h2f(f16_t h) {
 __host__ __device__ __forceinline__ f16_t f2h(float f) {
     f16_t r;
 #if defined(__HIP_DEVICE_COMPILE__)
-    f = __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);          // saturate (NaN passes through)
-    r.v = __builtin_bit_cast(uint16_t, (_Float16)f);            // v_cvt_f16_f32, round to nearest even
+    // saturate; v_med3_f32 returns min3 when an input is NaN (-65504 here), so NaN is put back explicitly: an overflow or
+    // NaN inside the half-precision decoder must stay visible downstream, as it does in the bf16 / float paths
+    const float sat = __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+    r.v = __builtin_bit_cast(uint16_t, (_Float16)(f != f ? f : sat));   // v_cvt_f16_f32, round to nearest even
     return r;
 #else
     if (f != f) { r.v = 0x7e00; return r; }

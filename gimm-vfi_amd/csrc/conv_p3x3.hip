@@ -274,14 +274,17 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
     __syncthreads();   // every wave is done reading the last staged step
     if (has_res) {
         // residual tile -> staging area (same layout: the result overwrites it in place), 128 DMA instructions of 2 rows
-        const gvfi_i32x4 srd_r = make_srd((const bf16_t*)p.res + n0);
+        // (descriptor at the tile's first pixel, offsets relative to it: the residual tensor itself may exceed the 2 GB a
+        // raw-buffer offset spans -- 7 timesteps of a 1024x544x256 decoder activation in one batch are 2.0 GB)
+        const long long pix0 = img_pix + (long long)y0 * p.W + x0;
+        const gvfi_i32x4 srd_r = make_srd((const bf16_t*)p.res + pix0 * p.ldr + n0);
 #pragma unroll
         for (int q = 0; q < 128 / NW; ++q) {
             const int piece = q * NW + wave;
             const int row = piece * 2 + (lane >> 5);
             bool ok;
             const long long pix = pix_of(row, ok);
-            const unsigned off = ok ? (unsigned)(pix * p.ldr * 2 + (((lane & 31) ^ (row & 15)) << 4)) : GVFI_DMA_OOB;
+            const unsigned off = ok ? (unsigned)((pix - pix0) * p.ldr * 2 + (((lane & 31) ^ (row & 15)) << 4)) : GVFI_DMA_OOB;
             bufdma16(off, srd_r, 0u, smem_lds + piece * 1024);
         }
         glds_wait_n<0>();
@@ -409,7 +412,7 @@ extern "C" int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* pp) {
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15) || (p.ld0 % 8) || (p.c1 > 0 && (p.ld1 % 8))) return 0;
     // per-lane DMA offsets are 32-bit and stay below the descriptor's range: 18 image rows of the widest source
     if ((long long)18 * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) * 2 >= 0x7fffff00ll) return 0;
-    if (p.res && (long long)p.N * p.H * p.W * p.ldr * 2 >= 0x7fffff00ll) return 0;       // ... and the residual image
+    if (p.res && (long long)18 * p.W * p.ldr * 2 >= 0x7fffff00ll) return 0;               // ... and the residual tile's rows
     return (long long)p.N * p.H * p.W >= 65536 ? 1 : 2;
 }
 

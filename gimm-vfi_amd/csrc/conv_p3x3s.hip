@@ -199,7 +199,9 @@ template <int BN, int CK, bool PROF = false> __global__ void __launch_bounds__(2
     __syncthreads();   // every wave is done reading the patch and the last weight stage
     if (has_res) {
         // residual tile -> staging area (row pitch SP; the result overwrites it in place)
-        const gvfi_i32x4 srd_r = make_srd(p.res);
+        // (descriptor at the tile's first pixel, offsets relative to it: the tensor may exceed the 2 GB an offset spans)
+        const long long pix0 = img_pix + (long long)y0 * p.W + x0;
+        const gvfi_i32x4 srd_r = make_srd((const bf16_t*)p.res + pix0 * p.ldr);
 #pragma unroll
         for (int q = 0; q < RQ; ++q) {
             const int piece = q * NW + wave;
@@ -208,7 +210,7 @@ template <int BN, int CK, bool PROF = false> __global__ void __launch_bounds__(2
             const int row = byte / SP, unit = (byte % SP) >> 4;
             bool ok;
             const long long pix = pix_of(row < BM ? row : 0, ok);
-            const unsigned off = (ok && row < BM && unit * 8 < p.Cout) ? (unsigned)(pix * p.ldr * 2 + unit * 16) : GVFI_DMA_OOB;
+            const unsigned off = (ok && row < BM && unit * 8 < p.Cout) ? (unsigned)((pix - pix0) * p.ldr * 2 + unit * 16) : GVFI_DMA_OOB;
             bufdma16(off, srd_r, 0u, smem_lds + piece * 1024);
         }
         glds_wait_n<0>();
@@ -353,7 +355,7 @@ extern "C" int gvfi_conv2d_p3x3s_eligible(const gvfi_conv_params* pp) {
     if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.w & 15) || (p.ld0 % 8)) return 0;
     // per-lane DMA offsets are 32-bit and stay below the descriptor's range
     if ((long long)18 * p.W * p.ld0 * 2 >= 0x7fffff00ll) return 0;
-    if (p.res && (long long)p.N * p.H * p.W * p.ldr * 2 >= 0x7fffff00ll) return 0;
+    if (p.res && (long long)18 * p.W * p.ldr * 2 >= 0x7fffff00ll) return 0;
     return (long long)p.N * p.H * p.W >= 65536 ? 1 : 2;
 }
 

@@ -283,7 +283,7 @@ extern "C" int gvfi_resize_nhwc(const void* src, int lds, int src_f32, void* dst
 template <typename T>
 __global__ void warp_nhwc_kernel(const void* __restrict__ src, int lds, int src_f32, const float* __restrict__ flow,
                                  int ldf, float fmul, void* __restrict__ dst, int ldd, int dst_f32, int C,
-                                 long long total, int H, int W) {
+                                 long long total, int H, int W, int src_N) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % C);
@@ -298,7 +298,7 @@ __global__ void warp_nhwc_kernel(const void* __restrict__ src, int lds, int src_
     const float x0f = floorf(fx), y0f = floorf(fy);
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float ax = fx - x0f, ay = fy - y0f;
-    const long long b = n * (long long)H * W;
+    const long long b = (src_N > 0 ? n % src_N : n) * (long long)H * W;
     float v = 0.f;
     v += (1.f - ax) * (1.f - ay) * ld_any<T>(src, (b + (long long)y0 * W + x0) * lds + c, src_f32);
     if (x0 + 1 < W) v += ax * (1.f - ay) * ld_any<T>(src, (b + (long long)y0 * W + x0 + 1) * lds + c, src_f32);
@@ -309,7 +309,8 @@ __global__ void warp_nhwc_kernel(const void* __restrict__ src, int lds, int src_
 }
 template <typename T>
 __global__ void warp_nhwc_vec_kernel(const T* __restrict__ src, int lds, const float* __restrict__ flow, int ldf,
-                                     float fmul, T* __restrict__ dst, int ldd, int C, long long total, int H, int W) {
+                                     float fmul, T* __restrict__ dst, int ldd, int C, long long total, int H, int W,
+                                     int src_N) {
     constexpr int VE = Elem<T>::VE;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -326,7 +327,7 @@ __global__ void warp_nhwc_vec_kernel(const T* __restrict__ src, int lds, const f
     const float x0f = floorf(fx), y0f = floorf(fy);
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float ax = fx - x0f, ay = fy - y0f;
-    const long long b = n * (long long)H * W;
+    const long long b = (src_N > 0 ? n % src_N : n) * (long long)H * W;
     const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
     const T* p00 = src + (b + (long long)y0 * W + x0) * lds + c;
     const Vec16<T> a00 = *(const Vec16<T>*)p00;
@@ -347,7 +348,8 @@ __global__ void warp_nhwc_vec_kernel(const T* __restrict__ src, int lds, const f
     *(Vec16<T>*)(dst + pix * ldd + c) = o;
 }
 extern "C" int gvfi_warp_nhwc(const void* src, int lds, int src_f32, const float* flow, int ldf, float fmul, void* dst,
-                              int ldd, int dst_f32, int C, int N, int H, int W, int dtype, void* stream) {
+                              int ldd, int dst_f32, int C, int N, int src_N, int H, int W, int dtype, void* stream) {
+    if (src_N < 0 || src_N > N) return -2;
     {
         bool vec = false;
         GVFI_DISPATCH_T(dtype, vec = (vec_tensors_ok<T>(src, lds, src_f32, dst, ldd, dst_f32, C)));
@@ -355,14 +357,14 @@ extern "C" int gvfi_warp_nhwc(const void* src, int lds, int src_f32, const float
             const long long totv = (long long)N * H * W * (C / (dtype == GVFI_F32 ? 4 : 8));
             GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((warp_nhwc_vec_kernel<T>), grid1d(totv), dim3(GVFI_BLOCK),
                                                       (hipStream_t)stream, (const T*)src, lds, flow, ldf, fmul, (T*)dst,
-                                                      ldd, C, totv, H, W));
+                                                      ldd, C, totv, H, W, src_N));
             return (int)hipGetLastError();
         }
     }
     const long long total = (long long)N * H * W * C;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((warp_nhwc_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, src, lds, src_f32, flow, ldf, fmul, dst, ldd,
-                                              dst_f32, C, total, H, W));
+                                              dst_f32, C, total, H, W, src_N));
     return (int)hipGetLastError();
 }
 
@@ -393,22 +395,23 @@ extern "C" int gvfi_pixel_shuffle2(const void* src, int lds, void* dst, int ldd,
 template <typename T>
 __global__ void copy_channels_kernel(const void* __restrict__ src, int lds, int src_f32, const void* __restrict__ add,
                                      int lda, int add_f32, void* __restrict__ dst, int ldd, int dst_f32, int C,
-                                     float mul, long long total) {
+                                     float mul, long long total, long long src_npix) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % C);
     const long long pix = idx / C;
-    float v = mul * ld_any<T>(src, pix * lds + c, src_f32);
+    float v = mul * ld_any<T>(src, (src_npix > 0 ? pix % src_npix : pix) * lds + c, src_f32);
     if (add) v += ld_any<T>(add, pix * lda + c, add_f32);
     st_any<T>(dst, pix * ldd + c, dst_f32, v);
 }
 extern "C" int gvfi_copy_channels(const void* src, int lds, int src_f32, const void* add, int lda, int add_f32,
-                                  void* dst, int ldd, int dst_f32, int C, float mul, long long npix, int dtype,
-                                  void* stream) {
+                                  void* dst, int ldd, int dst_f32, int C, float mul, long long npix, long long src_npix,
+                                  int dtype, void* stream) {
+    if (src_npix < 0 || src_npix > npix) return -2;
     const long long total = npix * C;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((copy_channels_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, src, lds, src_f32, add, lda, add_f32, dst, ldd,
-                                              dst_f32, C, mul, total));
+                                              dst_f32, C, mul, total, src_npix));
     return (int)hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ template <typename T>
 __global__ void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                    const float* __restrict__ l2, const float* __restrict__ l3,
                                    const float* __restrict__ coords, T* __restrict__ out, int ldo, long long total,
-                                   int h2, int w2, int radius) {
+                                   int h2, int w2, int radius, long long src_nq) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int win = 2 * radius + 1;
@@ -46,7 +46,8 @@ __global__ void corr_lookup_kernel(const float* __restrict__ l0, const float* __
     const int l = (int)((idx / win) & 3);
     const long long q = idx / (4 * win);  // global query index (n*h*w + y*w + x)
     const int hl = h2 >> l, wl = w2 >> l;
-    const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + q * (long long)hl * wl;
+    // src_nq > 0: the volume holds src_nq maps and query q reads map q % src_nq (timestep-batched look-ups of one pyramid)
+    const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + (src_nq > 0 ? q % src_nq : q) * (long long)hl * wl;
     const float sc = 1.0f / (float)(1 << l);
     const float qx = coords[q * 2 + 0] * sc, qy = coords[q * 2 + 1] * sc;
     // bilinear_sampler: normalise to [-1,1] then grid_sample un-normalises (align_corners=True)
@@ -100,15 +101,16 @@ __global__ void corr_lookup_kernel(const float* __restrict__ l0, const float* __
     }
 }
 extern "C" int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3,
-                                const float* coords, void* out, int ldo, int dtype, int N, int h, int w, int h2,
+                                const float* coords, void* out, int ldo, int dtype, int N, int src_N, int h, int w, int h2,
                                 int w2, int radius, void* stream) {
+    if (src_N < 0 || src_N > N) return -2;
     const int win = 2 * radius + 1;
     const long long total = (long long)N * h * w * 4 * win;
     if ((h2 >> 3) < 2 || (w2 >> 3) < 2) return -2;  // coarsest level must be >= 2x2 (reference divides by W-1)
     if (win > CORR_MAX_WIN) return -2;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((corr_lookup_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, l0, l1, l2, l3, coords, (T*)out, ldo, total, h2, w2,
-                                              radius));
+                                              radius, (long long)src_N * h * w));
     return (int)hipGetLastError();
 }
 
@@ -126,7 +128,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) corr_lookup_lds_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                               const float* __restrict__ l2, const float* __restrict__ l3,
                                                               const float* __restrict__ coords, T* __restrict__ out, int ldo,
-                                                              long long nq, int h2, int w2, int radius) {
+                                                              long long nq, int h2, int w2, int radius, long long src_nq) {
     __shared__ float win[LQ][4][LWIN][LWIN];
     __shared__ int org[LQ][4][2];          // map coordinates of the staged window's corner (x, y)
     const int tid = threadIdx.x;
@@ -168,7 +170,7 @@ __global__ void __launch_bounds__(256) corr_lookup_lds_kernel(const float* __res
             const int hl = h2 >> l, wl = w2 >> l;
             const int x = org[ql][l][0] + c, y = org[ql][l][1] + r;
             if (x >= 0 && x < wl && y >= 0 && y < hl) {
-                const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + q * (long long)hl * wl;
+                const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + (src_nq > 0 ? q % src_nq : q) * (long long)hl * wl;
                 v = base[(long long)y * wl + x];
             }
         }
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(256) corr_lookup_lds_kernel(const float* __res
         } else if (x0f > -2.f && x0f < (float)wl && y0f > -2.f && y0f < (float)hl) {
             // (a tap whose cell left the staged window through rounding: direct reads, same expression)
             const int x0 = (int)x0f, y0 = (int)y0f;
-            const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + q * (long long)hl * wl;
+            const float* base = (l == 0 ? l0 : (l == 1 ? l1 : (l == 2 ? l2 : l3))) + (src_nq > 0 ? q % src_nq : q) * (long long)hl * wl;
             const bool xin0 = x0 >= 0 && x0 < wl, xin1 = x0 + 1 >= 0 && x0 + 1 < wl;
             const bool yin0 = y0 >= 0 && y0 < hl, yin1 = y0 + 1 >= 0 && y0 + 1 < hl;
             if (xin0 && yin0) v += (1.f - ax) * (1.f - ay) * base[(long long)y0 * wl + x0];
@@ -224,13 +226,14 @@ __global__ void __launch_bounds__(256) corr_lookup_lds_kernel(const float* __res
     }
 }
 extern "C" int gvfi_corr_lookup_lds(const float* l0, const float* l1, const float* l2, const float* l3,
-                                    const float* coords, void* out, int ldo, int dtype, int N, int h, int w, int h2,
+                                    const float* coords, void* out, int ldo, int dtype, int N, int src_N, int h, int w, int h2,
                                     int w2, int radius, void* stream) {
     const long long nq = (long long)N * h * w;
+    if (src_N < 0 || src_N > N) return -2;
     if ((h2 >> 3) < 2 || (w2 >> 3) < 2 || radius != 4) return -2;
     const unsigned grid = (unsigned)((nq + LQ - 1) / LQ);
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((corr_lookup_lds_kernel<T>), dim3(grid), dim3(256), (hipStream_t)stream, l0,
-                                            l1, l2, l3, coords, (T*)out, ldo, nq, h2, w2, radius));
+                                            l1, l2, l3, coords, (T*)out, ldo, nq, h2, w2, radius, (long long)src_N * h * w));
     return (int)hipGetLastError();
 }
 

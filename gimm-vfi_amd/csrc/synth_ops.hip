@@ -69,15 +69,16 @@ __device__ __forceinline__ void sample_border_rgb(const float* __restrict__ img,
 __global__ void warp_blend_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
                                   const float* __restrict__ f0, const float* __restrict__ f1,
                                   const float* __restrict__ mask, float* __restrict__ out, long long total, int H,
-                                  int W) {
+                                  int W, int src_B) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const long long HW = (long long)H * W;
     const long long pix = idx % HW, b = idx / HW;
     const int x = (int)(pix % W), y = (int)(pix / W);
     float a[3], c[3];
-    sample_border_rgb(i0 + b * HW * 4, H, W, (float)x + f0[idx * 2], (float)y + f0[idx * 2 + 1], a);
-    sample_border_rgb(i1 + b * HW * 4, H, W, (float)x + f1[idx * 2], (float)y + f1[idx * 2 + 1], c);
+    const long long bs = src_B > 0 ? b % src_B : b;
+    sample_border_rgb(i0 + bs * HW * 4, H, W, (float)x + f0[idx * 2], (float)y + f0[idx * 2 + 1], a);
+    sample_border_rgb(i1 + bs * HW * 4, H, W, (float)x + f1[idx * 2], (float)y + f1[idx * 2 + 1], c);
     const float m = gvfi_sigmoid(mask[idx]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -86,10 +87,11 @@ __global__ void warp_blend_kernel(const float* __restrict__ i0, const float* __r
     }
 }
 extern "C" int gvfi_warp_blend(const float* img4_0, const float* img4_1, const float* f0, const float* f1,
-                               const float* mask, float* out_nchw, int B, int H, int W, void* stream) {
+                               const float* mask, float* out_nchw, int B, int src_B, int H, int W, void* stream) {
+    if (src_B < 0 || src_B > B) return -2;
     const long long total = (long long)B * H * W;
     GVFI_LAUNCH_SIMPLE(warp_blend_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, img4_0, img4_1, f0, f1,
-                       mask, out_nchw, total, H, W);
+                       mask, out_nchw, total, H, W, src_B);
     return (int)hipGetLastError();
 }
 
@@ -144,7 +146,8 @@ template <typename T>
 __global__ void combine_warps_up_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
                                         const float* __restrict__ dec, int ldd, int H, int W, float rscale, float inv,
                                         T* __restrict__ act, int lda, int pad, float* __restrict__ mean4,
-                                        float* __restrict__ f0p, float* __restrict__ f1p, long long total, int Hf, int Wf) {
+                                        float* __restrict__ f0p, float* __restrict__ f1p, long long total, int Hf, int Wf,
+                                        int src_B) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const long long HWf = (long long)Hf * Wf;
@@ -168,11 +171,12 @@ __global__ void combine_warps_up_kernel(const float* __restrict__ i0, const floa
     }
     float mean[3] = {0.f, 0.f, 0.f};
     float v9[9];
+    const long long bs = src_B > 0 ? b % src_B : b;       // image of the source batch (timestep-batched decoder output)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float w0[3], w1[3];
-        sample_border_rgb(i0 + b * HWf * 4, Hf, Wf, (float)x + d[2 * k], (float)y + d[2 * k + 1], w0);
-        sample_border_rgb(i1 + b * HWf * 4, Hf, Wf, (float)x + d[6 + 2 * k], (float)y + d[6 + 2 * k + 1], w1);
+        sample_border_rgb(i0 + bs * HWf * 4, Hf, Wf, (float)x + d[2 * k], (float)y + d[2 * k + 1], w0);
+        sample_border_rgb(i1 + bs * HWf * 4, Hf, Wf, (float)x + d[6 + 2 * k], (float)y + d[6 + 2 * k + 1], w1);
         const float m = d[12 + k];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -212,7 +216,8 @@ __global__ void combine_warps_up_kernel(const float* __restrict__ i0, const floa
 }
 extern "C" int gvfi_combine_warps_up(const float* img4_0, const float* img4_1, const float* dec, int ldd, int H, int W,
                                      void* act, int lda, int pad, float* mean4, float* flow0_planar, float* flow1_planar,
-                                     int B, int Hf, int Wf, int dtype, void* stream) {
+                                     int B, int src_B, int Hf, int Wf, int dtype, void* stream) {
+    if (src_B < 0 || src_B > B) return -2;
     if (H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0 || (ldd & 3) || (((uintptr_t)dec | (uintptr_t)mean4) & 15)) return -2;
     if ((long long)Hf * W != (long long)H * Wf) return -3;       // one isotropic scale
     const float inv = (float)((double)Hf / (double)H);           // torch: scale_factor = 1 / ds_factor, flows x the same
@@ -220,7 +225,7 @@ extern "C" int gvfi_combine_warps_up(const float* img4_0, const float* img4_1, c
     const long long total = (long long)B * Hf * Wf;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((combine_warps_up_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
                                               (hipStream_t)stream, img4_0, img4_1, dec, ldd, H, W, rscale, inv, (T*)act,
-                                              lda, pad, mean4, flow0_planar, flow1_planar, total, Hf, Wf));
+                                              lda, pad, mean4, flow0_planar, flow1_planar, total, Hf, Wf, src_B));
     return (int)hipGetLastError();
 }
 

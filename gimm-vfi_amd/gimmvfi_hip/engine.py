@@ -60,6 +60,11 @@ class Engine:
         # with the float state against 32.26 dB without, profiles/r3_f_policy.md -- the loss is the rounding of the update
         # block's MFMA operands, amplified by the un-trained recurrence) and it costs 1.3 % (326.2 vs 330.7 frames/s)
         self.gru_state_f32 = os.environ.get("GVFI_GRU_STATE_F32", "0") == "1"
+        # frame synthesis of several timesteps of a pair as ONE batch (gimmvfi_r.py:376-396 runs them one by one): at 2K / 4K
+        # a pair is B = 1 and the 1/8- and 1/4-resolution layers of the decoders launch 68-272 workgroups on 256 CUs; the
+        # timesteps are independent once their flows exist.  Upper bound on T*B*H*W working-resolution pixels per batch
+        # (activation memory: ~6 KB per pixel); 0 = one timestep at a time
+        self.t_batch_pix = int(float(os.environ.get("GVFI_T_BATCH_PIX", "4.1e6")))
         self.layers = {}
         self._build(sd)
 
@@ -596,27 +601,39 @@ class Engine:
         i1q = rt.resize(View(img4[B:], 0, 4), 4, 0.25)
 
         out = {k: [] for k in ("imgt_pred", "other_pred", "flowt0_pred", "flowt1_pred", "ninrflow", "flowt")}
-        for i, (c, cur_t) in enumerate(zip(coord, t)):
-            assert isinstance(c, tuple) and c[1] is None, "sub-sampled coordinates are a training feature"
-            cg = c[0].to(device=rt.device, dtype=torch.float32).contiguous()
-            tv = cur_t.to(device=rt.device, dtype=torch.float32).reshape(-1).contiguous()
-            assert cg.shape[0] == B and cg.shape[1] == 1 and cg.shape[-1] == 3 and tv.numel() == B
-            Hc, Wc = cg.shape[2], cg.shape[3]
-            ninr = self._motion_inr(latcat, f01, f10, z0, z1, cg, tv, B, H, W, taps, f"t{i}_")
-            flow_t = rt.f32(B, Hc, Wc, 2)
-            ninr_nchw = rt.f32(B, 2, 1, Hc, Wc)
-            rt._chk(lib.flow_unnormalize(ninr.data_ptr(), scaler.data_ptr(), flow_t.data_ptr(), ninr_nchw.data_ptr(),
-                                         B, Hc * Wc, st()), "flow_unnormalize")
-            out["ninrflow"].append(ninr_nchw)
-            ft_nchw = rt.nhwc_to_nchw(flow_t, 2)
-            out["flowt"].append(ft_nchw.squeeze())     # B==1 squeeze quirk, gimmvfi_r.py:364-372
-            assert (Hc, Wc) == (H, W), "frame synthesis needs the INR grid at the working resolution"
-            pred, f0p, f1p, oth = self._synthesize(B, H, W, Hf, Wf, img4, img4_full, flow_t, tv, up8, up4, i0q, i1q,
-                                                   pyr, pyrT, taps, f"t{i}_", want_aux)
-            out["imgt_pred"].append(pred)
-            out["flowt0_pred"].append(f0p)
-            out["flowt1_pred"].append(f1p)
-            out["other_pred"].append(oth)
+        T = len(t)
+        G = max(1, min(T, self.t_batch_pix // max(B * HW, 1)))      # timesteps per synthesis batch
+        for i0 in range(0, T, G):
+            g = min(G, T - i0)
+            flow_all = rt.f32(g * B, H, W, 2)                       # [t][b] order
+            tvs = []
+            for k in range(g):
+                i = i0 + k
+                c, cur_t = coord[i], t[i]
+                assert isinstance(c, tuple) and c[1] is None, "sub-sampled coordinates are a training feature"
+                cg = c[0].to(device=rt.device, dtype=torch.float32).contiguous()
+                tv = cur_t.to(device=rt.device, dtype=torch.float32).reshape(-1).contiguous()
+                assert cg.shape[0] == B and cg.shape[1] == 1 and cg.shape[-1] == 3 and tv.numel() == B
+                Hc, Wc = cg.shape[2], cg.shape[3]
+                ninr = self._motion_inr(latcat, f01, f10, z0, z1, cg, tv, B, H, W, taps, f"t{i}_")
+                assert (Hc, Wc) == (H, W), "frame synthesis needs the INR grid at the working resolution"
+                flow_t = flow_all[k * B:(k + 1) * B]
+                ninr_nchw = rt.f32(B, 2, 1, Hc, Wc)
+                rt._chk(lib.flow_unnormalize(ninr.data_ptr(), scaler.data_ptr(), flow_t.data_ptr(), ninr_nchw.data_ptr(),
+                                             B, Hc * Wc, st()), "flow_unnormalize")
+                out["ninrflow"].append(ninr_nchw)
+                ft_nchw = rt.nhwc_to_nchw(flow_t, 2)
+                out["flowt"].append(ft_nchw.squeeze())     # B==1 squeeze quirk, gimmvfi_r.py:364-372
+                tvs.append(tv)
+            tv_all = tvs[0] if g == 1 else torch.cat(tvs)
+            pred, f0p, f1p, oth = self._synthesize(g * B, B, H, W, Hf, Wf, img4, img4_full, flow_all, tv_all, up8, up4, i0q, i1q,
+                                                   pyr, pyrT, taps, i0, want_aux)
+            for k in range(g):
+                sl = slice(k * B, (k + 1) * B)
+                out["imgt_pred"].append(pred[sl])
+                out["flowt0_pred"].append([f[sl] for f in f0p])
+                out["flowt1_pred"].append([f[sl] for f in f1p])
+                out["other_pred"].append([o[sl] for o in oth])
         out["raft_flow"] = raft_flow
         out["nflow"] = nflow
         return out
@@ -676,9 +693,12 @@ class Engine:
         rt.conv(Ls[p + ".7"], x, y, act1=A.ACT_RELU)
         return y
 
-    def _synthesize(self, B, H, W, Hf, Wf, img4, img4_full, flow_t, tv, up8, up4, i0q, i1q, pyr, pyrT, taps, tag,
+    def _synthesize(self, B, sb, H, W, Hf, Wf, img4, img4_full, flow_t, tv, up8, up4, i0q, i1q, pyr, pyrT, taps, ti0,
                     want_aux):
-        """gimmvfi_r.py:222-322."""
+        """gimmvfi_r.py:222-322 for B = g * sb images: g timesteps [t][b] of the sb pairs in one batch.  flow_t [B,H,W,2],
+        tv [B]; the t-independent sources (img4, up8, up4, i0q / i1q: 2 * sb images [frame 0 | frame 1]; pyr / pyrT: sb
+        volumes) are read modulo sb by the warp / copy / look-up / combine kernels.  ti0: index of the first timestep (tap
+        names).  Returns tensors of B images in the same [t][b] order."""
         rt, Ls, lib = self.rt, self.layers, self.rt.lib
         st = rt.stream
         HW = H * W
@@ -692,8 +712,8 @@ class Engine:
         rt.resize(ft1, 2, 0.25, mul=0.25, out=View(fl4in, 2, 2))
         # ---- NewInitDecoder  fi_components.py:255-276
         f_in = rt.act(B, h4, w4, 272, zero=True, pitch=rt.cp64(272), zero_pad_only=True)
-        rt.warp(up8[:B], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
-        rt.warp(up8[B:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
+        rt.warp(up8[:sb], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
+        rt.warp(up8[sb:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
         rt.copy(View(fl4in, 0, 4), View(f_in, 256, 4), 4)
         rt.copy(View(i0q.t, 0, 3), View(f_in, 260, 3), 3)
         rt.copy(View(i1q.t, 0, 3), View(f_in, 263, 3), 3)
@@ -709,9 +729,13 @@ class Engine:
         ft_4 = rt.act(B, h4, w4, 128)
         rt.conv(Ls["init.ft"], x, ft_4)
         mask_4 = View(st4, 4, 1)
-        if taps is not None:
-            taps[tag + "init_flow0_4"] = st4[..., 0:2].clone()
-            taps[tag + "init_ft_4"] = ft_4.clone()
+        def tap(name, ten):
+            if taps is not None:
+                for k in range(B // sb):
+                    taps[f"t{ti0 + k}_{name}"] = ten[k * sb:(k + 1) * sb].clone()
+
+        tap("init_flow0_4", st4[..., 0:2])
+        tap("init_ft_4", ft_4)
         others = []
         if want_aux:
             # warp_w_mask at scale 4  gimmvfi_r.py:213-220, 259-261
@@ -719,8 +743,8 @@ class Engine:
             f1u = rt.resize(View(st4, 2, 2), 2, 4.0, mul=4.0)
             m4u = rt.resize(mask_4, 1, 4.0)
             iw4 = rt.f32(B, 3, H, W)
-            rt._chk(lib.warp_blend(img4[:B].data_ptr(), img4[B:].data_ptr(), f0u.t.data_ptr(), f1u.t.data_ptr(),
-                                   m4u.t.data_ptr(), iw4.data_ptr(), B, H, W, st()), "warp_blend")
+            rt._chk(lib.warp_blend(img4[:sb].data_ptr(), img4[sb:].data_ptr(), f0u.t.data_ptr(), f1u.t.data_ptr(),
+                                   m4u.t.data_ptr(), iw4.data_ptr(), B, 0 if sb == B else sb, H, W, st()), "warp_blend")
             others = [iw4]
         # ---- _amt_corr_scale_lookup (downsample=2)  gimmvfi_r.py:494-507
         fl0 = rt.resize(View(st4, 0, 2), 2, 0.5, mul=0.5).t
@@ -729,8 +753,8 @@ class Engine:
         rt._chk(lib.lookup_coords(fl0.data_ptr(), fl1.data_ptr(), tv.data_ptr(), c0.data_ptr(), c1.data_ptr(), B, h8,
                                   w8, st()), "lookup_coords")
         corr = rt.act(B, h8, w8, 648, zero=True, pitch=rt.cp64(648), zero_pad_only=True)
-        rt.corr_lookup(pyr, c0, View(corr, 0, 324), B, h8, w8, h8, w8)
-        rt.corr_lookup(pyrT, c1, View(corr, 324, 324), B, h8, w8, h8, w8)
+        rt.corr_lookup(pyr, c0, View(corr, 0, 324), B, h8, w8, h8, w8, src_n=0 if sb == B else sb)
+        rt.corr_lookup(pyrT, c1, View(corr, 324, 324), B, h8, w8, h8, w8, src_n=0 if sb == B else sb)
         flow_lr = rt.f32(B, h8, w8, 4)
         rt.copy(fl0, View(flow_lr, 0, 2), 2)
         rt.copy(fl1, View(flow_lr, 2, 2), 2)
@@ -741,24 +765,23 @@ class Engine:
         flow4 = rt.f32(B, h4, w4, 4)
         rt.copy(View(st4, 0, 4), flow4, 4)
         self._amt_update("amt_update4_high", ft_4, flow4, corr_up, B, h4, w4, st4, ft_4, low=False)
-        if taps is not None:
-            taps[tag + "upd_flow0_4"] = st4[..., 0:2].clone()
-            taps[tag + "upd_ft_4"] = ft_4.clone()
+        tap("upd_flow0_4", st4[..., 0:2])
+        tap("upd_ft_4", ft_4)
         # ---- NewMultiFlowDecoder  fi_components.py:307-340
         fl0u = rt.resize(View(st4, 0, 2), 2, 4.0, mul=4.0).t
         fl1u = rt.resize(View(st4, 2, 2), 2, 4.0, mul=4.0).t
         mku = rt.resize(mask_4, 1, 4.0).t
         fin = rt.act(B, H, W, 273, zero=True, pitch=rt.cp64(273), zero_pad_only=True)
         rt.resize(ft_4, 128, 4.0, out=View(fin, 0, 128))
-        rt.warp(up4[:B], 64, fl0u, View(fin, 128, 64))
-        rt.warp(up4[B:], 64, fl1u, View(fin, 192, 64))
+        rt.warp(up4[:sb], 64, fl0u, View(fin, 128, 64))
+        rt.warp(up4[sb:], 64, fl1u, View(fin, 192, 64))
         rt.copy(fl0u, View(fin, 256, 2), 2)
         rt.copy(fl1u, View(fin, 258, 2), 2)
         rt.copy(mku, View(fin, 260, 1), 1)
-        rt.copy(View(img4[:B], 0, 3), View(fin, 261, 3), 3)
-        rt.copy(View(img4[B:], 0, 3), View(fin, 264, 3), 3)
-        rt.warp(View(img4[:B], 0, 3), 3, fl0u, View(fin, 267, 3))
-        rt.warp(View(img4[B:], 0, 3), 3, fl1u, View(fin, 270, 3))
+        rt.copy(View(img4[:sb], 0, 3), View(fin, 261, 3), 3)
+        rt.copy(View(img4[sb:], 0, 3), View(fin, 264, 3), 3)
+        rt.warp(View(img4[:sb], 0, 3), 3, fl0u, View(fin, 267, 3))
+        rt.warp(View(img4[sb:], 0, 3), 3, fl1u, View(fin, 270, 3))
         p = "amt_final_decoder.convblock"
         x = rt.act(B, H, W, 256)
         rt.conv(Ls[p + ".0.0"], fin, x, act1=A.ACT_PRELU)
@@ -768,21 +791,20 @@ class Engine:
         rt.conv(Ls[p + ".4"], x, dec)
         rt._chk(lib.decoder_head(dec.data_ptr(), 24, fl0u.data_ptr(), fl1u.data_ptr(), mku.data_ptr(), B * HW, st()),
                 "decoder_head")
-        if taps is not None:
-            taps[tag + "final_flow0_1"] = dec[..., 0:6].clone()
-            taps[tag + "final_mask"] = dec[..., 12:15].clone()
-            taps[tag + "final_res"] = dec[..., 15:24].clone()
+        tap("final_flow0_1", dec[..., 0:6])
+        tap("final_mask", dec[..., 12:15])
+        tap("final_res", dec[..., 15:24])
         # ---- multi_flow_combine + comb_block  fi_components.py:57-94, gimmvfi_r.py:294-308.  With DS_SCALE < 1 the decoder
         # output lives at the working resolution: its bilinear up-sampling (flows x Hf/H), the six warps + blends and the
         # planar copies of the up-sampled flows for the return dict are one pass over the full-resolution pixels
-        i0f, i1f = (img4[:B], img4[B:]) if img4_full is None else (img4_full[:B], img4_full[B:])
+        i0f, i1f = (img4[:sb], img4[sb:]) if img4_full is None else (img4_full[:sb], img4_full[sb:])
         cw = rt.act(B, Hf, Wf, 9, zero=False)
         mean4 = rt.f32(B, Hf, Wf, 4)
         f01 = rt.f32(B, 3, 2, Hf, Wf)
         f11 = rt.f32(B, 3, 2, Hf, Wf)
         rt._chk(lib.combine_warps_up(i0f.data_ptr(), i1f.data_ptr(), dec.data_ptr(), 24, H, W, cw.data_ptr(), cw.shape[-1],
-                                     cw.shape[-1], mean4.data_ptr(), f01.data_ptr(), f11.data_ptr(), B, Hf, Wf, rt.dtype,
-                                     st()), "combine_warps_up")
+                                     cw.shape[-1], mean4.data_ptr(), f01.data_ptr(), f11.data_ptr(), B, 0 if sb == B else sb, Hf, Wf,
+                                     rt.dtype, st()), "combine_warps_up")
         cb = rt.act(B, Hf, Wf, 18, zero=True)
         # (pad16: cb's channels 18..23 and o4's / mean4's channel 3 are padding owned here -> whole 16-byte stores)
         rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU, pad16=True, algo=rt.comb_algo)

@@ -36,17 +36,24 @@ class FramePrefetcher:
     """frames[i] -> device tensor (1,3,Hp,Wp), decoded once, ``lookahead`` frames ahead of the consumer.
 
     ``pad_fn(t) -> t`` is applied on the host (the CLI passes InputPadder.pad).  ``get(i)`` must be called with
-    non-decreasing i (each frame may be requested any number of times while it is within the window)."""
+    non-decreasing i (each frame may be requested any number of times while it is within the window).
 
-    def __init__(self, paths, device, pad_fn=None, lookahead=4, workers=4, decode=decode_rgb01):
+    ``order``: the frame indices this consumer will ask for, ascending (default: every frame).  Under the multi-GPU round
+    schedule a rank owns non-contiguous blocks of the video: only ITS frames are decoded (decode work and pinned memory
+    per rank are O(video / world) and O(look-ahead), not O(video)), and the look-ahead runs along that order."""
+
+    def __init__(self, paths, device, pad_fn=None, lookahead=4, workers=4, decode=decode_rgb01, order=None):
         self.paths, self.device, self.pad_fn, self.decode = list(paths), torch.device(device), pad_fn, decode
+        self.order = list(range(len(self.paths))) if order is None else sorted(set(int(i) for i in order))
+        assert all(0 <= i < len(self.paths) for i in self.order)
+        self.pos = {i: k for k, i in enumerate(self.order)}
         self.lookahead = max(1, lookahead)
         self.pool = ThreadPoolExecutor(max_workers=workers)
         self.on_gpu = self.device.type == "cuda"
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.futures = {}      # index -> Future[(host tensor)]
         self.ready = {}        # index -> (device tensor, event)
-        self.next_submit = 0
+        self.next_submit = 0   # position in self.order of the next frame to hand to the decode pool
         self.decodes = 0       # statistics (tests): every frame is decoded exactly once
         self._lock = threading.Lock()
 
@@ -61,14 +68,19 @@ class FramePrefetcher:
             self.decodes += 1
         return t
 
-    def _submit_upto(self, hi):
-        hi = min(hi, len(self.paths) - 1)
-        while self.next_submit <= hi:
-            self.futures[self.next_submit] = self.pool.submit(self._load, self.next_submit)
+    def _submit_upto(self, hi_pos):
+        hi_pos = min(hi_pos, len(self.order) - 1)
+        while self.next_submit <= hi_pos:
+            i = self.order[self.next_submit]
+            self.futures[i] = self.pool.submit(self._load, i)
             self.next_submit += 1
 
     def get(self, i):
-        self._submit_upto(i + self.lookahead)
+        if i not in self.pos:
+            raise KeyError(f"frame {i} is not in this prefetcher's order")
+        self._submit_upto(self.pos[i] + self.lookahead)
+        for k in [k for k in self.futures if k < i]:        # never requested and now behind the consumer: drop
+            self.futures.pop(k).cancel()
         if i not in self.ready:
             host = self.futures.pop(i).result()
             if self.on_gpu:
@@ -121,6 +133,13 @@ class ResultDrain:
         """Returns the event that marks the end of the D2H copies (None on CPU): a caller that re-uses `tensors` as
         staging buffers waits for it before overwriting them."""
         self.slots.acquire()
+        if self.err is None:
+            # a post() that already failed (sink.put, an encoder) surfaces at the next submit, not only at finish(): the GPU
+            # loop must not run the rest of the video into a dead writer
+            for _, fut in self.pending:
+                if fut.done() and fut.exception() is not None:
+                    self.err = fut.exception()
+                    break
         if self.err is not None:
             self.slots.release()
             raise self.err
@@ -264,6 +283,8 @@ class VideoSink:
             self.png_slots.acquire()
             self.png_pool.submit(self._save_png, index, frame)
             return
+        if self.err is not None:            # the ordered writer died: do not pile frames up behind it
+            raise self.err
         with self._lock:
             self._pending[index] = frame
             self._lock.notify_all()
@@ -307,8 +328,11 @@ class VideoSink:
             raise self.err
         assert self.written == self.total, (self.written, self.total)
         if shutil.which("ffmpeg"):
-            subprocess.run(["ffmpeg", "-y", "-framerate", f"{self.fps}", "-i", f"{self.frame_dir}/%04d.png", "-c:v", "libx264",
-                            "-pix_fmt", "yuv420p", self.path])
-            shutil.rmtree(self.frame_dir, ignore_errors=True)
-            return self.path
+            # yuv420p needs even dimensions: pad odd frames by one row / column instead of failing
+            r = subprocess.run(["ffmpeg", "-y", "-framerate", f"{self.fps}", "-i", f"{self.frame_dir}/%04d.png",
+                                "-vf", "pad=ceil(iw/2)*2:ceil(ih/2)*2", "-c:v", "libx264", "-pix_fmt", "yuv420p", self.path])
+            if r.returncode == 0 and os.path.isfile(self.path) and os.path.getsize(self.path) > 0:
+                shutil.rmtree(self.frame_dir, ignore_errors=True)
+                return self.path
+            print(f"[VideoSink] ffmpeg failed (exit code {r.returncode}); the frames are kept in {self.frame_dir}")
         return self.frame_dir

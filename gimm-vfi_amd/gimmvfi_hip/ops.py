@@ -477,11 +477,12 @@ class Runtime:
         self._chk(self.lib.avgpool2_f32(src.data_ptr(), dst.data_ptr(), maps, h, w, self.stream()), "avgpool2_f32")
         return dst
 
-    def corr_lookup(self, pyr, coords, out, n, h, w, h2, w2, radius=4):
+    def corr_lookup(self, pyr, coords, out, n, h, w, h2, w2, radius=4, src_n=0):
+        """src_n: the pyramid holds src_n images and query image i reads image i % src_n (0: one map per query image)."""
         out = V(out)
         fn = self.lib.corr_lookup_lds if (self.lookup_lds and radius == 4) else self.lib.corr_lookup
         self._chk(fn(pyr[0].data_ptr(), pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(),
-                                       coords.data_ptr(), out.ptr, out.ld, self.dtype, n, h, w, h2, w2, radius,
+                                       coords.data_ptr(), out.ptr, out.ld, self.dtype, n, src_n, h, w, h2, w2, radius,
                                        self.stream()), "corr_lookup")
 
     def coords_init(self, n, h, w):
@@ -626,11 +627,14 @@ class Runtime:
         return out
 
     def warp(self, src, c, flow, out, fmul=1.0):
+        """A source with fewer images than `out` is read modulo its batch (out image n <- src image n % src_n)."""
         src, out, flow = V(src), V(out), V(flow)
         n, h, w = out.t.shape[:3]
-        assert src.t.shape[1] == h and src.t.shape[2] == w and flow.t.shape[1] == h
+        assert src.t.shape[1] == h and src.t.shape[2] == w and flow.t.shape[1] == h and flow.t.shape[0] == n
+        sn = src.t.shape[0]
+        assert sn == n or (0 < sn < n and n % sn == 0), (sn, n)
         self._chk(self.lib.warp_nhwc(src.ptr, src.ld, src.is_f32, flow.ptr, flow.ld, float(fmul), out.ptr, out.ld,
-                                     out.is_f32, c, n, h, w, self.dtype, self.stream()), "warp_nhwc")
+                                     out.is_f32, c, n, 0 if sn == n else sn, h, w, self.dtype, self.stream()), "warp_nhwc")
         return out
 
     def pixel_shuffle2(self, src, cout):
@@ -642,12 +646,15 @@ class Runtime:
         return out
 
     def copy(self, src, dst, c, mul=1.0, add=None):
+        """A source with fewer pixels than `dst` (a whole divisor) is read modulo its size: broadcast over timesteps."""
         src, dst = V(src), V(dst)
         a = None if add is None else V(add)
+        sp = src.npix
+        assert sp >= dst.npix or (sp > 0 and dst.npix % sp == 0), (sp, dst.npix)
         self._chk(self.lib.copy_channels(src.ptr, src.ld, src.is_f32, None if a is None else a.ptr,
                                          0 if a is None else a.ld, 0 if a is None else a.is_f32, dst.ptr, dst.ld,
-                                         dst.is_f32, c, float(mul), dst.npix, self.dtype, self.stream()),
-                  "copy_channels")
+                                         dst.is_f32, c, float(mul), dst.npix, 0 if sp >= dst.npix else sp, self.dtype,
+                                         self.stream()), "copy_channels")
         return dst
 
     # ------------------------------------------------------------------ FlowFormer glue (csrc/flowformer_ops.hip)

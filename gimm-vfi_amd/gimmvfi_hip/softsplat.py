@@ -41,7 +41,7 @@ class softsplat_func:
 _KINDS = ("sum", "avg", "linear", "softmax")
 # how the normaliser (the splatted weight channel) is made safe to divide by   softsplat.py:322-334
 _EPS_POLICY = {
-    None: lambda n: n + 0.0000001,
+    "": lambda n: n + 0.0000001,
     "addeps": lambda n: n + 0.0000001,
     "zeroeps": lambda n: torch.where(n == 0.0, torch.ones_like(n), n),
     "clipeps": lambda n: n.clip(0.0000001, None),
@@ -60,6 +60,9 @@ def softsplat(tenIn, tenFlow, tenMetric, strMode, return_norm=False):
     (default / "addeps": + 1e-7, "zeroeps": 0 -> 1, "clipeps": clip at 1e-7).  return_norm: (numerator, normaliser)."""
     kind, _, eps = strMode.partition("-")
     assert kind in _KINDS, strMode
+    # "sum" / "avg" take no suffix: the reference only recognises the bare words (softsplat.py:289-296) and with a suffix
+    # silently computes something else (no weight channel, yet the last INPUT channel as the normaliser) -- rejected here
+    assert kind in ("linear", "softmax") or eps == "", f"softsplat: mode {strMode!r}: 'sum' / 'avg' take no eps suffix"
     assert (tenMetric is None) == (kind in ("sum", "avg")), f"mode {kind!r}: metric {'not ' if tenMetric is None else ''}given"
     if kind == "sum":
         weight = None
@@ -73,7 +76,8 @@ def softsplat(tenIn, tenFlow, tenMetric, strMode, return_norm=False):
     _finite_or_die(acc, "the splatted sums")
     if weight is None:
         return acc
-    norm = _EPS_POLICY[eps if eps in _EPS_POLICY else None](acc[:, -1:, :, :])
+    # an unknown suffix ("linear-foo") leaves the normaliser untouched, as the reference's if / elif chain does (softsplat.py:325-334)
+    norm = _EPS_POLICY.get(eps, lambda n: n)(acc[:, -1:, :, :])
     if return_norm:
         return acc[:, :-1, :, :], norm
     out = acc[:, :-1, :, :] / norm

@@ -152,7 +152,9 @@ def main(argv=None):
     # every rank is O(one round), whatever the length of the video
     rounds = shard.round_schedule(num_pairs, bsz, world)
     my_blocks = [rnd[rank] for rnd in rounds]
-    frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image, lookahead=bsz + 3)
+    # (only this rank's frames are decoded: block (j0, b) reads frames j0 .. j0 + b)
+    my_frames = [j for j0, b in my_blocks if b > 0 for j in range(j0, j0 + b + 1)]
+    frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image, lookahead=bsz + 3, order=my_frames)
     drain = ResultDrain(device, depth=12, workers=8)      # composing + resizing the frames of a block: ~0.4 s at 2K
     rt = model.engine(device).rt
     gatherer = shard.RoundGather(rank, world) if world > 1 else None

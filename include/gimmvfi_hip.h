@@ -177,14 +177,18 @@ int gvfi_instnorm_apply(const void* x, int ld, int C, int N, int HW, const float
 
 /* ---- correlation pyramid + lookup (raft/corr.py:23-93,127-165; raft/utils/utils.py:66-80) */
 int gvfi_avgpool2_f32(const float* src, float* dst, long long maps, int h, int w, void* stream);
+/* src_N (also gvfi_warp_nhwc / gvfi_warp_blend / gvfi_combine_warps_up; gvfi_copy_channels: src_npix): 0 = the source
+ * holds N images; 0 < src_N <= N = the source holds src_N images and output image n reads source image n % src_N -- the
+ * T timesteps of a pair run through frame synthesis as ONE batch [t][b] against the pair's t-independent tensors
+ * (correlation pyramids, context features, images), the loop of gimmvfi_r.py:376-396 without replicating them */
 int gvfi_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3,
                      const float* coords /*[N,h,w,2] (x,y)*/, void* out, int ldo, int dtype,
-                     int N, int h, int w, int h2, int w2, int radius, void* stream);
+                     int N, int src_N, int h, int w, int h2, int w2, int radius, void* stream);
 /* the same look-up with the windows staged through LDS (one workgroup per 8 queries; identical results); which of the two
  * the engine launches is decided by measurement (GVFI_LOOKUP_LDS, profiles/r3_lookup_ab.txt) */
 int gvfi_corr_lookup_lds(const float* l0, const float* l1, const float* l2, const float* l3,
                      const float* coords /*[N,h,w,2] (x,y)*/, void* out, int ldo, int dtype,
-                     int N, int h, int w, int h2, int w2, int radius, void* stream);
+                     int N, int src_N, int h, int w, int h2, int w2, int radius, void* stream);
 
 /* patch matrix of a stride-1 zero-padded KHxKW convolution over c (tiny) channels: out[n,oy,ox, (kh*KW+kw)*c + ch],
  * zero-filled up to ldo (a whole K chunk); turns raft/update.py:100,107 (convf1, 2 -> 128, 7x7) and
@@ -266,12 +270,13 @@ int gvfi_resize_nhwc(const void* src, int lds, int src_f32, void* dst, int ldd, 
                      int N, int H, int W, int Ho, int Wo, float rscale, float mul, int dtype, void* stream);
 /* backward warp, border padding, align_corners=True; flow float [N,H,W,ldf] at channel foff, scaled by fmul */
 int gvfi_warp_nhwc(const void* src, int lds, int src_f32, const float* flow, int ldf, float fmul,
-                   void* dst, int ldd, int dst_f32, int C, int N, int H, int W, int dtype, void* stream);
+                   void* dst, int ldd, int dst_f32, int C, int N, int src_N, int H, int W, int dtype, void* stream);
 int gvfi_pixel_shuffle2(const void* src, int lds, void* dst, int ldd, int Cout, int N, int H, int W,
                         int dtype, void* stream);
 /* dst[.,0:C] = mul*src[.,0:C] (+ add[.,0:C]) with independent dtypes/pitches */
 int gvfi_copy_channels(const void* src, int lds, int src_f32, const void* add, int lda, int add_f32,
-                       void* dst, int ldd, int dst_f32, int C, float mul, long long npix, int dtype, void* stream);
+                       void* dst, int ldd, int dst_f32, int C, float mul, long long npix, long long src_npix, int dtype,
+                       void* stream);
 /* per-sample time scaling of a flow field: dst0 = -t*f, dst1 = (1-t)*f   (gimmvfi_r.py:239-240) */
 int gvfi_flow_split_t(const float* flow_t, const float* t, float* ft0, float* ft1, int B, int HW, void* stream);
 /* lookup coordinates of gimmvfi_r.py:494-507: c0 = grid + fl1/(1-t), c1 = grid + fl0/t */
@@ -344,7 +349,7 @@ int gvfi_softmax_rows(const float* x, int n, void* y, int ldy, long long rows, i
 /* ---- frame synthesis glue (modules/fi_components.py:57-94,255-340; gimmvfi_r.py:213-220,305-308) */
 /* out = clamp((sigmoid(mask)*warp(img0,f0) + (1-sigmoid(mask))*warp(img1,f1) + 1)/2, 0, 1), NCHW float */
 int gvfi_warp_blend(const float* img4_0, const float* img4_1, const float* f0, const float* f1,
-                    const float* mask, float* out_nchw, int B, int H, int W, void* stream);
+                    const float* mask, float* out_nchw, int B, int src_B, int H, int W, void* stream);
 /* multi_flow_combine front half: 3 candidate blends + residual -> act [B,H,W,pad>=9] dtype, mean [B,H,W,4] float.
  * dec = final decoder output float [B,H,W,24] = [flow0(6) flow1(6) mask(3, post-sigmoid) res(9)] */
 int gvfi_combine_warps(const float* img4_0, const float* img4_1, const float* dec, int ldd, void* act, int lda,
@@ -354,8 +359,8 @@ int gvfi_combine_warps(const float* img4_0, const float* img4_1, const float* de
  * copies of the up-sampled flows that forward() returns as flowt0_pred[0] / flowt1_pred[0] (NULL = not wanted).
  * H == Hf is allowed (plain multi_flow_combine + the planar flows). */
 int gvfi_combine_warps_up(const float* img4_0, const float* img4_1, const float* dec, int ldd, int H, int W, void* act,
-                          int lda, int pad, float* mean4, float* flow0_planar, float* flow1_planar, int B, int Hf,
-                          int Wf, int dtype, void* stream);
+                          int lda, int pad, float* mean4, float* flow0_planar, float* flow1_planar, int B, int src_B,
+                          int Hf, int Wf, int dtype, void* stream);
 /* final decoder head fix-up (fi_components.py:331-340): dec[.,0:6]+=flow0 x3, [6:12]+=flow1 x3,
  * [12:15] = sigmoid(dec + mask) ; flows float [.,2], mask float [.,1] */
 int gvfi_decoder_head(float* dec, int ldd, const float* flow0, const float* flow1, const float* mask,

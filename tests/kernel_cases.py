@@ -555,9 +555,26 @@ def combine_warps_up_case(rt, B=2, H=12, W=20, scale=2):
     mean42 = rt.f32(B, Hf, Wf, 4)
     f02, f12 = rt.f32(B, 3, 2, Hf, Wf), rt.f32(B, 3, 2, Hf, Wf)
     rt._chk(rt.lib.combine_warps_up(i0d.data_ptr(), i1d.data_ptr(), dec_d.data_ptr(), 24, H, W, cw2.data_ptr(),
-                                    cw2.shape[-1], cw2.shape[-1], mean42.data_ptr(), f02.data_ptr(), f12.data_ptr(), B,
+                                    cw2.shape[-1], cw2.shape[-1], mean42.data_ptr(), f02.data_ptr(), f12.data_ptr(), B, 0,
                                     Hf, Wf, rt.dtype, rt.stream()), "combine_warps_up")
     assert torch.equal(cw2.cpu(), cw.cpu())
+    # timestep-batched form: the decoder output of 2 timesteps [t][b] against the SAME B source images (src_B = B)
+    # == the two timesteps run separately
+    dec2 = torch.cat([dec_d, dec_d.flip(-3).contiguous()], 0).contiguous()
+    cw3 = rt.act(2 * B, Hf, Wf, 9, zero=False)
+    mean43 = rt.f32(2 * B, Hf, Wf, 4)
+    f03, f13 = rt.f32(2 * B, 3, 2, Hf, Wf), rt.f32(2 * B, 3, 2, Hf, Wf)
+    rt._chk(rt.lib.combine_warps_up(i0d.data_ptr(), i1d.data_ptr(), dec2.data_ptr(), 24, H, W, cw3.data_ptr(),
+                                    cw3.shape[-1], cw3.shape[-1], mean43.data_ptr(), f03.data_ptr(), f13.data_ptr(), 2 * B, B,
+                                    Hf, Wf, rt.dtype, rt.stream()), "combine_warps_up")
+    cw4 = rt.act(B, Hf, Wf, 9, zero=False)
+    mean44 = rt.f32(B, Hf, Wf, 4)
+    rt._chk(rt.lib.combine_warps_up(i0d.data_ptr(), i1d.data_ptr(), dec2[B:].data_ptr(), 24, H, W, cw4.data_ptr(),
+                                    cw4.shape[-1], cw4.shape[-1], mean44.data_ptr(), None, None, B, 0,
+                                    Hf, Wf, rt.dtype, rt.stream()), "combine_warps_up")
+    assert torch.equal(cw3[:B].cpu(), cw.cpu()) and torch.equal(cw3[B:].cpu(), cw4.cpu())
+    assert torch.equal(mean43[:B].cpu(), mean4.cpu()) and torch.equal(mean43[B:].cpu(), mean44.cpu())
+    assert torch.equal(f03[:B].cpu(), f02.cpu())
     assert torch.equal(mean42.cpu(), mean4.cpu())
     assert torch.equal(f02.cpu().reshape(B, 6, Hf, Wf), f0.cpu())
     assert torch.equal(f12.cpu().reshape(B, 6, Hf, Wf), f1.cpu())

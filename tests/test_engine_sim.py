@@ -72,3 +72,34 @@ def test_sequence_mode_shares_encoder_work_and_changes_nothing(sd):
     for i in range(2):
         assert maxabs(a["imgt_pred"][i], b["imgt_pred"][i]) < 1e-5
         assert maxabs(a["flowt"][i], b["flowt"][i]) < 1e-4
+
+
+def test_timestep_batched_synthesis_equals_one_by_one(sd):
+    """Engine.forward runs frame synthesis of several timesteps as ONE batch [t][b] whose t-independent sources (images,
+    context features, correlation pyramids) are read modulo the pair batch by the warp / copy / look-up / combine kernels
+    (gvfi_*'s src_N): same frames, flows and stage taps as the reference's one-timestep-at-a-time loop
+    (gimmvfi_r.py:376-396), here with T = 3, B = 2 and a group bound that splits the timesteps 2 + 1."""
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    x = synthetic_pairs(2, 128, 128, seed=41)
+    tl = (0.25, 0.5, 0.875)
+    coords = [(orc.sample_coord_input(2, (128, 128), [t], 1.0), None) for t in tl]
+    ts = [t * torch.ones(2) for t in tl]
+    eng = Engine(SimRuntime("fp32"), sd)
+    outs, taps = [], []
+    for pix in (0, 2 * 2 * 128 * 128, 10 ** 9):            # one by one | groups of 2 + 1 | all three together
+        eng.t_batch_pix = pix
+        tp = {}
+        outs.append(eng.forward(x, coords, ts, taps=tp))
+        taps.append(tp)
+    for o, tp in zip(outs[1:], taps[1:]):
+        for i in range(3):
+            assert maxabs(o["imgt_pred"][i], outs[0]["imgt_pred"][i]) < 1e-5
+            assert tuple(o["imgt_pred"][i].shape) == (2, 3, 128, 128)
+            for k in ("flowt0_pred", "flowt1_pred"):
+                for a, b in zip(o[k][i], outs[0][k][i]):
+                    assert a.shape == b.shape and maxabs(a, b) < 1e-4
+            assert maxabs(o["other_pred"][i][0], outs[0]["other_pred"][i][0]) < 1e-5
+            assert maxabs(o["flowt"][i], outs[0]["flowt"][i]) < 1e-4     # (same launches; the splat's float atomics reorder)
+            for name in ("init_ft_4", "upd_ft_4", "upd_flow0_4", "final_res"):
+                assert maxabs(tp[f"t{i}_{name}"], taps[0][f"t{i}_{name}"]) < 1e-4, (i, name)

@@ -147,3 +147,37 @@ def test_png_writer_is_lossless_and_standard():
         im.load()
         assert im.mode == "RGB" and im.size == (f.shape[1], f.shape[0])
         assert np.array_equal(np.array(im), f)
+
+
+def test_prefetcher_under_the_round_schedule_decodes_only_the_ranks_frames():
+    """with world > 1 a rank asks for non-contiguous blocks of the video.  The prefetcher is given the
+    rank's own frame order: it decodes those frames only (about frames / world, not the whole video) and holds a bounded
+    number of futures / ready frames at any time -- rank 3 of 8 over 160 pairs used to decode 158 of 161 frames and keep
+    128 pinned tensors it never popped."""
+    from gimmvfi_hip import shard
+
+    num_pairs, bsz, world, rank = 160, 4, 8, 3
+    rounds = shard.round_schedule(num_pairs, bsz, world)
+    my_blocks = [rnd[rank] for rnd in rounds]
+    my_frames = [j for j0, b in my_blocks if b > 0 for j in range(j0, j0 + b + 1)]
+    calls, lock = [], threading.Lock()
+
+    def decode(path):
+        with lock:
+            calls.append(path)
+        return torch.full((1, 3, 2, 2), float(path))
+
+    lookahead = bsz + 3
+    pf = FramePrefetcher(list(range(num_pairs + 1)), "cpu", lookahead=lookahead, workers=3, decode=decode, order=my_frames)
+    worst = 0
+    for j0, b in my_blocks:
+        for j in range(j0, j0 + b + 1):
+            assert float(pf.get(j)[0, 0, 0, 0]) == j
+            worst = max(worst, len(pf.futures) + len(pf.ready))
+    pf.close()
+    assert sorted(calls) == sorted(set(my_frames)) and pf.decodes == len(set(my_frames))
+    assert len(set(my_frames)) == (bsz + 1) * len(rounds)            # 25 of 161 frames for this rank
+    assert worst <= lookahead + 3, worst                             # look-ahead + the sliding pair window
+    assert not pf.futures                                            # nothing left behind
+    with pytest.raises(KeyError):
+        pf.get(0)                                                    # a frame of another rank

@@ -109,6 +109,24 @@ def test_wrapper_error_behaviour():
         ss.softsplat(x, flow, metric, "median")
     with pytest.raises(AssertionError):
         ss.softsplat_func.apply(x, flow)               # CPU tensors: softsplat.py:439-440 `assert False`
+    for bad in ("sum-addeps", "avg-zeroeps"):          # the reference only knows the bare words; with a suffix it silently
+        with pytest.raises(AssertionError):            # divides by the last INPUT channel -- rejected
+            ss.softsplat(x, flow, None, bad)
+
+
+def test_unknown_eps_suffix_leaves_the_normaliser_untouched(monkeypatch):
+    """softsplat.py:325-334 is an if / elif chain without an else: "linear-foo" divides by the raw splatted weight (holes
+    give 0 / 0 = NaN and trip the NaN check).  On hole-free input the result equals the plain quotient."""
+    from gimmvfi_hip import softsplat as ss
+
+    monkeypatch.setattr(ss, "softsplat_func", _HostsimSplat)
+    x, _, metric = _inputs(seed=6)
+    flow = torch.zeros(x.shape[0], 2, *x.shape[2:]) + 0.25          # every target pixel receives weight
+    o, n = ss.softsplat(x, flow, metric, "linear-foo", return_norm=True)
+    raw = orc.splat_sum(torch.cat([x * metric, metric], 1), flow)
+    assert torch.equal(n, raw[:, -1:]) or float((n - raw[:, -1:]).abs().max()) < 1e-6
+    o2, n2 = ss.softsplat(x, flow, metric, "linear", return_norm=True)
+    assert float((n2 - n).abs().max()) > 0 and float((n2 - n - 1e-7).abs().max()) < 1e-6
 
 
 @pytest.mark.gpu
