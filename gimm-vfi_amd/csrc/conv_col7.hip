@@ -283,6 +283,12 @@ __global__ void __launch_bounds__(256) conv_col7_kernel(Col7Args a) {
             unsigned char* yb = (unsigned char*)p.y + t0 * ysz;
             const unsigned char* rb_ = (const unsigned char*)p.res + t0 * rsz;
             const int nunits = C7_T * C7_T * a.upp, upr = C7_T * a.upp;
+            // algo bit 6: the 3-channel float result leaves as imgt_pred = clamp((y + 1) / 2, 0, 1) in PLANAR (N, 3, Ho, Wo)
+            // float at y2 (gimmvfi_r.py:308, fi_components.py:92) -- the arithmetic of gvfi_finalize_image on the value that
+            // would have been stored to y; the NHWC y itself is not written (one pass less over the full-resolution frame)
+            const bool planar = (p.algo & 64) != 0;
+            float* pl = (float*)p.y2 + (long long)n_img * 3 * p.Ho * p.Wo + (long long)oy0 * p.Wo + ox0;
+            const long long plane = (long long)p.Ho * p.Wo;
             constexpr int PF = 4;
 #pragma unroll 1
             for (int u0 = tid; u0 < nunits; u0 += 256 * PF) {
@@ -315,6 +321,13 @@ __global__ void __launch_bounds__(256) conv_col7_kernel(Col7Args a) {
                         f.w = cl > 3 ? f.w + rv[k].w : 0.f;
                         val[k] = __builtin_bit_cast(uint4, f);
                     }
+                    if (planar) {
+                        const float4 f = __builtin_bit_cast(float4, val[k]);
+                        pl[pixo[k]] = fminf(fmaxf((f.x + 1.0f) / 2.0f, 0.f), 1.f);
+                        pl[plane + pixo[k]] = fminf(fmaxf((f.y + 1.0f) / 2.0f, 0.f), 1.f);
+                        pl[2 * plane + pixo[k]] = fminf(fmaxf((f.z + 1.0f) / 2.0f, 0.f), 1.f);
+                        continue;
+                    }
                     *(uint4*)(yb + (pixo[k] * ysz + jj[k] * 16u)) = val[k];
                 }
             }
@@ -337,6 +350,7 @@ static int col7_plan(const gvfi_conv_params& p, Col7Args& a) {
     if ((p.ldy * ey) % 16 || ((uintptr_t)p.y & 15) || ((uintptr_t)p.x0 & 15) || ((uintptr_t)p.w & 15)) return 0;
     if (p.res != nullptr && (!p.res_f32 || !p.y_f32 || ((p.ldr * 4) % 16) || ((uintptr_t)p.res & 15))) return 0;
     if (p.res != nullptr && p.out_scale != 1.0f) return 0;     // (the scale is applied before the residual here, after it in the other kernels)
+    if ((p.algo & 64) && (p.Cout != 3 || !p.y_f32 || p.y2 == nullptr || ((uintptr_t)p.y2 & 3))) return 0;   // planar finalize: 3 float channels
     a.p = p;
     const int cround = (p.Cout + unit - 1) / unit * unit;
     a.sb = cround * ey;

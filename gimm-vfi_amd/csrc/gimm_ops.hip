@@ -208,6 +208,160 @@ extern "C" int gvfi_softsplat_normalize(const float* acc, int C, void* dst, int 
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------ the same splat as a deterministic gather
+// The scatter above issues (C+1) x 4 device-scope float atomics per source pixel (62 M for 8 x 256 x 448: 1.8 TB/s of fabric
+// traffic for 132 MB of algorithmic bytes, and a sum whose rounding depends on arrival order).  Here a source pixel is
+// entered ONCE into the list of the cell (floor(fx), floor(fy)) of its target (one integer exchange), and every TARGET
+// pixel then walks the lists of the four cells whose sources reach it -- (tx-1..tx) x (ty-1..ty) -- and adds their
+// contributions in ascending source index: one writer per output, no float atomics, a result that does not depend on
+// scheduling, and the "linear-zeroeps" normalisation (softsplat.py:325-344) applied in the same pass.  Every product is
+// the reference's expression (v = lat * Z; v * w with the four corner weights of softsplat.py:394-404); only the ORDER of
+// the additions is fixed where the reference leaves it to the hardware.
+// Cells: x0 in [-1, W-1], y0 in [-1, H-1] -> (H+1) x (W+1) list heads per image and direction, -1 = empty (set by the
+// caller); next[] has one entry per source pixel.  Both directions run in one launch: image n = d * B + b with d = 0:
+// flow 0->1 scaled by t, d = 1: flow 1->0 scaled by 1 - t (gimmvfi_r.py:171-186).
+__global__ void softsplat_lists_kernel(const float* __restrict__ f01, const float* __restrict__ f10, const float* __restrict__ t,
+                                       int* __restrict__ head, int* __restrict__ next, long long total, int B, int H, int W) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over (d, b, y, x)
+    if (idx >= total) return;
+    const long long HW = (long long)H * W;
+    const long long n = idx / HW, pix = idx - n * HW;
+    const int d = (int)(n / B), b = (int)(n - (long long)d * B);
+    const int x = (int)(pix % W), y = (int)(pix / W);
+    const float* fl = (d ? f10 : f01) + ((long long)b * HW + pix) * 2;
+    const float ts = d ? (1.0f - t[b]) : t[b];
+    const float fx = (float)x + fl[0] * ts, fy = (float)y + fl[1] * ts;
+    if (!isfinite(fx) || !isfinite(fy)) return;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    if (!(x0f >= -1.0f && x0f <= (float)(W - 1) && y0f >= -1.0f && y0f <= (float)(H - 1))) return;   // no corner inside the image
+    const long long cell = (n * (H + 1) + ((int)y0f + 1)) * (long long)(W + 1) + ((int)x0f + 1);
+    next[idx] = atomicExch(head + cell, (int)pix);
+}
+template <typename T>
+__global__ void softsplat_gather_kernel(const T* __restrict__ lat, int ldl, const float* __restrict__ f01,
+                                        const float* __restrict__ f10, const float* __restrict__ z0,
+                                        const float* __restrict__ z1, const float* __restrict__ t,
+                                        const int* __restrict__ head, const int* __restrict__ next, T* __restrict__ dst, int ldd,
+                                        long long total, int B, int H, int W) {
+    constexpr int C = 16, CAP = 8, NONE = 0x7fffffff;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over (d, b, ty, tx)
+    if (idx >= total) return;
+    const long long HW = (long long)H * W;
+    const long long n = idx / HW, pix = idx - n * HW;
+    const int d = (int)(n / B), b = (int)(n - (long long)d * B);
+    const int tx = (int)(pix % W), ty = (int)(pix / W);
+    const float* fl = (d ? f10 : f01) + (long long)b * HW * 2;
+    const float* zz = (d ? z1 : z0) + (long long)b * HW;
+    const T* la = lat + (long long)b * HW * ldl + 16 * d;
+    const float ts = d ? (1.0f - t[b]) : t[b];
+    const int* nx = next + n * HW;
+    // the four cells (cx, cy) = (tx - 1 + i, ty - 1 + j) in list coordinates (+1): always inside the (H+1) x (W+1) grid
+    const int* hd = head + (n * (H + 1) + ty) * (long long)(W + 1) + tx;
+    float acc[C + 1];
+#pragma unroll
+    for (int c = 0; c <= C; ++c) acc[c] = 0.f;
+    auto add = [&](int s) {
+        const int sx = s % W, sy = s / W;
+        const float fx = (float)sx + fl[(long long)s * 2] * ts, fy = (float)sy + fl[(long long)s * 2 + 1] * ts;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+        // the corner of the source's 2 x 2 footprint this target is: the reference's four weight expressions
+        const float wx = tx == x0 ? ((float)x1 - fx) : (fx - (float)x0);
+        const float wy = ty == y0 ? ((float)y1 - fy) : (fy - (float)y0);
+        const float w = wx * wy;
+        const float zv = zz[s];
+        constexpr int NV = C * (int)sizeof(T) / 16;          // 16-byte vectors of the source's latent
+        uint4 q[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) q[k] = ((const uint4*)(la + (long long)s * ldl))[k];
+        const T* e = (const T*)q;
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += (Elem<T>::ld(e + c) * zv) * w;
+        acc[C] += zv * w;
+    };
+    // sources of the four lists in ascending index: up to CAP of them through a sorted register array ...
+    int a[CAP];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) a[k] = NONE;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int s = hd[(long long)j * (W + 1) + i];
+            while (s >= 0) {
+                ++cnt;
+                int e = s;
+#pragma unroll
+                for (int k = 0; k < CAP; ++k) {
+                    const int lo = e < a[k] ? e : a[k];
+                    e = e < a[k] ? a[k] : e;
+                    a[k] = lo;
+                }
+                s = nx[s];
+            }
+        }
+    if (cnt <= CAP) {
+        for (int k = 0; k < cnt; ++k) {
+            add(a[0]);
+#pragma unroll
+            for (int q = 0; q + 1 < CAP; ++q) a[q] = a[q + 1];
+        }
+    } else {
+        // ... longer lists (many sources converging on one cell): repeated selection of the next larger index
+        int last = -1;
+        for (int k = 0; k < cnt; ++k) {
+            int best = NONE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int s = hd[(long long)j * (W + 1) + i];
+                    while (s >= 0) {
+                        if (s > last && s < best) best = s;
+                        s = nx[s];
+                    }
+                }
+            add(best);
+            last = best;
+        }
+    }
+    float nrm = acc[C];
+    if (nrm == 0.0f) nrm = 1.0f;
+    __attribute__((aligned(16))) T o[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) Elem<T>::st(o + c, acc[c] / nrm);
+    T* dp = dst + ((long long)b * HW + pix) * ldd + 16 * d;
+    if (sizeof(T) == 2) {
+        *(uint4*)dp = *(const uint4*)o;
+        *(uint4*)(dp + 8) = *(const uint4*)(o + 8);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) dp[c] = o[c];
+    }
+}
+extern "C" int gvfi_softsplat_lists(const float* f01, const float* f10, const float* t, int* head, int* next, int B, int H,
+                                    int W, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffll) return -2;
+    const long long total = 2LL * B * H * W;
+    GVFI_LAUNCH_SIMPLE(softsplat_lists_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, f01, f10, t, head, next,
+                       total, B, H, W);
+    return (int)hipGetLastError();
+}
+extern "C" int gvfi_softsplat_gather(const void* lat, int ldl, const float* f01, const float* f10, const float* z0,
+                                     const float* z1, const float* t, const int* head, const int* next, void* dst, int ldd,
+                                     int B, int H, int W, int dtype, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return -2;
+    // lat: [B,H,W,ldl] with the direction-d latent in channels [16 d, 16 d + 16); dst likewise (16-byte aligned rows)
+    if (dtype != GVFI_F32 && ((((uintptr_t)lat | (uintptr_t)dst) & 15) || (ldl & 7) || (ldd & 7))) return -2;
+    if (dtype == GVFI_F32 && ((((uintptr_t)lat) & 15) || (ldl & 3))) return -2;
+    const long long total = 2LL * B * H * W;
+    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((softsplat_gather_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
+                                              (hipStream_t)stream, (const T*)lat, ldl, f01, f10, z0, z1, t, head, next,
+                                              (T*)dst, ldd, total, B, H, W));
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ the reference's native op, same contract
 // softsplat_func.forward / kernel `softsplat_out` (modules/softsplat.py:358-446): tenIn (N,C,H,W) f32, tenFlow (N,2,H,W)
 // f32, tenOut (N,C,H,W) f32 ZERO-INITIALISED BY THE CALLER, accumulated with float atomics.  One thread per (n, y, x);

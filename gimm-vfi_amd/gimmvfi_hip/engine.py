@@ -65,6 +65,8 @@ class Engine:
         # timesteps are independent once their flows exist.  Upper bound on T*B*H*W working-resolution pixels per batch
         # (activation memory: ~6 KB per pixel); 0 = one timestep at a time
         self.t_batch_pix = int(float(os.environ.get("GVFI_T_BATCH_PIX", "4.1e6")))
+        # softmax splat as a deterministic gather over per-cell source lists (csrc/gimm_ops.hip); 0 = the float-atomic scatter
+        self.splat_gather = os.environ.get("GVFI_SPLAT_GATHER", "1") != "0"
         self.layers = {}
         self._build(sd)
 
@@ -483,13 +485,23 @@ class Engine:
         HW = H * W
         Hc, Wc = cg.shape[2], cg.shape[3]
         # softmax splatting of the two latents to time t   gimmvfi_r.py:171-193
-        for d, (fl, zz) in enumerate(((f01, z0), (f10, z1))):
-            acc = rt.f32(B, H, W, 17, zero=True)
-            rt._chk(lib.softsplat_accum(View(latcat, 16 * d, 16).ptr, latcat.shape[-1], 16, fl.data_ptr(),
-                                        zz.data_ptr(), tv.data_ptr(), d, acc.data_ptr(), B, H, W, rt.dtype, st()),
-                    "softsplat_accum")
-            rt._chk(lib.softsplat_normalize(acc.data_ptr(), 16, View(latcat, 32 + 16 * d, 16).ptr,
-                                            latcat.shape[-1], B * HW, rt.dtype, st()), "softsplat_normalize")
+        if self.splat_gather:
+            # deterministic gather over per-cell source lists, both directions and the normalisation in one launch
+            head = torch.full((2, B, H + 1, W + 1), -1, dtype=torch.int32, device=rt.device)
+            nxt = torch.empty((2, B, H, W), dtype=torch.int32, device=rt.device)
+            rt._chk(lib.softsplat_lists(f01.data_ptr(), f10.data_ptr(), tv.data_ptr(), head.data_ptr(), nxt.data_ptr(), B, H, W,
+                                        st()), "softsplat_lists")
+            rt._chk(lib.softsplat_gather(latcat.data_ptr(), latcat.shape[-1], f01.data_ptr(), f10.data_ptr(), z0.data_ptr(),
+                                         z1.data_ptr(), tv.data_ptr(), head.data_ptr(), nxt.data_ptr(), View(latcat, 32, 32).ptr,
+                                         latcat.shape[-1], B, H, W, rt.dtype, st()), "softsplat_gather")
+        else:
+            for d, (fl, zz) in enumerate(((f01, z0), (f10, z1))):
+                acc = rt.f32(B, H, W, 17, zero=True)
+                rt._chk(lib.softsplat_accum(View(latcat, 16 * d, 16).ptr, latcat.shape[-1], 16, fl.data_ptr(),
+                                            zz.data_ptr(), tv.data_ptr(), d, acc.data_ptr(), B, H, W, rt.dtype, st()),
+                        "softsplat_accum")
+                rt._chk(lib.softsplat_normalize(acc.data_ptr(), 16, View(latcat, 32 + 16 * d, 16).ptr,
+                                                latcat.shape[-1], B * HW, rt.dtype, st()), "softsplat_normalize")
         r0 = rt.act(B, H, W, 32)
         rt.conv(Ls["res_conv.0"], latcat, r0)
         r1 = rt.act(B, H, W, 64)
@@ -809,9 +821,12 @@ class Engine:
         # (pad16: cb's channels 18..23 and o4's / mean4's channel 3 are padding owned here -> whole 16-byte stores)
         rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU, pad16=True, algo=rt.comb_algo)
         o4 = rt.f32(B, Hf, Wf, 4)
-        rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3), pad16=True, algo=rt.comb_algo)
         pred = rt.f32(B, 3, Hf, Wf)
-        rt._chk(lib.finalize_image(o4.data_ptr(), 4, pred.data_ptr(), B, Hf, Wf, st()), "finalize_image")
+        # (the column kernel stores clamp((y + 1) / 2, 0, 1) straight into the planar frame; other kernels leave o4 to finalize_image)
+        rt.conv(Ls["amt_comb_block.2"], View(cb, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3), pad16=True, algo=rt.comb_algo,
+                planar3=pred if rt.fold_finalize else None)
+        if not rt.last_planar:
+            rt._chk(lib.finalize_image(o4.data_ptr(), 4, pred.data_ptr(), B, Hf, Wf, st()), "finalize_image")
         f04 = rt.nhwc_to_nchw(View(st4, 0, 2), 2)
         f14 = rt.nhwc_to_nchw(View(st4, 2, 2), 2)
         return pred, [f01, f04], [f11, f14], others

@@ -260,6 +260,8 @@ class Runtime:
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
         self._lanes = {}         # stream id -> extra streams for lanes()
         self.last_stats_fused = False
+        self.last_planar = False
+        self.fold_finalize = os.environ.get("GVFI_FOLD_FINALIZE", "1") != "0"   # A/B switch: finalize_image inside the last 7x7 layer
 
     def sibling(self, precision):
         """A runtime of another precision over the same library and device (GIMM-VFI-F's float flow-estimator stages)."""
@@ -309,8 +311,11 @@ class Runtime:
     # ------------------------------------------------------------------ convolution
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False):
-        """state_f32 (GRU epilogues, bf16 mode): the recurrent state tensors are float (gvfi_conv_params.state_f32).
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False, planar3=None):
+        """planar3: float (N, 3, Ho, Wo) tensor -- when the column kernel takes this launch (3 float output channels) the result
+        leaves finalised, clamp((y + 1) / 2, 0, 1), in planar form there and `out` is NOT written (gvfi_finalize_image folded
+        in); ``self.last_planar`` says whether that happened (else the caller finalises `out` itself).
+        state_f32 (GRU epilogues, bf16 mode): the recurrent state tensors are float (gvfi_conv_params.state_f32).
         stats: optional zero-initialised f32 [N, cout, 2]; when the library can fuse the InstanceNorm statistics
         into this convolution (gvfi_conv2d_stats_ok) they are accumulated there and True is returned in
         ``self.last_stats_fused``, else the caller computes them with instnorm_stats."""
@@ -411,6 +416,16 @@ class Runtime:
             # A/B switch GVFI_P3X3=0: with algo 0 the LIBRARY would still route to the halo-staged / patch kernels by itself;
             # an explicit algo (LDS-DMA where it is eligible, else generic) makes the baseline really theirs
             p.algo = (2 if self.lib.conv2d_glds_eligible(C.byref(p)) else 1) | (p.algo & ~15)
+        self.last_planar = False
+        if planar3 is not None and layer is not None:
+            assert planar3.dtype == torch.float32 and planar3.is_contiguous() and tuple(planar3.shape) == (n, 3, p.Ho, p.Wo)
+            keep_algo, keep_y2 = p.algo, p.y2
+            p.algo, p.y2 = p.algo | 64, planar3.data_ptr()
+            plan = (C.c_int * 5)()
+            if self.lib.conv2d_col7_eligible(C.byref(p)) >= 1 and self.lib.conv2d_plan(C.byref(p), plan) == 0 and plan[0] == 7:
+                self.last_planar = True
+            else:
+                p.algo, p.y2 = keep_algo, keep_y2
         self.last_stats_fused = False
         if stats is not None:
             p.stats = stats.data_ptr()

@@ -104,6 +104,10 @@ typedef struct {
                                          * y and res up to the next 16-byte boundary -- a ragged   *
                                          * last channel group may be accessed in whole 16-byte     *
                                          * units, y's pad channels receive zeros (patch kernel);   *
+                                         * bit 6 (column kernel, Cout 3, float y): the result is   *
+                                         * finalised to clamp((y + 1) / 2, 0, 1) and stored PLANAR *
+                                         * (N, 3, Ho, Wo) float at y2; y is not written           *
+                                         * (gvfi_finalize_image folded into the last layer);       *
                                          * bit 5 / 7: A/B switches (8-wave tile: DMA issue spread *
                                          * over the MFMA groups; 64-byte K chunks), bits 8..:      *
                                          * profiling switches (skip phases, s_memtime stamps)     */
@@ -243,6 +247,18 @@ int gvfi_splat_weights(const float* f01, const float* f10, const float* gfilt9, 
 int gvfi_softsplat_accum(const void* lat, int ldl, int C, const float* flow, const float* z, const float* t,
                          int one_minus_t, float* acc, int B, int H, int W, int dtype, void* stream);
 int gvfi_softsplat_normalize(const float* acc, int C, void* dst, int ldd, long long npix, int dtype, void* stream);
+/* the same softmax splat + "linear-zeroeps" normalisation as a DETERMINISTIC gather, both directions in one launch
+ * (softsplat.py:286-352, 371-421; gimmvfi_r.py:171-193): gvfi_softsplat_lists enters every source pixel into the list
+ * of its target cell (floor(x + t_d * flow), one integer exchange per pixel); gvfi_softsplat_gather walks, per target
+ * pixel, the four cells whose sources reach it and adds their contributions in ascending source index -- no float
+ * atomics, a result independent of scheduling.  head: int [2][B][H+1][W+1] set to -1 by the caller; next: int [2][B][H][W]
+ * (scratch).  lat [B,H,W,ldl]: direction d's 16 latent channels at [16 d, 16 d + 16); dst likewise; t [B]: direction 0
+ * uses t, direction 1 uses 1 - t. */
+int gvfi_softsplat_lists(const float* f01, const float* f10, const float* t, int* head, int* next, int B, int H, int W,
+                         void* stream);
+int gvfi_softsplat_gather(const void* lat, int ldl, const float* f01, const float* f10, const float* z0, const float* z1,
+                          const float* t, const int* head, const int* next, void* dst, int ldd, int B, int H, int W,
+                          int dtype, void* stream);
 /* The reference's native op with its own contract -- softsplat_func.forward / CuPy kernel `softsplat_out`
  * (modules/softsplat.py:358-446): tenIn (N,C,H,W) f32, tenFlow (N,2,H,W) f32, tenOut (N,C,H,W) f32 that the CALLER has
  * zero-initialised (softsplat.py:362-364), accumulated with float atomics on `stream`. */

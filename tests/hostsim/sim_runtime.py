@@ -69,11 +69,12 @@ class SimRuntime(Runtime):
 
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False):
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False, planar3=None):
         if self.emulate_conv:
             return super().conv(layer, x0, out, x1, act1, res, act2, out_scale, slope1, slope2, epi, y2, aux0, aux1,
-                                groups, w_group_stride, w_raw, cout, tile, algo, stats, pad16, state_f32)
+                                groups, w_group_stride, w_raw, cout, tile, algo, stats, pad16, state_f32, planar3)
         self.last_stats_fused = False     # the torch statement leaves the statistics to gvfi_instnorm_stats
+        self.last_planar = False          # ... and the planar finalisation to gvfi_finalize_image
         return self._torch_conv(layer, V(x0), V(out), None if x1 is None else V(x1), act1, res, act2, out_scale,
                                 slope1, slope2, epi, y2, aux0, aux1, groups, w_raw, cout)
 

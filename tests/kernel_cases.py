@@ -503,6 +503,83 @@ def splat_case(rt, B=2, H=12, W=20, C=16):
         assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max()))
 
 
+def col7_planar_case(rt, N=2, H=37, W=45, seed=8):
+    """Column kernel, last layer of the combination block (18 -> 3, float residual): the folded finalisation (algo bit 6:
+    clamp((y + 1) / 2, 0, 1) stored planar at y2, y untouched) equals the NHWC result + gvfi_finalize_image bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    dev = _dev(rt)
+    x = _rounded(rt, torch.randn(N, 18, H, W, generator=g))
+    w = _rounded(rt, torch.randn(3, 18, 7, 7, generator=g) / (18 * 49) ** 0.5)
+    lay = ConvLayer(rt, w, torch.randn(3, generator=g))
+    xa = rt.act(N, H, W, 18, zero=True)
+    xa[..., :18] = x.permute(0, 2, 3, 1).to(xa.dtype)
+    xa = xa.to(dev)
+    mean4 = (torch.rand(N, H, W, 4, generator=g) * 2 - 1).to(dev)
+    o4 = rt.f32(N, H, W, 4)
+    rt.conv(lay, View(xa, 0, 18), View(o4, 0, 3), res=View(mean4, 0, 3), pad16=True, algo=7)
+    assert not rt.last_planar
+    want = rt.f32(N, 3, H, W)
+    rt._chk(rt.lib.finalize_image(o4.data_ptr(), 4, want.data_ptr(), N, H, W, rt.stream()), "finalize_image")
+    o4b = rt.f32(N, H, W, 4)
+    o4b.fill_(7.0)
+    got = rt.f32(N, 3, H, W)
+    got.fill_(-5.0)
+    rt.conv(lay, View(xa, 0, 18), View(o4b, 0, 3), res=View(mean4, 0, 3), pad16=True, algo=7, planar3=got)
+    assert rt.last_planar
+    assert torch.equal(got.cpu(), want.cpu())
+    assert float((o4b.cpu() - 7.0).abs().max()) == 0.0          # the NHWC tensor is not written
+    assert float(want.min()) >= 0.0 and float(want.max()) <= 1.0 and float(want.std()) > 0.05
+
+
+def splat_gather_case(rt, B=2, H=12, W=20, converge=False):
+    """The list-based gather form of the softmax splat (gvfi_softsplat_lists + gvfi_softsplat_gather): both directions in one
+    launch, the same edge cases as splat_case, against the oracle; bit-identical over repeated runs (one writer per output,
+    fixed order of additions); converge: all sources of a 6 x 6 block land in ONE cell (lists longer than the register
+    array -> the repeated-selection branch)."""
+    g = torch.Generator().manual_seed(15)
+    dev = _dev(rt)
+    C = 16
+    lat = [_rounded(rt, torch.randn(B, C, H, W, generator=g)) for _ in range(2)]
+    flow = [torch.randn(B, 2, H, W, generator=g) * 5 for _ in range(2)]
+    flow[0][0, :, 2, 3] = float("nan")
+    flow[0][0, 0, 4, 5] = float("inf")
+    flow[1][1, :, :, :6] = 40.0          # splat a whole band out of the image -> holes
+    flow[1][0, :, 0, 0] = float("-inf")
+    t = torch.tensor([0.3, 0.75])[:B]
+    if converge:
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        for d in range(2):       # pixels (2..7, 3..8) of image 0 all move to (5.3, 6.6) at this direction's time scale
+            ts0 = float((1 - t[0]) if d else t[0])
+            flow[d][0, 0, 2:8, 3:9] = (6.6 - xs[2:8, 3:9]) / ts0
+            flow[d][0, 1, 2:8, 3:9] = (5.3 - ys[2:8, 3:9]) / ts0
+    z = [torch.rand(B, 1, H, W, generator=g) + 0.5 for _ in range(2)]
+    latcat = rt.act(B, H, W, 64, zero=True)
+    for d in range(2):
+        latcat[..., 16 * d:16 * d + 16] = _to_act(rt, lat[d]).to(dev)[..., :16]
+    fd = [f.permute(0, 2, 3, 1).contiguous().to(dev) for f in flow]
+    zd = [zz.reshape(B, H, W).contiguous().to(dev) for zz in z]
+    td = t.to(dev)
+    outs = []
+    for _ in range(3):
+        head = torch.full((2, B, H + 1, W + 1), -1, dtype=torch.int32, device=dev)
+        nxt = torch.empty((2, B, H, W), dtype=torch.int32, device=dev)
+        latcat[..., 32:] = 7.0
+        rt._chk(rt.lib.softsplat_lists(fd[0].data_ptr(), fd[1].data_ptr(), td.data_ptr(), head.data_ptr(), nxt.data_ptr(), B, H, W,
+                                       rt.stream()), "softsplat_lists")
+        rt._chk(rt.lib.softsplat_gather(latcat.data_ptr(), latcat.shape[-1], fd[0].data_ptr(), fd[1].data_ptr(), zd[0].data_ptr(),
+                                        zd[1].data_ptr(), td.data_ptr(), head.data_ptr(), nxt.data_ptr(),
+                                        View(latcat, 32, 32).ptr, latcat.shape[-1], B, H, W, rt.dtype, rt.stream()), "softsplat_gather")
+        outs.append(latcat.float().cpu().clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])        # deterministic
+    assert torch.equal(outs[0][..., :32], torch.cat([_to_act(rt, lat[0])[..., :16], _to_act(rt, lat[1])[..., :16]], -1).float().cpu())
+    for d in range(2):
+        ts = (1 - t) if d else t
+        ref = orc.softsplat_linear_zeroeps(lat[d], flow[d] * ts.view(-1, 1, 1, 1), z[d])
+        o = outs[0][..., 32 + 16 * d:48 + 16 * d].permute(0, 3, 1, 2)
+        assert torch.isfinite(o).all()
+        assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max())), (d, float((o - ref).abs().max()))
+
+
 def splat_nchw_case(rt, N=2, C=5, H=13, W=21):
     """The reference's native op contract (softsplat_func.forward, softsplat.py:358-446): NCHW f32 in / out, the
     caller zero-initialises tenOut; checked against the O(P) restatement of the CuPy kernel in the oracle."""

@@ -229,6 +229,18 @@ def test_softsplat_edge_cases(rt):
     kc.splat_case(rt)
 
 
+def test_col7_folded_finalisation_equals_finalize_image(rt):
+    if rt.precision != "bf16":
+        pytest.skip("the column kernel is bf16 only")
+    kc.col7_planar_case(rt)
+    kc.col7_planar_case(rt, N=1, H=70, W=71, seed=9)
+
+
+def test_softsplat_gather_is_deterministic_and_matches_the_oracle(rt):
+    kc.splat_gather_case(rt)
+    kc.splat_gather_case(rt, converge=True)
+
+
 def test_combine_warps_up_equals_separate_passes(rt):
     for scale in (1, 2, 4):
         kc.combine_warps_up_case(rt, scale=scale)

@@ -42,7 +42,11 @@ def variants(cout):
 def main():
     stamps_mode = "--stamps" in sys.argv
     rt = Runtime(L.get(), "bf16", "cuda:0")
+    only = os.environ.get("RING_ONLY")            # PMC passes: one shape (substring of its name) ...
+    wdir_only = os.environ.get("RING_WDIR_ONLY")  # ... and only the weights-direct variant of the tile the engine picks
     for name, N, H, W, Cin, Cout, KH, KW, split in SHAPES:
+        if only and only not in name:
+            continue
         w = torch.randn(Cout, Cin, KH, KW) / (Cin * KH * KW) ** 0.5
         lay = ConvLayer(rt, w, torch.randn(Cout), wdir=True)
         x = torch.randn(N, H, W, Cin, device="cuda").to(rt.tdtype)
@@ -56,6 +60,8 @@ def main():
         ref = None
         cells = []
         for bm, bn, ns in variants(Cout):
+            if wdir_only and not (ns == 0 and bm == 64):
+                continue
             tile = bn | (bm << 10) | (ns << 20)
             algo = 2 if ns else 6
             try:
