@@ -330,11 +330,12 @@ __global__ void warp_nhwc_vec_kernel(const T* __restrict__ src, int lds, const f
     const long long b = (src_N > 0 ? n % src_N : n) * (long long)H * W;
     const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
     const T* p00 = src + (b + (long long)y0 * W + x0) * lds + c;
+    // four unconditional vector loads in flight together (an absent neighbour re-reads the pixel itself; its weight is never used)
+    const long long ox = xin ? lds : 0, oy = yin ? (long long)W * lds : 0;
     const Vec16<T> a00 = *(const Vec16<T>*)p00;
-    Vec16<T> a01 = a00, a10 = a00, a11 = a00;
-    if (xin) a01 = *(const Vec16<T>*)(p00 + lds);
-    if (yin) a10 = *(const Vec16<T>*)(p00 + (long long)W * lds);
-    if (xin && yin) a11 = *(const Vec16<T>*)(p00 + (long long)(W + 1) * lds);
+    const Vec16<T> a01 = *(const Vec16<T>*)(p00 + ox);
+    const Vec16<T> a10 = *(const Vec16<T>*)(p00 + oy);
+    const Vec16<T> a11 = *(const Vec16<T>*)(p00 + oy + ox);
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < VE; ++e) {

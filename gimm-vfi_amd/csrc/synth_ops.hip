@@ -55,13 +55,18 @@ __device__ __forceinline__ void sample_border_rgb(const float* __restrict__ img,
     const float ax = fx - x0f, ay = fy - y0f;
     const bool x1ok = x0 + 1 < W, y1ok = y0 + 1 < H;
     const float* p = img + ((long long)y0 * W + x0) * 4;
+    // the four taps as UNCONDITIONAL 16-byte loads (an absent neighbour re-reads the pixel itself): loads inside the `if`s
+    // below cannot be hoisted by the compiler, and six samples per pixel then are 24 dependent memory round trips instead
+    // of one batch of 24 loads in flight.  The arithmetic (which taps are added, in which order) is unchanged.
+    const long long dx = x1ok ? 4 : 0, dy = y1ok ? 4LL * W : 0;
+    const float4 t00 = *(const float4*)p, t01 = *(const float4*)(p + dx);
+    const float4 t10 = *(const float4*)(p + dy), t11 = *(const float4*)(p + dy + dx);
     float w = (1.f - ax) * (1.f - ay);
-    o[0] = w * p[0]; o[1] = w * p[1]; o[2] = w * p[2];
-    if (x1ok) { w = ax * (1.f - ay); o[0] += w * p[4]; o[1] += w * p[5]; o[2] += w * p[6]; }
+    o[0] = w * t00.x; o[1] = w * t00.y; o[2] = w * t00.z;
+    if (x1ok) { w = ax * (1.f - ay); o[0] += w * t01.x; o[1] += w * t01.y; o[2] += w * t01.z; }
     if (y1ok) {
-        const float* q = p + 4LL * W;
-        w = (1.f - ax) * ay; o[0] += w * q[0]; o[1] += w * q[1]; o[2] += w * q[2];
-        if (x1ok) { w = ax * ay; o[0] += w * q[4]; o[1] += w * q[5]; o[2] += w * q[6]; }
+        w = (1.f - ax) * ay; o[0] += w * t10.x; o[1] += w * t10.y; o[2] += w * t10.z;
+        if (x1ok) { w = ax * ay; o[0] += w * t11.x; o[1] += w * t11.y; o[2] += w * t11.z; }
     }
 }
 
@@ -142,22 +147,45 @@ extern "C" int gvfi_combine_warps(const float* img4_0, const float* img4_1, cons
 // ~4.6 ms of the 19 ms per timestep.  Per-channel arithmetic is that of resize_nhwc_kernel (mul * (ly.w0*(lx.w0*v00 +
 // lx.w1*v01) + ly.w1*(lx.w0*v10 + lx.w1*v11))) followed by that of combine_warps_kernel, so the results are bit-equal to
 // the separate passes; with H == Hf (rscale = inv = 1) the interpolation weights are exactly (1, 0).
-template <typename T>
-__global__ void combine_warps_up_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
+// STAGE (up-sampling by >= 2, Wf a multiple of the block): a block is 256 consecutive pixels of ONE full-resolution row; the
+// <= 130 x 2 decoder pixels its bilinear taps touch are copied to LDS once (3 float4 loads per thread instead of 24 through
+// the texture path: at 4K, 7 timesteps, the kernel was 3.6 ms at 2.3x its L1-path bound) and the taps are LDS reads.  The
+// values read are the same, so the results are bit-identical to the direct form.
+#define CWU_SPAN 130
+template <typename T, bool STAGE>
+__global__ void __launch_bounds__(256) combine_warps_up_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
                                         const float* __restrict__ dec, int ldd, int H, int W, float rscale, float inv,
                                         T* __restrict__ act, int lda, int pad, float* __restrict__ mean4,
                                         float* __restrict__ f0p, float* __restrict__ f1p, long long total, int Hf, int Wf,
                                         int src_B) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
     const long long HWf = (long long)Hf * Wf;
+    __shared__ __attribute__((aligned(16))) float sdec[STAGE ? 2 * CWU_SPAN * 24 : 4];
+    int sx0 = 0;
+    if (STAGE) {
+        // (Wf % 256 == 0: the block lies in one row of one image, and total is a multiple of the block)
+        const long long idx0 = (long long)blockIdx.x * 256;
+        const long long pix0 = idx0 % HWf, b0 = idx0 / HWf;
+        const int xb = (int)(pix0 % Wf), yb = (int)(pix0 / Wf);
+        const Lerp lyb = src_index(yb, rscale, H);
+        sx0 = src_index(xb, rscale, W).i0;
+        const int nsx = src_index(xb + 255, rscale, W).i1 - sx0 + 1;       // <= CWU_SPAN (host: inv >= 2)
+        for (int u = threadIdx.x; u < 2 * nsx * 6; u += 256) {
+            const int r = u / (nsx * 6), v = u - r * (nsx * 6);
+            const int px = v / 6, q = v - px * 6;
+            const float* src = dec + ((b0 * H + (r ? lyb.i1 : lyb.i0)) * (long long)W + sx0 + px) * ldd + 4 * q;
+            *(float4*)(sdec + (r * CWU_SPAN + px) * 24 + 4 * q) = *(const float4*)src;
+        }
+        __syncthreads();
+    }
+    if (idx >= total) return;
     const long long pix = idx % HWf, b = idx / HWf;
     const int x = (int)(pix % Wf), y = (int)(pix / Wf);
     const Lerp ly = src_index(y, rscale, H), lx = src_index(x, rscale, W);
-    const float* p00 = dec + ((b * H + ly.i0) * (long long)W + lx.i0) * ldd;
-    const float* p01 = dec + ((b * H + ly.i0) * (long long)W + lx.i1) * ldd;
-    const float* p10 = dec + ((b * H + ly.i1) * (long long)W + lx.i0) * ldd;
-    const float* p11 = dec + ((b * H + ly.i1) * (long long)W + lx.i1) * ldd;
+    const float* p00 = STAGE ? sdec + (lx.i0 - sx0) * 24 : dec + ((b * H + ly.i0) * (long long)W + lx.i0) * ldd;
+    const float* p01 = STAGE ? sdec + (lx.i1 - sx0) * 24 : dec + ((b * H + ly.i0) * (long long)W + lx.i1) * ldd;
+    const float* p10 = STAGE ? sdec + (CWU_SPAN + lx.i0 - sx0) * 24 : dec + ((b * H + ly.i1) * (long long)W + lx.i0) * ldd;
+    const float* p11 = STAGE ? sdec + (CWU_SPAN + lx.i1 - sx0) * 24 : dec + ((b * H + ly.i1) * (long long)W + lx.i1) * ldd;
     float d[24];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -223,9 +251,17 @@ extern "C" int gvfi_combine_warps_up(const float* img4_0, const float* img4_1, c
     const float inv = (float)((double)Hf / (double)H);           // torch: scale_factor = 1 / ds_factor, flows x the same
     const float rscale = (float)(1.0 / ((double)Hf / (double)H));
     const long long total = (long long)B * Hf * Wf;
-    GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((combine_warps_up_kernel<T>), grid1d(total), dim3(GVFI_BLOCK),
-                                              (hipStream_t)stream, img4_0, img4_1, dec, ldd, H, W, rscale, inv, (T*)act,
-                                              lda, pad, mean4, flow0_planar, flow1_planar, total, Hf, Wf, src_B));
+    // staged form: whole rows of 256-pixel blocks, up-sampling by 2 or more (<= 130 decoder pixels per block row), ldd == 24
+    const bool stage = GVFI_BLOCK == 256 && (Wf % 256) == 0 && Hf >= 2 * H && ldd == 24;
+    if (stage) {
+        GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((combine_warps_up_kernel<T, true>), grid1d(total), dim3(256),
+                                                (hipStream_t)stream, img4_0, img4_1, dec, ldd, H, W, rscale, inv, (T*)act,
+                                                lda, pad, mean4, flow0_planar, flow1_planar, total, Hf, Wf, src_B));
+    } else {
+        GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((combine_warps_up_kernel<T, false>), grid1d(total), dim3(GVFI_BLOCK),
+                                                  (hipStream_t)stream, img4_0, img4_1, dec, ldd, H, W, rscale, inv, (T*)act,
+                                                  lda, pad, mean4, flow0_planar, flow1_planar, total, Hf, Wf, src_B));
+    }
     return (int)hipGetLastError();
 }
 
@@ -283,6 +319,52 @@ extern "C" int gvfi_frames_to_u8(const float* src_nchw, unsigned char* dst_nhwc,
     const long long HW = (long long)H * W, total = 3 * HW * B;
     GVFI_LAUNCH_SIMPLE(frames_to_u8_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, src_nchw, dst_nhwc,
                        total, HW);
+    return (int)hipGetLastError();
+}
+
+// Side-by-side frames of the CLI's output.mp4 (reference src/video_Nx.py:139-151, 198-216: cv2.hconcat([ori_image[-1],
+// images[-1]]) per written frame), composed on the device from what is already resident: the padded float input frames of a
+// block of consecutive pairs and its interpolated uint8 frames -- one D2H per block, no second PNG decode and no hconcat on
+// the host.  Frame f of the block (after an optional leading [orig 0 | orig 0], the video's first frame): pair jj = g / N, slot
+// i = g % N; i < N-1: [orig jj | interpolated frame i of pair jj], i = N-1: [orig jj+1 | orig jj+1].  Originals are converted
+// like the reference converts them, (float * 255.0f) truncated to uint8; output BGR (cv2 / VideoSink order).
+__global__ void compose_sbs_kernel(const float* __restrict__ frames, int Hp, int Wp, int pad_top, int pad_left,
+                                   const unsigned char* __restrict__ pred, unsigned char* __restrict__ out, long long total,
+                                   int lead, int N, int H0, int W0) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over (f, y, x of 2 * W0)
+    if (idx >= total) return;
+    const int W2 = 2 * W0;
+    const int x = (int)(idx % W2), y = (int)((idx / W2) % H0);
+    const int f = (int)(idx / ((long long)W2 * H0));
+    const bool first = lead && f == 0;
+    const int g = f - lead;
+    const int jj = first ? 0 : g / N, i = first ? N - 1 : g - (g / N) * N;
+    const int k = first ? 0 : (i == N - 1 ? jj + 1 : jj);        // the original frame shown in this video frame
+    const bool right = x >= W0;
+    const int xx = right ? x - W0 : x;
+    unsigned char* o = out + idx * 3;
+    if (right && !first && i < N - 1) {
+        const unsigned char* p = pred + ((((long long)jj * (N - 1) + i) * H0 + y) * W0 + xx) * 3;     // RGB
+        o[0] = p[2]; o[1] = p[1]; o[2] = p[0];
+        return;
+    }
+    const long long plane = (long long)Hp * Wp;
+    const float* src = frames + (long long)k * 3 * plane + (long long)(y + pad_top) * Wp + (xx + pad_left);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = src[(2 - c) * plane] * 255.0f;          // BGR: channel c of the output = plane 2 - c
+        o[c] = (unsigned char)v;                                 // astype(np.uint8) of a value in [0, 255]: truncation
+    }
+}
+extern "C" int gvfi_compose_sbs_u8(const float* frames, int n_frames, int Hp, int Wp, int pad_top, int pad_left,
+                                   const unsigned char* pred_u8, int pairs, int N, int lead, unsigned char* out, int H0, int W0,
+                                   void* stream) {
+    if (pairs <= 0 || n_frames != pairs + 1 || N < 2 || H0 <= 0 || W0 <= 0 || pad_top < 0 || pad_left < 0 ||
+        pad_top + H0 > Hp || pad_left + W0 > Wp || (lead != 0 && lead != 1))
+        return -2;
+    const long long total = ((long long)pairs * N + lead) * H0 * 2 * W0;
+    GVFI_LAUNCH_SIMPLE(compose_sbs_kernel, grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream, frames, Hp, Wp, pad_top,
+                       pad_left, pred_u8, out, total, lead, N, H0, W0);
     return (int)hipGetLastError();
 }
 

@@ -67,6 +67,11 @@ class Engine:
         self.t_batch_pix = int(float(os.environ.get("GVFI_T_BATCH_PIX", "4.1e6")))
         # softmax splat as a deterministic gather over per-cell source lists (csrc/gimm_ops.hip); 0 = the float-atomic scatter
         self.splat_gather = os.environ.get("GVFI_SPLAT_GATHER", "1") != "0"
+        # everything behind the encoders that does not depend on the flow -- BidirCorrBlock's volumes, the context projections and
+        # the t-independent up-sampling stacks of both decoders (HBM-bound full-resolution layers) -- as one more parallel launch
+        # sequence beside the update iterations (latency chains that leave the matrix pipe 28 % busy, profiles/r4_wdir_pmc.json);
+        # 0 = after the recurrence, on the main stream
+        self.side_branch = os.environ.get("GVFI_SIDE_BRANCH", "1") != "0"
         self.layers = {}
         self._build(sd)
 
@@ -282,7 +287,9 @@ class Engine:
         of B consecutive pairs (pair b = frames b, b+1)."""
         return torch.cat([torch.arange(B, device=device), torch.arange(1, B + 1, device=device)])
 
-    def _raft(self, imgA, B, iters, taps, seq=False):
+    def _raft(self, imgA, B, iters, taps, seq=False, side=None):
+        """side(fmap, cfeats): optional launch sequence that only needs the encoders' outputs; it runs as one more parallel
+        lane beside the update iterations (or after them when lanes are off)."""
         rt, Ls = self.rt, self.layers
         n = 2 * B
         H, W = imgA.shape[1:3]
@@ -406,10 +413,16 @@ class Engine:
         # of the recurrence under-fills the chip (M = n*h8*w8 rows -> 224-448 workgroups with serial phases), so
         # independent sequences overlap each other's prologues, tails and epilogues.  Same arithmetic per image.
         k = 1 if taps is not None else max(1, min(self.raft_lanes, n))
-        with rt.lanes(k) as lanes:
+        ks = k + (1 if (side is not None and taps is None and self.side_branch) else 0)
+        with rt.lanes(ks) as lanes:
+            if ks > k:
+                with lanes[k]:
+                    side(fmap, cfeats)
             for i in range(k):
                 with lanes[i]:
                     chain(i * n // k, (i + 1) * n // k)
+        if side is not None and ks == k:
+            side(fmap, cfeats)
         rt.conv(Ls[u + ".mask.0"], hA, fh, act1=A.ACT_RELU)
         mask = rt.f32(n, h8, w8, 576)
         rt.conv(Ls[u + ".mask.2"], fh, mask, out_scale=0.25)
@@ -588,7 +601,19 @@ class Engine:
         HW = H * W
 
         # ---- cal_bidirection_flow (gimmvfi_r.py:126-156)
-        f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps, seq)
+        # t-independent decoder front ends, hoisted out of the timestep loop -- and, where the flow estimator offers a parallel
+        # lane (`front`), out of the critical path altogether
+        pre = {}
+
+        def front(feat4_, feat8_):
+            pre["up8"] = self._init_upsample(feat8_)      # [2B,h4,w4,128]
+            pre["up4"] = self._final_upsample(feat4_)     # [2B,H,W,64]
+            pre["i0q"] = rt.resize(View(img4[:B], 0, 4), 4, 0.25)   # fi_components.py:265-267
+            pre["i1q"] = rt.resize(View(img4[B:], 0, 4), 4, 0.25)
+
+        f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps, seq, front=front)
+        if not pre:
+            front(feat4, feat8)
         h4, w4 = H // 4, W // 4
         scaler = rt.f32(B, zero=True)
         rt._chk(lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), B, HW, st()), "flow_absmax")
@@ -606,11 +631,7 @@ class Engine:
             taps["pl0"] = latcat[..., 0:16].clone()
             taps["feat0_4"], taps["feat0_8"] = feat4[:B], feat8[:B]
 
-        # ---- t-independent decoder front ends, hoisted out of the timestep loop
-        up8 = self._init_upsample(feat8)      # [2B,h4,w4,128]
-        up4 = self._final_upsample(feat4)     # [2B,H,W,64]
-        i0q = rt.resize(View(img4[:B], 0, 4), 4, 0.25)   # fi_components.py:265-267
-        i1q = rt.resize(View(img4[B:], 0, 4), 4, 0.25)
+        up8, up4, i0q, i1q = pre["up8"], pre["up4"], pre["i0q"], pre["i1q"]
 
         out = {k: [] for k in ("imgt_pred", "other_pred", "flowt0_pred", "flowt1_pred", "ninrflow", "flowt")}
         T = len(t)
@@ -650,24 +671,31 @@ class Engine:
         out["nflow"] = nflow
         return out
 
-    def _flow(self, imgA, B, iters, taps, seq=False):
+    def _flow(self, imgA, B, iters, taps, seq=False, front=None):
         """Bidirectional flow + what frame synthesis needs from the flow estimator (gimmvfi_r.py:126-141): flows
         [B,H,W,2] f32 of both directions, the two correlation pyramids of BidirCorrBlock, context features at 1/4
-        (128 ch) and 1/8 (256 ch) for both frames."""
+        (128 ch) and 1/8 (256 ch) for both frames.  front(feat4, feat8): the caller's flow-independent work on the context
+        features; with the projections and the volumes it forms the side lane of Engine._raft."""
         rt, Ls = self.rt, self.layers
         n = 2 * B
         H, W = imgA.shape[1:3]
-        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps, seq)
-        f01, f10 = flow_up[:B], flow_up[B:]
         h4, w4 = H // 4, W // 4
-        g = rt.act(n, h8, w8, 256)
-        rt.conv(Ls["amt_fproj"], fmap, g)
-        pyr, pyrT = self._bidir_pyramids(g, B, h8, w8)
-        feat4 = rt.act(n, h4, w4, 128)
-        rt.conv(Ls["amt_second_last_cproj"], cfeats[1], feat4)
-        feat8 = rt.act(n, h8, w8, 256)
-        rt.conv(Ls["amt_last_cproj"], cfeats[2], feat8)
-        return f01, f10, pyr, pyrT, feat4, feat8, (h8, w8)
+        so = {}
+
+        def side(fmap, cfeats):
+            h8, w8 = fmap.shape[1:3]
+            g = rt.act(n, h8, w8, 256)
+            rt.conv(Ls["amt_fproj"], fmap, g)
+            so["pyr"], so["pyrT"] = self._bidir_pyramids(g, B, h8, w8)
+            so["feat4"] = rt.act(n, h4, w4, 128)
+            rt.conv(Ls["amt_second_last_cproj"], cfeats[1], so["feat4"])
+            so["feat8"] = rt.act(n, h8, w8, 256)
+            rt.conv(Ls["amt_last_cproj"], cfeats[2], so["feat8"])
+            if front is not None:
+                front(so["feat4"], so["feat8"])
+
+        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps, seq, side=side)
+        return flow_up[:B], flow_up[B:], so["pyr"], so["pyrT"], so["feat4"], so["feat8"], (h8, w8)
 
     def _bidir_pyramids(self, g, B, h8, w8):
         """BidirCorrBlock (raft/corr.py:23-45): volume + transposed volume, each with its pooled pyramid."""

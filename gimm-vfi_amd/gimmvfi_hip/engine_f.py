@@ -731,8 +731,9 @@ class EngineF(Engine):
         return flow_up, fmap, cfeat, (h8, w8)
 
 
-    def _flow(self, imgA, B, iters, taps, seq=False):
-        """gimmvfi_f.py:114-139: FlowFormer both ways, BidirCorrBlock on its (converted) features, context features
+    def _flow(self, imgA, B, iters, taps, seq=False, front=None):
+        """(front: the caller's flow-independent work -- run by the caller itself here, after the flow estimator.)
+        gimmvfi_f.py:114-139: FlowFormer both ways, BidirCorrBlock on its (converted) features, context features
         of the Twins context encoder at 1/4 and 1/8 -- no projections in this model."""
         flow_up, fmap, cfeat, (h8, w8) = self._flowformer(imgA, B, iters, taps, seq)
         pyr, pyrT = self._bidir_pyramids(fmap, B, h8, w8)

@@ -760,6 +760,18 @@ class Runtime:
         self._chk(self.lib.frames_to_u8(frames_nchw.data_ptr(), out.data_ptr(), b, h, w, self.stream()), "frames_to_u8")
         return out
 
+    def compose_sbs(self, frames, pad_top, pad_left, pred_u8, n_interp, lead):
+        """[orig | interpolated] video frames of a block of consecutive pairs (gvfi_compose_sbs_u8): frames (b+1, 3, Hp, Wp) float,
+        pred_u8 [b, N-1, H0, W0, 3] RGB -> [b * N + lead, H0, 2 * W0, 3] BGR uint8."""
+        b, nm1, h0, w0, _ = pred_u8.shape
+        assert frames.dtype == torch.float32 and frames.is_contiguous() and frames.shape[0] == b + 1 and frames.shape[1] == 3
+        assert pred_u8.dtype == torch.uint8 and pred_u8.is_contiguous() and nm1 == n_interp - 1
+        out = torch.empty((b * n_interp + int(lead), h0, 2 * w0, 3), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.compose_sbs_u8(frames.data_ptr(), b + 1, frames.shape[2], frames.shape[3], int(pad_top), int(pad_left),
+                                          pred_u8.data_ptr(), b, n_interp, int(lead), out.data_ptr(), h0, w0, self.stream()),
+                  "compose_sbs_u8")
+        return out
+
     def nhwc_to_nchw(self, src, c):
         src = V(src)
         assert src.is_f32

@@ -154,7 +154,8 @@ def main(argv=None):
     my_blocks = [rnd[rank] for rnd in rounds]
     # (only this rank's frames are decoded: block (j0, b) reads frames j0 .. j0 + b)
     my_frames = [j for j0, b in my_blocks if b > 0 for j in range(j0, j0 + b + 1)]
-    frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image, lookahead=bsz + 3, order=my_frames)
+    # (a 2K PNG takes ~0.1 s to decode and the model consumes ~12 frames / s / GPU at 2K 8x: 8 decode threads, 8 frames ahead)
+    frames_in = FramePrefetcher(paths, device, pad_fn=padder.pad, decode=load_image, lookahead=bsz + 7, workers=8, order=my_frames)
     drain = ResultDrain(device, depth=12, workers=8)      # composing + resizing the frames of a block: ~0.4 s at 2K
     rt = model.engine(device).rt
     gatherer = shard.RoundGather(rank, world) if world > 1 else None
@@ -176,25 +177,27 @@ def main(argv=None):
         """blocks: [(first pair, pairs)] of the tensors handed to the drain, in order (one per contributing rank)."""
         def fn(*hosts):
             tq = time.perf_counter()
-            # hosts: per block (pred_u8 [b, N-1, H, W, 3] RGB, pics_u8 [b*(N-1), h, w, 3] BGR flow pictures, colour-coded on
-            # the GPU by gvfi_flow_to_image).  Output frame order of the reference (video_Nx.py:225-246): [orig0|orig0],
-            # then per pair its N-1 [orig_j | interp] frames and [orig_j+1 | orig_j+1]; the very last frame is dropped
+            # hosts: per block (comp_u8 [b*N (+1), H, 2W, 3] BGR side-by-side frames, composed on the GPU from the resident input
+            # frames by gvfi_compose_sbs_u8; pics_u8 [b*(N-1), h, w, 3] BGR flow pictures, colour-coded on the GPU by
+            # gvfi_flow_to_image).  Output frame order of the reference (video_Nx.py:225-246): [orig0|orig0], then per pair its
+            # N-1 [orig_j | interp] frames and [orig_j+1 | orig_j+1]; the very last frame is dropped
             out_sink, flow_sink = sinks
             for k, (j0, b) in enumerate(blocks):
-                pred, pics = hosts[2 * k].numpy(), hosts[2 * k + 1].numpy()
-                origs = [to_bgr_u8(load_image(paths[j])[0]) for j in range(j0, j0 + b + 1)]
+                comp, pics = hosts[2 * k].numpy(), hosts[2 * k + 1].numpy()
+                lead = 1 if j0 == 0 else 0
+                if lead:
+                    out_sink.put(0, comp[0])
                 for jj in range(b):
                     j = j0 + jj
-                    if j == 0:
-                        out_sink.put(0, np.concatenate([origs[0], origs[0]], 1))
+                    for i in range(N):
+                        if i == N - 1 and j + 1 >= num_pairs:
+                            continue
+                        out_sink.put(1 + j * N + i, comp[lead + jj * N + i])
                     for i in range(N - 1):
-                        out_sink.put(1 + j * N + i, np.concatenate([origs[jj], pred[jj, i][:, :, ::-1]], 1))   # hconcat([orig, interp])
                         fimg = pics[jj * (N - 1) + i]
                         if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
                             fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
                         flow_sink.put(j * (N - 1) + i, fimg)
-                    if j + 1 < num_pairs:
-                        out_sink.put(1 + j * N + (N - 1), np.concatenate([origs[jj + 1], origs[jj + 1]], 1))
             if prof is not None:
                 prof["post"] += time.perf_counter() - tq
             return None
@@ -207,7 +210,7 @@ def main(argv=None):
         if k == 1:           # the first round pays model packing + graph capture: steady state starts here
             torch.cuda.synchronize(device)
             t_warm, pairs_warm = time.perf_counter(), sum(c for _, c in rounds[0])
-        pred_u8 = torch.zeros((0, N - 1, H0, W0, 3), dtype=torch.uint8, device=device)
+        comp_u8 = torch.zeros((0, H0, 2 * W0, 3), dtype=torch.uint8, device=device)
         pics_u8 = torch.zeros((0, hf, wf, 3), dtype=torch.uint8, device=device)
         if b > 0:
             tp = time.perf_counter()
@@ -227,6 +230,8 @@ def main(argv=None):
                 out = model.forward_sequence(frames, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
                 preds = torch.stack([padder.unpad(out["imgt_pred"][i]) for i in range(N - 1)], 1)       # [b, N-1, 3, H, W]
                 pred_u8 = rt.frames_to_u8(preds.reshape(-1, *preds.shape[2:]).contiguous()).reshape(b, N - 1, H0, W0, 3)
+                # [orig | interp] video frames from the frames already resident (reference: a second decode + cv2.hconcat per frame)
+                comp_u8 = rt.compose_sbs(frames, padder._pad[2], padder._pad[0], pred_u8, N, lead=(j0 == 0))
                 flows = []
                 for i in range(N - 1):
                     u = padder.unpad(out["flowt"][i])
@@ -242,8 +247,8 @@ def main(argv=None):
             if copied[par] is not None:
                 torch.cuda.current_stream(device).wait_event(copied[par])    # staging buffers of round k-2 fully drained
             cnt = [c for _, c in rounds[k]]
-            got = gatherer.gather([pred_u8, pics_u8], [(bsz, N - 1, H0, W0, 3), (bsz * (N - 1), hf, wf, 3)],
-                                  [cnt, [c * (N - 1) for c in cnt]])
+            got = gatherer.gather([comp_u8, pics_u8], [(bsz * N + 1, H0, 2 * W0, 3), (bsz * (N - 1), hf, wf, 3)],
+                                  [[c * N + (1 if (c > 0 and jb == 0) else 0) for jb, c in rounds[k]], [c * (N - 1) for c in cnt]])
             if rank == 0:
                 blocks = [blk for blk in rounds[k] if blk[1] > 0]
                 tens = []
@@ -252,7 +257,7 @@ def main(argv=None):
                         tens += [got[0][r], got[1][r]]
                 copied[par] = drain.submit(k, tens, post(blocks))
         elif b > 0:
-            drain.submit(k, [pred_u8, pics_u8], post([(j0, b)]))
+            drain.submit(k, [comp_u8, pics_u8], post([(j0, b)]))
         if prof is not None:
             prof["submit"] += time.perf_counter() - tp
     tp = time.perf_counter()

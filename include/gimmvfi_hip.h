@@ -389,6 +389,14 @@ int gvfi_nhwc_to_nchw_f32(const float* src, int ld, float* dst, int C, int N, in
 /* output frame (B,3,H,W) float in [0,1] -> uint8 [B,H,W,3] (truncation of x*255, src/video_Nx.py:192-196);
  * the unit that is gathered to rank 0 over RCCL in multi-GPU runs */
 int gvfi_frames_to_u8(const float* src_nchw, unsigned char* dst_nhwc, int B, int H, int W, void* stream);
+/* the CLI's side-by-side output frames composed on the device (src/video_Nx.py:139-151,198-216): frames = the padded float
+ * (pairs + 1, 3, Hp, Wp) input frames of a block of consecutive pairs (un-padded picture at (pad_top, pad_left), H0 x W0),
+ * pred_u8 = its interpolated frames [pairs, N-1, H0, W0, 3] RGB; out [pairs * N + lead, H0, 2 * W0, 3] BGR uint8: an
+ * optional leading [orig 0 | orig 0], then per pair N-1 x [orig j | interpolated i] and [orig j+1 | orig j+1].  Originals
+ * are (float * 255) truncated, as the reference's astype(np.uint8). */
+int gvfi_compose_sbs_u8(const float* frames, int n_frames, int Hp, int Wp, int pad_top, int pad_left,
+                        const unsigned char* pred_u8, int pairs, int N, int lead, unsigned char* out, int H0, int W0,
+                        void* stream);
 /* flow colour coding of the CLI's flow.mp4 (reference src/utils/flow_viz.py:20-136 flow_to_image, src/video_Nx.py:199-207):
  * flow = n_img planar (u, v) float images img_stride floats apart, wheel = the 55 x 3 Middlebury wheel, radmax_zeroed =
  * n_img zeroed words of scratch (per-image max radius), out = [n_img][h][w][3] uint8 (BGR when bgr != 0) */

@@ -11,11 +11,12 @@ A full 4K x 7 result is 187 MB, so a fixture keeps, per timestep:
 for timesteps `keep` (block means for all of them), plus the un-padded uint8 input frames of the demo cases
 (synthetic inputs are re-generated from the seed; `in_sum` guards that re-generation).
 
-    python oracle/make_golden_hires.py [--model r|f] [--flow-head-scale S] [case ...]
+    python oracle/make_golden_hires.py [--model r|f] [--flow-head-scale S] [--share-frames] [case ...]
 
 --flow-head-scale S (model f): the seeded weights with the FlowFormer decoder's flow head multiplied by S
 (params.random_state_dict_f(0, flow_head_scale=S)) -- flows of a few pixels instead of 40-50 px of folds; the fixture
 is written as hr_f_<case>_fh<100*S>.npz.  Separates conditioning of the un-trained recurrence from arithmetic.
+--share-frames: a demo case's fixture refers to the input frames stored in hr_<model>_<case>.npz instead of repeating them.
 """
 import json
 import os
@@ -101,6 +102,9 @@ def main():
         i = args.index("--flow-head-scale")
         fh_scale = float(args[i + 1])
         del args[i:i + 2]
+    share_frames = "--share-frames" in args      # demo cases: the input frames live in the case's full-scale fixture
+    if share_frames:
+        args.remove("--share-frames")
     names = args or list(CASES)
     out_dir = os.path.join(ROOT, "tests", "golden")
     if model_kind == "f":
@@ -127,9 +131,9 @@ def main():
                 ft = o["flowt"][i]
                 ft = ft if ft.dim() == 3 else ft[0]
                 arrs[f"flowt_{i}"] = ft[:, ::2, ::2].numpy().astype(np.float16)
-        if raw is not None:
+        if raw is not None and not share_frames:
             arrs["frames_u8"] = raw
-        meta = {"model": model_kind, "flow_head_scale": fh_scale, "kind": kind, "H": H, "W": W, "Hp": Hp, "Wp": Wp, "pad": pad, "ds": ds, "N": N,
+        meta = {"frames_from": f"hr_{model_kind}_{name}" if (raw is not None and share_frames) else None, "model": model_kind, "flow_head_scale": fh_scale, "kind": kind, "H": H, "W": W, "Hp": Hp, "Wp": Wp, "pad": pad, "ds": ds, "N": N,
                 "seed": src if kind == "synthetic" else None, "keep": KEEP, "t": tl,
                 "in_sum": int(torch.round(x * 255.0).to(torch.int64).sum()),
                 "flow_absmax": float(max(float(f.abs().max()) for f in o["flowt"])),

@@ -503,6 +503,29 @@ def splat_case(rt, B=2, H=12, W=20, C=16):
         assert float((o - ref).abs().max()) <= tol(rt, float(ref.abs().max()))
 
 
+def compose_sbs_case(rt, b=3, N=4, H0=21, W0=30, pad=(1, 1, 5, 6)):
+    """gvfi_compose_sbs_u8 against the reference's host statement (src/video_Nx.py:139-151, 198-216): originals converted with
+    (x * 255.0).astype(np.uint8) on the un-padded frame, BGR, cv2.hconcat([orig, frame]); with and without the leading frame."""
+    import numpy as np
+
+    g = torch.Generator().manual_seed(33)
+    dev = _dev(rt)
+    l, r, t, bt = pad
+    orig = torch.randint(0, 256, (b + 1, 3, H0, W0), generator=g).float() / 255.0          # load_image: uint8 / 255.0
+    frames = F.pad(orig, (l, r, t, bt), mode="replicate").contiguous()
+    pred = torch.randint(0, 256, (b, N - 1, H0, W0, 3), generator=g, dtype=torch.uint8)
+    ob = [(orig[k].numpy().transpose(1, 2, 0) * 255.0)[:, :, ::-1].astype(np.uint8) for k in range(b + 1)]
+    for lead in (0, 1):
+        got = rt.compose_sbs(frames.to(dev), t, l, pred.to(dev), N, lead).cpu().numpy()
+        want = [np.concatenate([ob[0], ob[0]], 1)] if lead else []
+        for jj in range(b):
+            for i in range(N - 1):
+                want.append(np.concatenate([ob[jj], pred[jj, i].numpy()[:, :, ::-1]], 1))
+            want.append(np.concatenate([ob[jj + 1], ob[jj + 1]], 1))
+        want = np.stack(want)
+        assert got.shape == want.shape and (got == want).all()
+
+
 def col7_planar_case(rt, N=2, H=37, W=45, seed=8):
     """Column kernel, last layer of the combination block (18 -> 3, float residual): the folded finalisation (algo bit 6:
     clamp((y + 1) / 2, 0, 1) stored planar at y2, y untouched) equals the NHWC result + gvfi_finalize_image bit for bit."""

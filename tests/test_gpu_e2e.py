@@ -223,5 +223,12 @@ def test_cli_13_frames_batched_sequence_equals_per_pair_forwards(tmp_path):
             assert got.shape == want.shape
             dd = np.abs(got.astype(np.int32) - want.astype(np.int32))
             worst, tot, cnt = max(worst, int(dd.max())), tot + float(dd.mean()), cnt + 1
+            # left half = the original frame j, composed on the device from the resident input (bit-exact: (x*255) truncated)
+            left = np.array(Image.open(out / "output_frames" / pngs[1 + j * N + i]))[:, :W, :]
+            assert (left == (a.numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)).all()
+        if j + 1 < nf - 1:                                                     # [orig j+1 | orig j+1] closes the pair
+            both = np.array(Image.open(out / "output_frames" / pngs[1 + j * N + N - 1]))
+            ob = (b.numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
+            assert (both[:, :W] == ob).all() and (both[:, W:] == ob).all()
     print(f"CLI 13 frames: |video frame - per-pair forward| max {worst} LSB, mean {tot / cnt:.4f} LSB")
     assert worst <= 4 and tot / cnt <= 0.05, (worst, tot / cnt)

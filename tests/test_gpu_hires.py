@@ -179,8 +179,9 @@ def hr_inputs(meta, z):
         sys.path.insert(0, os.path.join(ROOT, "gimm-vfi_amd", "src"))
         from utils.utils import InputPadder
 
+        frames = z["frames_u8"] if "frames_u8" in z.files else np.load(os.path.join(GOLDEN, meta["frames_from"] + ".npz"))["frames_u8"]
         fr = [torch.from_numpy(np.ascontiguousarray(f)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
-              for f in z["frames_u8"]]
+              for f in frames]
         i0, i2 = InputPadder(fr[0].shape, 32).pad(fr[0], fr[1])
         x = torch.stack([i0, i2], 2)
     assert tuple(x.shape[-2:]) == (meta["Hp"], meta["Wp"])
@@ -292,7 +293,15 @@ def test_hires_matches_reference_fixture(sd, name, prec):
 # GIMM-VFI-F in bf16 against the reference fixtures.  Default policy (flow_precision = "dec:f16"): the 40 dB tolerance of
 # every other bf16 test.  Fast mode (flow_precision = "bf16"): per-case pins = measured value + margin (three calls of
 # round 3 agree within 0.3 dB): it reaches 40 dB only while the flows are small (the *_fh015 fixtures below).
-F_DEFAULT_BOUNDS = (40.0, 0.25, 0.15, 13.0)
+# Default policy, per case as well (VERDICT r3 #5a: one global bound set by the worst fixture let a 2 dB regression on the easy
+# cases pass): measured value (rounds 3 and 4 agree within 0.2 dB / 3 % -- profiles/r3_gpu_parity.log, r4_gpu_parity_v1_tbatch.log)
+# + 1.5 dB / x1.3 / x1.3 / x1.2 of margin; every case stays above the 40 dB the path promises
+F_DEFAULT_BOUNDS = {
+    "demo_864x736": (48.7, 0.015, 0.135, 13.2),    # measured 50.3 dB, 0.011, 0.102 px, 10.9 px  (51 px flows)
+    "2k_ds050": (48.9, 0.027, 0.075, 5.4),         # 50.4 dB, 0.020, 0.057 px, 4.4 px
+    "demo2k_ds050": (40.0, 0.21, 0.125, 13.5),     # 41.6 dB, 0.16, 0.095 px, 11.2 px     (the hardest case: 1.6 dB above the promise)
+    "4k_ds025": (45.6, 0.185, 0.080, 5.5),         # 47.1 dB, 0.14, 0.060 px, 4.5 px
+}
 F_FAST_BOUNDS = {
     "demo_864x736": (37.5, 0.14, 0.50, 14.5),      # measured 39.0 dB, 0.11, 0.41 px, 12.6 px
     "2k_ds050": (38.3, 0.25, 0.26, 9.6),           # 39.8 dB, 0.20, 0.21 px, 8.3 px
@@ -333,7 +342,7 @@ def test_hires_f_matches_reference_fixture(sd_f, name, mode):
     m = _model_f(sd_f, mode)
     out = run_hr(m, meta, x)
     check_hr(out, meta, z, "fp32" if mode == "fp32" else "bf16", f"F {name} [{mode}]", "f",
-             bounds=F_DEFAULT_BOUNDS if mode == "bf16" else F_FAST_BOUNDS[name])
+             bounds=F_DEFAULT_BOUNDS[name] if mode == "bf16" else F_FAST_BOUNDS[name])
     del out, m
     torch.cuda.empty_cache()
 
@@ -352,5 +361,68 @@ def test_hires_f_small_flows_separate_conditioning_from_arithmetic(sd_f, name, m
     out = run_hr(m, meta, x)
     check_hr(out, meta, z, "fp32" if mode == "fp32" else "bf16", f"F {name} [{mode}]", "f",
              bounds=(50.0, 0.01, 0.03, 0.10) if mode == "bf16" else F_FAST_BOUNDS[name])
+    del out, m
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ flow-scale families (VERDICT r3 #5b)
+# No trained checkpoint exists offline; the seeded weights give the 32-iteration decoder 30-50 px flows full of fold-overs.  The
+# decoder's flow head scaled by S walks max |flow| from a few pixels (what a trained estimator produces on ordinary footage) to
+# that extreme.  Fixtures = the reference itself with those weights (oracle/make_golden_f448.py, make_golden_hires.py
+# --flow-head-scale); the printed lines are collected into profiles/r4_f_flow_scale_curve.md by tools/f_flow_curve.py.
+# bounds per S: (min PSNR dB, max p99.9 flow error px) for the default policy -- measured value - 2 dB / x1.4
+# measured (round 4, profiles/r4_f_flow_scale_curve.md): 62.9 / 59.1 / 56.5 / 54.2 dB, p99.9 0.042 / 0.116 / 0.35 / 3.4 px
+F448_FAMILY = {0.15: (60.8, 0.06), 0.4: (57.0, 0.165), 0.7: (54.5, 0.49), 1.0: (52.2, 4.8)}
+
+
+@pytest.mark.parametrize("scale", sorted(F448_FAMILY))
+def test_f_448_b8_flow_scale_family(scale):
+    path = os.path.join(GOLDEN, f"f448_fh{int(round(scale * 100)):03d}.npz")
+    if not os.path.isfile(path):
+        pytest.skip(f"{path} not generated")
+    from gimmvfi_hip.params import random_state_dict_f
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    x = synthetic_pairs(8, 256, 448, seed=100)
+    m = _model_f(random_state_dict_f(0, flow_head_scale=scale), "bf16")
+    c = [(m.sample_coord_input(8, (256, 448), [0.5], device=DEV), None)]
+    t = [0.5 * torch.ones(8, device=DEV)]
+    for _ in range(2):                                   # second call = graph replay (the forward bench.py times)
+        out = m(x.to(DEV), c, t=t)
+    torch.cuda.synchronize()
+    min_psnr, max_f999 = F448_FAMILY[scale]
+    for b in range(meta["samples"]):
+        img = out["imgt_pred"][0][b].float().cpu()
+        u8 = torch.round(img.clamp(0, 1) * 255.0)
+        ref = torch.from_numpy(z[f"img_{b}"]).float()
+        mse = float(((u8 - ref) / 255.0).pow(2).mean())
+        p = 99.0 if mse == 0 else -10.0 * np.log10(mse)
+        rf = torch.from_numpy(z[f"flowt_{b}"].astype(np.float32))
+        d = ((out["flowt"][0][b].float().cpu()[:, ::2, ::2] - rf).abs() - 1.5e-3 * rf.abs()).clamp_min(0).flatten()
+        f999 = float(d.kthvalue(int(d.numel() * 0.999))[0])
+        print(f"FAMILY 448x256 fh={scale:.2f} sample {b}: max |flow| {meta['flow_absmax'][b]:.1f} px, PSNR {p:.2f} dB, "
+              f"pixels > 1 LSB {float(((u8 - ref).abs() > 1).float().mean()):.2e}, flowt |d| mean {float(d.mean()):.2e} p99.9 {f999:.2e} px")
+        assert p >= min_psnr, (scale, b, p)
+        assert f999 <= max_f999, (scale, b, f999)
+    del out, m
+    torch.cuda.empty_cache()
+
+
+# demo-2K pair (the reference's own 2048x1080 frames, DS 0.5, 8x): the same family; S = 0.15 and 1.0 are the fixtures above
+# (min PSNR, frac > 1 LSB, mean flow err, p99.9); measured 50.0 dB, 0.048, 0.040 px, 0.18 px (max |flow| 22.9 px) and
+# 44.1 dB, 0.12, 0.069 px, 7.9 px (38.9 px) -- between the 52-55 dB of S = 0.15 (9 px) and the 41.6 dB of S = 1 (50 px)
+F2K_FAMILY = {0.4: (48.4, 0.063, 0.052, 0.24), 0.7: (42.5, 0.16, 0.09, 9.5)}
+
+
+@pytest.mark.parametrize("scale", sorted(F2K_FAMILY))
+def test_hires_f_demo2k_flow_scale_family(sd_f, scale):
+    meta, z = load_hr(f"demo2k_ds050_fh{int(round(scale * 100)):03d}", "f")
+    assert meta["flow_head_scale"] == scale
+    x = hr_inputs(meta, z)
+    m = _model_f(_sd_for(meta, sd_f), "bf16")
+    out = run_hr(m, meta, x)
+    check_hr(out, meta, z, "bf16", f"FAMILY demo2k_ds050 fh={scale:.2f} [bf16]", "f", bounds=F2K_FAMILY[scale])
     del out, m
     torch.cuda.empty_cache()

@@ -224,6 +224,11 @@ def test_softsplat_edge_cases(rt):
     kc.splat_case(rt, B=2, H=64, W=96)
 
 
+def test_compose_side_by_side_frames_like_the_reference_cli(rt):
+    kc.compose_sbs_case(rt)
+    kc.compose_sbs_case(rt, b=1, N=2, H0=8, W0=9, pad=(0, 0, 0, 0))
+
+
 def test_col7_folded_finalisation_equals_finalize_image(rt):
     if rt.precision != "bf16":
         pytest.skip("the column kernel is bf16 only")
@@ -240,6 +245,9 @@ def test_softsplat_gather_is_deterministic_and_matches_the_oracle(rt):
 def test_combine_warps_up_equals_separate_passes(rt):
     for scale in (1, 2, 4):
         kc.combine_warps_up_case(rt, scale=scale)
+    # full-resolution rows that are whole 256-pixel blocks: the decoder taps are staged through LDS
+    kc.combine_warps_up_case(rt, B=2, H=6, W=64, scale=4)
+    kc.combine_warps_up_case(rt, B=1, H=5, W=128, scale=2)
 
 
 def test_softsplat_native_op_contract(rt):

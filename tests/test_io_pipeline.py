@@ -181,3 +181,57 @@ def test_prefetcher_under_the_round_schedule_decodes_only_the_ranks_frames():
     assert not pf.futures                                            # nothing left behind
     with pytest.raises(KeyError):
         pf.get(0)                                                    # a frame of another rank
+
+
+def test_video_sink_cv2_branch_writes_in_order_and_surfaces_writer_errors(tmp_path, monkeypatch):
+    """The reference's container path (video_Nx.py:53-84: cv2.VideoWriter, mp4v) with a stand-in `cv2` module -- OpenCV is
+    not in the image, so this branch (in-order writer thread over out-of-order put()s) had never executed."""
+    import sys
+    import types
+
+    import numpy as np
+
+    from gimmvfi_hip.io_pipeline import VideoSink
+
+    log = {"frames": [], "released": 0, "args": None}
+
+    class Writer:
+        def __init__(self, path, fourcc, fps, size):
+            log["args"] = (path, fourcc, fps, size)
+
+        def write(self, frame):
+            if log.get("fail_at") == len(log["frames"]):
+                raise IOError("disk full")
+            log["frames"].append(int(frame[0, 0, 0]))
+
+        def release(self):
+            log["released"] += 1
+
+    fake = types.ModuleType("cv2")
+    fake.VideoWriter = Writer
+    fake.VideoWriter_fourcc = lambda *a: "".join(a)
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    path = str(tmp_path / "output.mp4")
+    sink = VideoSink(path, 16, 12, (8, 20))
+    assert sink.cv2 is fake and log["args"] == (path, "mp4v", 16, (20, 8))          # (width, height) as cv2 wants it
+    for idx in (3, 0, 1, 2, 7, 6, 5, 4, 11, 10, 9, 8):                                # producers finish out of order
+        sink.put(idx, np.full((8, 20, 3), idx, np.uint8))
+    assert sink.close() == path
+    assert log["frames"] == list(range(12)) and log["released"] == 1 and sink.written == 12
+    # frames larger than 2048 px go to the PNG + ffmpeg path even with OpenCV present (reference video_Nx.py:62-84)
+    big = VideoSink(str(tmp_path / "big.mp4"), 16, 1, (2176, 2 * 4096), png_workers=1)
+    assert big.cv2 is None
+    big.put(0, np.zeros((4, 4, 3), np.uint8))
+    assert big.close() is not None
+    # a writer error stops the sink: later put()s raise instead of queueing behind a dead writer, close() re-raises
+    log.update(frames=[], fail_at=2)
+    bad = VideoSink(str(tmp_path / "bad.mp4"), 16, 6, (8, 20))
+    for idx in range(3):
+        bad.put(idx, np.full((8, 20, 3), idx, np.uint8))
+    deadline = time.time() + 5.0
+    while bad.err is None and time.time() < deadline:
+        time.sleep(0.01)
+    with pytest.raises(IOError):
+        bad.put(3, np.zeros((8, 20, 3), np.uint8))
+    with pytest.raises(IOError):
+        bad.close()

@@ -1,0 +1,52 @@
+#!/bin/bash
+# One parametrised evidence script for the GPU box (replaces the per-call scripts of rounds 2-4).  Run through gpurun:
+#   gpurun --timeout 2400 -- 'bash tools/evidence.sh <out-tag> <step> [<step> ...]'
+# Outputs go to gpurun_out/<out-tag>/; copy what is to be judged into profiles/ (rNN_ prefix).  Steps:
+#   tests            the whole GPU suite (-m gpu) + parity lines          tests-fast   the suite without the live-CPU-oracle cases
+#   smoke            __graft_entry__.smoke()
+#   bench            the default bench line (headline + every BASELINE configuration)
+#   shapes-<cfg>     per-conv-shape table of one configuration (cfg: r448 r2k r4k f448 f4k)
+#   prof-<cfg>       rocprofv3 --kernel-trace summary (tools/rocpd_stats.py) of one configuration
+#   pmc-p3x3         PMC passes of the hot 3x3 kernel (SQ + GRBM | FETCH_SIZE | WRITE_SIZE, separate passes)
+#   pmc-wdir         PMC passes of the weights-direct recurrence kernel (SQ x2 | TCC | TCP | FETCH_SIZE | WRITE_SIZE)
+#   cli-2k, cli-448  end-to-end CLI throughput incl. PNG decode and video writing (tools/cli_bench.py)
+#   dry-<cfg>        bench.py --gpus 2 --dry: the sharded step's bookkeeping with real frame shapes on one GPU
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/$1; shift; mkdir -p $O
+cfg_args() {
+  case $1 in
+    r448) echo "";;
+    r2k) echo "--batch 1 --height 1088 --width 2048 --ds 0.5 --n-interp 8";;
+    r4k) echo "--batch 1 --height 2176 --width 4096 --ds 0.25 --n-interp 8";;
+    f448) echo "--model f";;
+    f4k) echo "--model f --batch 1 --height 2176 --width 4096 --ds 0.25 --n-interp 8";;
+    r448fp32) echo "--precision fp32";;
+  esac
+}
+for step in "$@"; do
+  case $step in
+    tests|tests-fast)
+      K=""; [ $step = tests-fast ] && K='-k not(live_oracle)'
+      timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider -rP --durations=10 ${K:+-k "not live_oracle"} > $O/gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests.log
+      grep -E "^(448x256|R |F |demo|2k_|4k_|demo2k|SNU|XTEST|CLI|FAMILY)|passed|failed|rc " $O/gpu_tests.log | cut -c1-230 > $O/gpu_parity.log; tail -3 $O/gpu_parity.log;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log;;
+    bench) ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_all.json 2> $O/bench_all.err; echo "rc $?" >> $O/bench_all.err; tail -c 600 $O/bench_all.json;;
+    shapes-*) c=${step#shapes-}; timeout 400 python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) --shapes $O/conv_shapes_$c.md > $O/bench_$c.json 2> $O/bench_$c.err; head -12 $O/conv_shapes_$c.md | cut -c1-160;;
+    prof-*) c=${step#prof-}; timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$c -o run -- python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/prof_$c.log 2>&1
+      python tools/rocpd_stats.py $O/prof_$c $O/kernel_stats_$c.md > /dev/null; rm -rf $O/prof_$c; head -14 $O/kernel_stats_$c.md | cut -c1-160;;
+    pmc-p3x3)
+      p() { n=$1; shift; rm -rf $O/pmc_$n; ONLYP3=1 timeout 150 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$n -o run -- python tools/conv_bench.py bf16 "final.resblock 256->256 3x3 @256" > $O/pmc_$n.log 2>&1; }
+      p mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS; p fetch FETCH_SIZE; p write WRITE_SIZE
+      python tools/pmc_report.py p3x3 $O/pmc_mfma $O/pmc_fetch $O/pmc_write > $O/pmc_p3x3.txt 2>&1; cut -c60-200 $O/pmc_p3x3.txt; rm -rf $O/pmc_*/;;
+    pmc-wdir)
+      p() { n=$1; shift; rm -rf $O/pw_$n; RING_ONLY="gru zr 128+128" RING_WDIR_ONLY=1 timeout 150 rocprofv3 --kernel-trace --pmc "$@" -d $O/pw_$n -o run -- python tools/ring_bench.py > $O/pw_$n.log 2>&1; }
+      p sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
+      p sq2 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES
+      p tcc TCC_HIT_sum TCC_MISS_sum; p tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum; p fetch FETCH_SIZE; p write WRITE_SIZE
+      python tools/pmc_report.py ConvArgs2 $O/pw_sq $O/pw_sq2 $O/pw_tcc $O/pw_tcp $O/pw_fetch $O/pw_write > $O/pmc_wdir.txt 2>&1; cut -c85-200 $O/pmc_wdir.txt; rm -rf $O/pw_*/;;
+    cli-2k) GVFI_CLI_TIMING=1 timeout 300 python tools/cli_bench.py 33 2048 1088 8 0.5 > $O/cli_bench_2k.txt 2>&1; cut -c1-300 $O/cli_bench_2k.txt;;
+    cli-448) timeout 200 python tools/cli_bench.py 65 448 256 2 > $O/cli_bench_448.txt 2>&1; grep -E "video_Nx|CLI:" $O/cli_bench_448.txt | cut -c1-300;;
+    dry-*) c=${step#dry-}; timeout 400 python bench.py --gpus 2 --dry --steps 3 --warmup 1 $(cfg_args $c) > $O/dry_$c.json 2> $O/dry_$c.err; tail -1 $O/dry_$c.json | cut -c1-700;;
+    *) echo "unknown step $step";;
+  esac
+done
