@@ -70,8 +70,10 @@ class Engine:
         # everything behind the encoders that does not depend on the flow -- BidirCorrBlock's volumes, the context projections and
         # the t-independent up-sampling stacks of both decoders (HBM-bound full-resolution layers) -- as one more parallel launch
         # sequence beside the update iterations (latency chains that leave the matrix pipe 28 % busy, profiles/r4_wdir_pmc.json);
-        # 0 = after the recurrence, on the main stream
-        self.side_branch = os.environ.get("GVFI_SIDE_BRANCH", "1") != "0"
+        # 0 = after the recurrence, on the main stream.
+        # Built and A/B'd in round 4 (profiles/r4_side_lane_ab.txt: 347.6 vs 348.3 frames/s at 448x256, 111.8 vs 111.5 at 2K, 96.4 vs
+        # 97.1 at 4K -- nothing: the recurrence's workgroups already hold the CUs' LDS / wave slots), so it stays off
+        self.side_branch = os.environ.get("GVFI_SIDE_BRANCH", "0") != "0"
         self.layers = {}
         self._build(sd)
 
