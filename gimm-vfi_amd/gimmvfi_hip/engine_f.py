@@ -233,6 +233,7 @@ class EngineF(Engine):
         # operand types): [flow_token_encoder.0 GELU, .2 (= query), norm1 + position code, q] and [proj + query, norm2,
         # ffn.0 GELU, ffn.3 + x]   decoder.py:84-120, 237-255.  GVFI_F_TOKCHAIN=0 keeps the 5 + 4 separate launches.
         self.chain_a = self.chain_c = None
+        self.fuse_token_path = os.environ.get("GVFI_F_TOKPATH", "1") != "0"      # A/B switch: 0 = look-up | chain | attention | chain
         if self.rt.precision in ("bf16", "fp16") and os.environ.get("GVFI_F_TOKCHAIN", "1") != "0":
             ca_ = md + ".decoder_layer.cross_attend"
             w2 = lambda k: sd[k + ".weight"].reshape(sd[k + ".weight"].shape[0], -1)
@@ -610,8 +611,17 @@ class EngineF(Engine):
                     co, co_alt = (rt.flow_step(tapl, patl, fp, co, fl, View(Xs, 126, 2), fc, coords_out=co_alt), co) if it > 0 else \
                         (rt.flow_step(tapl, patl, None, co, fl, View(Xs, 126, 2), fc), co_alt)
                 # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
-                rtt.cost_lookup(vol_s, co, View(crt, 64, 81), rows, h8, w8)
-                if tok.chain_a is not None and taps is None:
+                if tok.chain_a is not None and taps is None and tok.fuse_token_path:
+                    # look-up, both token chains and the cross-attention between them as ONE launch (csrc/token_path.hip)
+                    rtt.token_path(tok.chain_a, tok.chain_c, vol_s, co, View(crt_rows, 64, 81), View(kvm_s, 0, 128), K_LAT, P8,
+                                   View(crt_rows, 0, 64), h8, w8)
+                    lookup_done = True
+                else:
+                    rtt.cost_lookup(vol_s, co, View(crt, 64, 81), rows, h8, w8)
+                    lookup_done = False
+                if lookup_done:
+                    pass
+                elif tok.chain_a is not None and taps is None:
                     query, q, a_ = tok._tok(rows, 64), tok._tok(rows, 64), tok._tok(rows, 64)
                     rtt.token_chain(tok.chain_a, View(crt_rows, 64, 128), q, out1=query, coords=co, period=rows)
                     rtt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)

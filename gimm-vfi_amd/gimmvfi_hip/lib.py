@@ -73,6 +73,19 @@ class TokenChainParams(C.Structure):
     ]
 
 
+class TokenPathParams(C.Structure):
+    """Mirror of ``gvfi_token_path_params`` (include/gimmvfi_hip.h)."""
+
+    _fields_ = [
+        ("a", TokenChainParams), ("c", TokenChainParams),
+        ("maps", C.c_void_p), ("coords", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("radius", C.c_int),
+        ("taps_out", C.c_void_p), ("ldt", C.c_int),
+        ("kv", C.c_void_p), ("ldkv", C.c_int), ("K", C.c_int), ("P", C.c_longlong), ("scale", C.c_float),
+        ("out", C.c_void_p), ("ldo", C.c_int),
+        ("rows", C.c_longlong), ("dtype", C.c_int),
+    ]
+
+
 _CTYPES = {
     "int": C.c_int,
     "float": C.c_float,

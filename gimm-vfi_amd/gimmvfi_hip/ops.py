@@ -542,6 +542,26 @@ class Runtime:
         p.rows, p.dtype = rows, self.dtype
         self._chk(self.lib.token_chain(C.byref(p), self.stream()), "token_chain")
 
+    def token_path(self, ch_a, ch_c, maps, coords, taps_out, kv, n_latent, tokens_per_image, out, h, w, radius=4):
+        """The flow-token path of one decoder iteration in one launch (gvfi_token_path): cost look-up -> chain `ch_a` -> one-query
+        attention over the map's latent tokens -> chain `ch_c`.  taps_out / out: Views of [rows, ld] token matrices; kv: View of
+        the [images * K * P, >= 128] key | value matrix; coords float [rows, 2]."""
+        p = L.TokenPathParams()
+        taps_out, out, kv = V(taps_out), V(out), V(kv)
+        rows = out.npix
+        for dst, ch in ((p.a, ch_a), (p.c, ch_c)):
+            dst.wfrag, dst.bias = ch.wfrag.data_ptr(), ch.bias.data_ptr()
+            dst.ln_g, dst.ln_b, dst.eps, dst.ln_after = ch.ln_g.data_ptr(), ch.ln_b.data_ptr(), ch.eps, ch.ln_after
+            dst.act0, dst.act1, dst.res2_from0 = ch.act0, ch.act1, int(ch.res2_from0)
+        assert coords.dtype == torch.float32 and coords.is_contiguous() and maps.dtype == torch.float32 and maps.is_contiguous()
+        assert taps_out.npix == rows and out.c == 64 and taps_out.c >= (2 * radius + 1) ** 2 and kv.c >= 128
+        p.maps, p.coords, p.h, p.w, p.radius = maps.data_ptr(), coords.data_ptr(), h, w, radius
+        p.taps_out, p.ldt = taps_out.ptr, taps_out.ld
+        p.kv, p.ldkv, p.K, p.P, p.scale = kv.ptr, kv.ld, n_latent, tokens_per_image, float(8 ** -0.5)
+        p.out, p.ldo = out.ptr, out.ld
+        p.rows, p.dtype = rows, self.dtype
+        self._chk(self.lib.token_path(C.byref(p), self.stream()), "token_path")
+
     def s2d_conv(self, layer, x, out, **kw):
         """x: contiguous [N, H, W, ld] activation tensor (H, W multiples of layer.k), out: [N, H/k, W/k, cout]."""
         k = layer.k

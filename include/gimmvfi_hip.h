@@ -435,6 +435,24 @@ typedef struct {
 } gvfi_token_chain_params;
 int gvfi_token_chain(const gvfi_token_chain_params* p, void* stream);
 
+/* The whole flow-token path of one MemoryDecoder iteration as ONE launch (csrc/token_path.hip; decoder.py:237-255 look-up +
+ * flow_token_encoder, :35-120 CrossAttentionLayer): gvfi_cost_lookup (radius 4) -> gvfi_token_chain `a` (GELU linear, linear =
+ * query, LayerNorm + position code of `coords`, linear = q) -> the one-query attention of gvfi_attn_global over the K latent
+ * tokens of the token's cost map (8 heads of 8, key | value rows of 128 features at kv[(img * K + j) * P + p]) ->
+ * gvfi_token_chain `c` ([attention | query] linear + query, LayerNorm, GELU linear, linear + x).  Bit-identical to those four
+ * launches.  Of `a` / `c` only wfrag, bias, ln_g, ln_b, eps, ln_after, act0, act1, res2_from0 are read (the tensors in between
+ * never leave the chip).  rows = images * P tokens; maps float [rows][h*w]; coords float [rows][2]; taps_out [rows][ldt] receives
+ * the 81 taps (cost_forward), out [rows][ldo] the 64 result features (cost_global), both in dtype (GVFI_BF16 / GVFI_F16). */
+typedef struct {
+    gvfi_token_chain_params a, c;
+    const float* maps; const float* coords; int h, w, radius;
+    void* taps_out; int ldt;
+    const void* kv; int ldkv; int K; long long P; float scale;
+    void* out; int ldo;
+    long long rows; int dtype;
+} gvfi_token_path_params;
+int gvfi_token_path(const gvfi_token_path_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
