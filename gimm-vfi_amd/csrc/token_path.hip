@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) token_path_kernel(gvfi_token_path_params 
         const int win = 2 * p.radius + 1, ntap = win * win;
         const float* base = p.maps + row * (long long)p.h * p.w;
         const float qx = p.coords[row * 2 + 0], qy = p.coords[row * 2 + 1];
-        constexpr int TU = 7;
+        constexpr int TU = 14;
 #pragma unroll 1
         for (int it0 = 0; it0 * 2 < ntap + 1; it0 += TU) {
             float ax[TU], ay[TU], t00[TU], t01[TU], t10[TU], t11[TU];
@@ -248,21 +248,33 @@ __global__ void __launch_bounds__(256) token_path_kernel(gvfi_token_path_params 
             const T* qe = (const T*)&qv;
 #pragma unroll
             for (int d = 0; d < 8; ++d) { q8[d] = Elem<T>::ld(qe + d); o8[d] = 0.f; }
-            for (int j = 0; j < p.K; ++j) {
-                const T* kr = kvb + (long long)j * p.P * p.ldkv;
-                const uint4 kq = *(const uint4*)(kr + hd * 8), vq = *(const uint4*)(kr + 64 + hd * 8);
-                const T* ke = (const T*)&kq;
-                const T* ve = (const T*)&vq;
-                float s = 0.f;
+            // all key / value rows of the head in flight at once (a wave has nothing else to hide 8 dependent round trips behind)
+            constexpr int KB = 8;
+            for (int j0 = 0; j0 < p.K; j0 += KB) {
+                uint4 kq[KB], vq[KB];
 #pragma unroll
-                for (int d = 0; d < 8; ++d) s += q8[d] * Elem<T>::ld(ke + d);
-                s *= p.scale;
-                const float mn = fmaxf(m, s);
-                const float a = expf(m - mn), pe = expf(s - mn);
-                l = l * a + pe;
+                for (int u = 0; u < KB; ++u) {
+                    const int j = j0 + u < p.K ? j0 + u : p.K - 1;
+                    const T* kr = kvb + (long long)j * p.P * p.ldkv;
+                    kq[u] = *(const uint4*)(kr + hd * 8);
+                    vq[u] = *(const uint4*)(kr + 64 + hd * 8);
+                }
 #pragma unroll
-                for (int d = 0; d < 8; ++d) o8[d] = o8[d] * a + pe * Elem<T>::ld(ve + d);
-                m = mn;
+                for (int u = 0; u < KB; ++u) {
+                    if (j0 + u >= p.K) break;
+                    const T* ke = (const T*)&kq[u];
+                    const T* ve = (const T*)&vq[u];
+                    float s = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) s += q8[d] * Elem<T>::ld(ke + d);
+                    s *= p.scale;
+                    const float mn = fmaxf(m, s);
+                    const float a = expf(m - mn), pe = expf(s - mn);
+                    l = l * a + pe;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) o8[d] = o8[d] * a + pe * Elem<T>::ld(ve + d);
+                    m = mn;
+                }
             }
             const float inv = 1.0f / l;
             __attribute__((aligned(16))) T ov[8];

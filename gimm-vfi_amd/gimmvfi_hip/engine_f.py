@@ -233,7 +233,11 @@ class EngineF(Engine):
         # operand types): [flow_token_encoder.0 GELU, .2 (= query), norm1 + position code, q] and [proj + query, norm2,
         # ffn.0 GELU, ffn.3 + x]   decoder.py:84-120, 237-255.  GVFI_F_TOKCHAIN=0 keeps the 5 + 4 separate launches.
         self.chain_a = self.chain_c = None
-        self.fuse_token_path = os.environ.get("GVFI_F_TOKPATH", "1") != "0"      # A/B switch: 0 = look-up | chain | attention | chain
+        # the whole flow-token path of an iteration as ONE launch (csrc/token_path.hip, bit-identical).  Measured in round 4
+        # (profiles/r4_tokpath_ab_v1.txt, _v2.txt): 74 us against 61 us for the four launches it replaces -- 189.7 vs 191.8 frames/s:
+        # one wave owns 32 tokens end to end, i.e. 448 waves for 14 336 rows, and the look-up's 324 scattered loads per token then
+        # run on 112 CUs with nothing to hide them behind, where the separate look-up spreads 1.2 M threads over the chip.  Off.
+        self.fuse_token_path = os.environ.get("GVFI_F_TOKPATH", "0") != "0"
         if self.rt.precision in ("bf16", "fp16") and os.environ.get("GVFI_F_TOKCHAIN", "1") != "0":
             ca_ = md + ".decoder_layer.cross_attend"
             w2 = lambda k: sd[k + ".weight"].reshape(sd[k + ".weight"].shape[0], -1)
