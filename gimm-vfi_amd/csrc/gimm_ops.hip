@@ -260,52 +260,67 @@ __global__ void softsplat_gather_kernel(const T* __restrict__ lat, int ldl, cons
     float acc[C + 1];
 #pragma unroll
     for (int c = 0; c <= C; ++c) acc[c] = 0.f;
-    auto add = [&](int s) {
+    constexpr int NV = C * (int)sizeof(T) / 16;          // 16-byte vectors of a source's latent
+    struct Src { float fx, fy, zv; uint4 q[NV]; };
+    auto fetch = [&](int s, Src& r) {                     // loads only: several sources are requested before any is used
+        r.fx = fl[(long long)s * 2];
+        r.fy = fl[(long long)s * 2 + 1];
+        r.zv = zz[s];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) r.q[k] = ((const uint4*)(la + (long long)s * ldl))[k];
+    };
+    auto accumulate = [&](int s, const Src& r) {
         const int sx = s % W, sy = s / W;
-        const float fx = (float)sx + fl[(long long)s * 2] * ts, fy = (float)sy + fl[(long long)s * 2 + 1] * ts;
+        const float fx = (float)sx + r.fx * ts, fy = (float)sy + r.fy * ts;
         const float x0f = floorf(fx), y0f = floorf(fy);
         const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
         // the corner of the source's 2 x 2 footprint this target is: the reference's four weight expressions
         const float wx = tx == x0 ? ((float)x1 - fx) : (fx - (float)x0);
         const float wy = ty == y0 ? ((float)y1 - fy) : (fy - (float)y0);
         const float w = wx * wy;
-        const float zv = zz[s];
-        constexpr int NV = C * (int)sizeof(T) / 16;          // 16-byte vectors of the source's latent
-        uint4 q[NV];
+        const T* e = (const T*)r.q;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) q[k] = ((const uint4*)(la + (long long)s * ldl))[k];
-        const T* e = (const T*)q;
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] += (Elem<T>::ld(e + c) * zv) * w;
-        acc[C] += zv * w;
+        for (int c = 0; c < C; ++c) acc[c] += (Elem<T>::ld(e + c) * r.zv) * w;
+        acc[C] += r.zv * w;
     };
     // sources of the four lists in ascending index: up to CAP of them through a sorted register array ...
     int a[CAP];
 #pragma unroll
     for (int k = 0; k < CAP; ++k) a[k] = NONE;
     int cnt = 0;
+    int hs[4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int s = hd[(long long)j * (W + 1) + i];
-            while (s >= 0) {
-                ++cnt;
-                int e = s;
+        for (int i = 0; i < 2; ++i) hs[2 * j + i] = hd[(long long)j * (W + 1) + i];      // the four heads in flight together
 #pragma unroll
-                for (int k = 0; k < CAP; ++k) {
-                    const int lo = e < a[k] ? e : a[k];
-                    e = e < a[k] ? a[k] : e;
-                    a[k] = lo;
-                }
-                s = nx[s];
+    for (int c4 = 0; c4 < 4; ++c4) {
+        int s = hs[c4];
+        while (s >= 0) {
+            ++cnt;
+            int e = s;
+#pragma unroll
+            for (int k = 0; k < CAP; ++k) {
+                const int lo = e < a[k] ? e : a[k];
+                e = e < a[k] ? a[k] : e;
+                a[k] = lo;
             }
+            s = nx[s];
         }
+    }
     if (cnt <= CAP) {
-        for (int k = 0; k < cnt; ++k) {
-            add(a[0]);
+        // groups of four sources: their flows, weights and latents are requested together, then added in ascending index
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+            Src r[4];
 #pragma unroll
-            for (int q = 0; q + 1 < CAP; ++q) a[q] = a[q + 1];
+            for (int u = 0; u < 4; ++u) fetch(a[u] != NONE ? a[u] : a[0], r[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < cnt) accumulate(a[u], r[u]);
+#pragma unroll
+            for (int q = 0; q + 4 < CAP; ++q) a[q] = a[q + 4];
+#pragma unroll
+            for (int q = CAP - 4; q < CAP; ++q) a[q] = NONE;
         }
     } else {
         // ... longer lists (many sources converging on one cell): repeated selection of the next larger index
@@ -313,16 +328,16 @@ __global__ void softsplat_gather_kernel(const T* __restrict__ lat, int ldl, cons
         for (int k = 0; k < cnt; ++k) {
             int best = NONE;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    int s = hd[(long long)j * (W + 1) + i];
-                    while (s >= 0) {
-                        if (s > last && s < best) best = s;
-                        s = nx[s];
-                    }
+            for (int c4 = 0; c4 < 4; ++c4) {
+                int s = hs[c4];
+                while (s >= 0) {
+                    if (s > last && s < best) best = s;
+                    s = nx[s];
                 }
-            add(best);
+            }
+            Src r;
+            fetch(best, r);
+            accumulate(best, r);
             last = best;
         }
     }

@@ -299,12 +299,17 @@ __global__ void warp_nhwc_kernel(const void* __restrict__ src, int lds, int src_
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float ax = fx - x0f, ay = fy - y0f;
     const long long b = (src_N > 0 ? n % src_N : n) * (long long)H * W;
+    // (the four taps as unconditional loads -- an absent neighbour re-reads the pixel itself -- so that they are in flight
+    // together; which taps are added, and in which order, is unchanged)
+    const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
+    const long long p00 = b + (long long)y0 * W + x0, ox = xin ? 1 : 0, oy = yin ? W : 0;
+    const float t00 = ld_any<T>(src, p00 * lds + c, src_f32), t01 = ld_any<T>(src, (p00 + ox) * lds + c, src_f32);
+    const float t10 = ld_any<T>(src, (p00 + oy) * lds + c, src_f32), t11 = ld_any<T>(src, (p00 + oy + ox) * lds + c, src_f32);
     float v = 0.f;
-    v += (1.f - ax) * (1.f - ay) * ld_any<T>(src, (b + (long long)y0 * W + x0) * lds + c, src_f32);
-    if (x0 + 1 < W) v += ax * (1.f - ay) * ld_any<T>(src, (b + (long long)y0 * W + x0 + 1) * lds + c, src_f32);
-    if (y0 + 1 < H) v += (1.f - ax) * ay * ld_any<T>(src, (b + (long long)(y0 + 1) * W + x0) * lds + c, src_f32);
-    if (x0 + 1 < W && y0 + 1 < H)
-        v += ax * ay * ld_any<T>(src, (b + (long long)(y0 + 1) * W + x0 + 1) * lds + c, src_f32);
+    v += (1.f - ax) * (1.f - ay) * t00;
+    if (xin) v += ax * (1.f - ay) * t01;
+    if (yin) v += (1.f - ax) * ay * t10;
+    if (xin && yin) v += ax * ay * t11;
     st_any<T>(dst, pix * ldd + c, dst_f32, v);
 }
 template <typename T>
