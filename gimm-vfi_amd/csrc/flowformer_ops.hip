@@ -212,26 +212,18 @@ __global__ void cost_embed1_kernel(const float* __restrict__ vol, const float* _
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = bias[c];
-    // the 36 taps as UNCONDITIONAL loads at clamped positions, a row of six in flight together (loads behind the `continue`s of
-    // the first version were 36 dependent round trips per thread: 0.72 ms for 205 MB); an absent tap contributes v = 0
-#pragma unroll
+    // (measured in round 4: the 36 taps as unconditional, fully unrolled loads ran 4.3x SLOWER -- 3.09 instead of 0.72 ms: the
+    // taps of neighbouring output pixels overlap, so the loads are L1 hits either way, and the unrolled form spills)
     for (int ky = 0; ky < 6; ++ky) {
         const int yy = oy * 2 - 2 + ky;
-        const bool yok = (unsigned)yy < (unsigned)H;
-        const float* rowp = src + (long long)(yok ? yy : 0) * W;
-        float v[6];
-#pragma unroll
+        if ((unsigned)yy >= (unsigned)H) continue;
         for (int kx = 0; kx < 6; ++kx) {
             const int xx = ox * 2 - 2 + kx;
-            const bool ok = yok && (unsigned)xx < (unsigned)W;
-            const float t = rowp[ok ? xx : 0];
-            v[kx] = ok ? t : 0.f;
-        }
-#pragma unroll
-        for (int kx = 0; kx < 6; ++kx) {
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float v = src[(long long)yy * W + xx];
             const float* wk = w + (ky * 6 + kx) * 16;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] += v[kx] * wk[c];
+            for (int c = 0; c < 16; ++c) acc[c] += v * wk[c];
         }
     }
     T* o = out + idx * ldo;
