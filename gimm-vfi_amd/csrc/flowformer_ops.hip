@@ -230,9 +230,57 @@ __global__ void cost_embed1_kernel(const float* __restrict__ vol, const float* _
 #pragma unroll
     for (int c = 0; c < 16; ++c) Elem<T>::st(o + c, acc[c] > 0.f ? acc[c] : 0.f);
 }
+// The same convolution with ONE WORKGROUP PER COST MAP (round 4): the map (H x W floats, 7 KB at 448x256, 35 KB at the 2K / 4K
+// working grid) is copied to LDS once with coalesced 16-byte loads -- the volume crosses the memory system exactly once -- and the
+// 36 taps of every output pixel are LDS reads.  The thread-per-pixel form above re-reads every cost value nine times through the
+// L1 path in 36 dependent round trips per thread (0.72 ms for the 205 MB volume of 8 pairs at 448x256: 0.29 TB/s).  Same
+// accumulation order (bias, then ky, kx ascending): bit-identical results.
+template <typename T>
+__global__ void __launch_bounds__(256) cost_embed1_lds_kernel(const float* __restrict__ vol, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, T* __restrict__ out, int ldo,
+                                                              int H, int W, int Ho, int Wo) {
+    GVFI_DYN_SMEM(smem);
+    float* mp = (float*)smem;                       // [H][W]
+    const long long m = blockIdx.x;
+    const float* src = vol + m * (long long)H * W;
+    const int n = H * W;
+    if (((((uintptr_t)src) & 15) == 0) && (n & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < n; i += 256 * 4) *(float4*)(mp + i) = *(const float4*)(src + i);
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) mp[i] = src[i];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < Ho * Wo; o += 256) {
+        const int ox = o % Wo, oy = o / Wo;
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = bias[c];
+        for (int ky = 0; ky < 6; ++ky) {
+            const int yy = oy * 2 - 2 + ky;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 6; ++kx) {
+                const int xx = ox * 2 - 2 + kx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float v = mp[yy * W + xx];
+                const float* wk = w + (ky * 6 + kx) * 16;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] += v * wk[c];
+            }
+        }
+        T* op = out + (m * (long long)Ho * Wo + o) * ldo;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Elem<T>::st(op + c, acc[c] > 0.f ? acc[c] : 0.f);
+    }
+}
 extern "C" int gvfi_cost_embed1(const float* vol, const float* w, const float* bias, void* out, int ldo, long long maps,
                                 int H, int W, int Ho, int Wo, int dtype, void* stream) {
     if (ldo < 16) return -2;
+    const long long shm = (long long)H * W * 4;
+    if (shm <= 64 * 1024 && maps <= 0x7fffffffll && getenv("GVFI_COST_EMBED_LDS0") == nullptr) {
+        GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP_SHM((cost_embed1_lds_kernel<T>), dim3((unsigned)maps), dim3(256), (int)shm,
+                                                    (hipStream_t)stream, vol, w, bias, (T*)out, ldo, H, W, Ho, Wo));
+        return (int)hipGetLastError();
+    }
     const long long total = maps * Ho * Wo;
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_SIMPLE((cost_embed1_kernel<T>), grid1d(total), dim3(GVFI_BLOCK), (hipStream_t)stream,
                                               vol, w, bias, (T*)out, ldo, total, H, W, Ho, Wo));

@@ -36,6 +36,7 @@ def _all(rt):
     kf.dwconv_case(rt, f32=True)
     kf.pos_embed_case(rt)
     kf.cost_embed_lookup_case(rt)
+    kf.cost_embed_lookup_case(rt, maps=5, h=8, w=12)                   # whole float4 rows: the 16-byte copy of the LDS-staged form
     kf.attn_window_case(rt)
     kf.attn_window_case(rt, B=1, H=7, W=14, C=128, heads=4)          # head_dim 32, no padding
     kf.attn_window_case(rt, B=1, H=15, W=8, C=128, heads=8)          # head_dim 16, ragged in both directions
