@@ -104,6 +104,27 @@ def images_to_video(imgs, output_video_path, fps=15):
     return frame_dir
 
 
+def round_frames(blocks, hosts, N, num_pairs):
+    """Video positions of what one round delivered.  blocks: [(first pair j0, pairs b)] in rank order; hosts: per block the
+    composed side-by-side frames [b*N (+1 when j0 == 0), H, 2W, 3] and the flow pictures [b*(N-1), h, w, 3] (numpy).  Yields
+    ("out", index in output.mp4, frame) and ("flow", index in flow.mp4, picture) in the reference's order (video_Nx.py:225-246):
+    [orig0|orig0], then per pair N-1 x [orig_j | interp] and [orig_j+1 | orig_j+1]; the video's very last frame is dropped."""
+    for k, (j0, b) in enumerate(blocks):
+        comp, pics = hosts[2 * k], hosts[2 * k + 1]
+        lead = 1 if j0 == 0 else 0
+        assert comp.shape[0] == b * N + lead and pics.shape[0] == b * (N - 1), (comp.shape, pics.shape, j0, b)
+        if lead:
+            yield "out", 0, comp[0]
+        for jj in range(b):
+            j = j0 + jj
+            for i in range(N):
+                if i == N - 1 and j + 1 >= num_pairs:
+                    continue
+                yield "out", 1 + j * N + i, comp[lead + jj * N + i]
+            for i in range(N - 1):
+                yield "flow", j * (N - 1) + i, pics[jj * (N - 1) + i]
+
+
 def main(argv=None):
     args, extra_args = parse_args(argv)
     set_seed(args.seed)
@@ -182,22 +203,13 @@ def main(argv=None):
             # gvfi_flow_to_image).  Output frame order of the reference (video_Nx.py:225-246): [orig0|orig0], then per pair its
             # N-1 [orig_j | interp] frames and [orig_j+1 | orig_j+1]; the very last frame is dropped
             out_sink, flow_sink = sinks
-            for k, (j0, b) in enumerate(blocks):
-                comp, pics = hosts[2 * k].numpy(), hosts[2 * k + 1].numpy()
-                lead = 1 if j0 == 0 else 0
-                if lead:
-                    out_sink.put(0, comp[0])
-                for jj in range(b):
-                    j = j0 + jj
-                    for i in range(N):
-                        if i == N - 1 and j + 1 >= num_pairs:
-                            continue
-                        out_sink.put(1 + j * N + i, comp[lead + jj * N + i])
-                    for i in range(N - 1):
-                        fimg = pics[jj * (N - 1) + i]
-                        if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
-                            fimg = np.array(Image.fromarray(fimg).resize((W0, H0), Image.BILINEAR))
-                        flow_sink.put(j * (N - 1) + i, fimg)
+            for kind, idx, img in round_frames(blocks, [h_.numpy() for h_ in hosts], N, num_pairs):
+                if kind == "out":
+                    out_sink.put(idx, img)
+                else:
+                    if ds_factor != 1.0:   # flow_t lives at the working resolution; resize the picture for the video
+                        img = np.array(Image.fromarray(img).resize((W0, H0), Image.BILINEAR))
+                    flow_sink.put(idx, img)
             if prof is not None:
                 prof["post"] += time.perf_counter() - tq
             return None
