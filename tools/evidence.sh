@@ -30,7 +30,7 @@ for step in "$@"; do
       timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider -rP --durations=10 ${K:+-k "not live_oracle"} > $O/gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests.log
       grep -E "^(448x256|R |F |demo|2k_|4k_|demo2k|SNU|XTEST|CLI|FAMILY)|passed|failed|rc " $O/gpu_tests.log | cut -c1-230 > $O/gpu_parity.log; tail -3 $O/gpu_parity.log;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log;;
-    bench) ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_all.json 2> $O/bench_all.err; echo "rc $?" >> $O/bench_all.err; tail -c 600 $O/bench_all.json;;
+    bench) ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --details $O/bench_full.json ) > $O/bench_line.json 2> $O/bench_all.err; echo "rc $?" >> $O/bench_all.err; tail -c 1700 $O/bench_line.json;;
     shapes-*) c=${step#shapes-}; timeout 400 python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) --shapes $O/conv_shapes_$c.md > $O/bench_$c.json 2> $O/bench_$c.err; head -12 $O/conv_shapes_$c.md | cut -c1-160;;
     prof-*) c=${step#prof-}; timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$c -o run -- python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/prof_$c.log 2>&1
       python tools/rocpd_stats.py $O/prof_$c $O/kernel_stats_$c.md > /dev/null; rm -rf $O/prof_$c; head -14 $O/kernel_stats_$c.md | cut -c1-160;;
