@@ -7,9 +7,10 @@ flow_t).  Differences: runs on the MI355X HIP kernels (no CuPy / CUDA), and unde
 ``python -m torch.distributed.run --nproc-per-node G`` the frame pairs are sharded over G GPUs in ROUNDS of G x `--batch`
 consecutive pairs (gimmvfi_hip/shard.py:round_schedule); after every round the device-resident uint8 result frames and
 flow pictures are gathered to rank 0 over RCCL (the path's only collective) and written to the videos in order while the
-next round computes -- memory on every rank is O(one round).  Every rank runs `--batch` consecutive pairs per forward and
-encodes each frame once (model.forward_sequence); frame decode / upload, result download, composition and video writing
-run in a host pipeline beside the GPU (gimmvfi_hip/io_pipeline.py).  Without OpenCV the frames are written as PNGs
+next round computes -- memory on every rank is O(one round), and a rank decodes only its own frames.  Every rank runs `--batch`
+consecutive pairs per forward and encodes each frame once (model.forward_sequence); the [original | interpolated] frames are
+composed on the device from the resident input frames (gvfi_compose_sbs_u8); frame decode / upload, result download and
+video writing run in a host pipeline beside the GPU (gimmvfi_hip/io_pipeline.py).  Without OpenCV the frames are written as PNGs
 (OUT/output_frames, OUT/flow_frames) and encoded with ffmpeg when it is on PATH.
 ``--random-init`` (addition) runs with seeded random weights when no checkpoint is available."""
 import argparse
@@ -71,13 +72,9 @@ def load_image(img_path):
     return (torch.from_numpy(raw.copy()).permute(2, 0, 1) / 255.0).to(torch.float).unsqueeze(0)
 
 
-def to_bgr_u8(img_chw):
-    """float CHW in [0,1] -> uint8 HWC BGR (truncation, reference video_Nx.py:140-148)."""
-    return (img_chw.detach().cpu().numpy().transpose(1, 2, 0) * 255.0)[:, :, ::-1].astype(np.uint8)
-
-
 def images_to_video(imgs, output_video_path, fps=15):
-    # reference video_Nx.py:53-84 (cv2.VideoWriter, ffmpeg for > 2048); PNG fallback without OpenCV
+    # reference video_Nx.py:53-84 (cv2.VideoWriter, ffmpeg for > 2048); PNG fallback without OpenCV.  Kept for callers of the
+    # reference's module surface; main() streams through gimmvfi_hip.io_pipeline.VideoSink instead of collecting a list
     height, width, _ = imgs[0].shape
     big = max(height, width // 2) > 2048
     if cv2 is not None and not big:
