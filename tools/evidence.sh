@@ -9,6 +9,7 @@
 #   prof-<cfg>       rocprofv3 --kernel-trace summary (tools/rocpd_stats.py) of one configuration
 #   pmc-p3x3         PMC passes of the hot 3x3 kernel (SQ + GRBM | FETCH_SIZE | WRITE_SIZE, separate passes)
 #   pmc-wdir         PMC passes of the weights-direct recurrence kernel (SQ x2 | TCC | TCP | FETCH_SIZE | WRITE_SIZE)
+#   hbm-<cfg>        HBM bytes per kernel (FETCH_SIZE / WRITE_SIZE passes over a bench run, joined with prof-<cfg>'s durations)
 #   cli-2k, cli-448  end-to-end CLI throughput incl. PNG decode and video writing (tools/cli_bench.py)
 #   dry-<cfg>        bench.py --gpus 2 --dry: the sharded step's bookkeeping with real frame shapes on one GPU
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -44,6 +45,9 @@ for step in "$@"; do
       p sq2 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES
       p tcc TCC_HIT_sum TCC_MISS_sum; p tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum; p fetch FETCH_SIZE; p write WRITE_SIZE
       python tools/pmc_report.py ConvArgs2 $O/pw_sq $O/pw_sq2 $O/pw_tcc $O/pw_tcp $O/pw_fetch $O/pw_write > $O/pmc_wdir.txt 2>&1; cut -c85-200 $O/pmc_wdir.txt; rm -rf $O/pw_*/;;
+    hbm-*) c=${step#hbm-}       # needs kernel_stats_<cfg>.md of a prof-<cfg> step of the same tag (un-profiled durations)
+      for ctr in FETCH_SIZE WRITE_SIZE; do rm -rf $O/hbm_$ctr; timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/hbm_$ctr -o run -- python bench.py --configs none --no-cpu-baseline --steps 3 --warmup 1 $(cfg_args $c) > $O/hbm_$ctr.log 2>&1; done
+      python tools/pmc_table.py $O/kernel_stats_$c.md $O/hbm_table_$c.md $O/hbm_FETCH_SIZE $O/hbm_WRITE_SIZE > /dev/null; rm -rf $O/hbm_FETCH_SIZE $O/hbm_WRITE_SIZE; head -16 $O/hbm_table_$c.md | cut -c1-170;;
     cli-2k) GVFI_CLI_TIMING=1 timeout 300 python tools/cli_bench.py 33 2048 1088 8 0.5 > $O/cli_bench_2k.txt 2>&1; cut -c1-300 $O/cli_bench_2k.txt;;
     cli-448) timeout 200 python tools/cli_bench.py 65 448 256 2 > $O/cli_bench_448.txt 2>&1; grep -E "video_Nx|CLI:" $O/cli_bench_448.txt | cut -c1-300;;
     dry-*) c=${step#dry-}; timeout 400 python bench.py --gpus 2 --dry --steps 3 --warmup 1 $(cfg_args $c) > $O/dry_$c.json 2> $O/dry_$c.err; tail -1 $O/dry_$c.json | cut -c1-700;;
