@@ -92,6 +92,7 @@ class EngineF(Engine):
     # ------------------------------------------------------------------ weight preparation
     def _lin(self, sd, key, name=None, **kw):
         kw = {k: v for k, v in kw.items() if k != "wdir" or v}
+        kw.setdefault("lin", True)      # many-row, small-K linears take the row-linear kernel (csrc/conv_lin.hip) where it applies
         w = sd[key + ".weight"]
         b = sd.get(key + ".bias")
         self._add(name or key, w.reshape(w.shape[0], w.shape[1], 1, 1), b, **kw)
@@ -99,6 +100,7 @@ class EngineF(Engine):
     def _lin_cat(self, sd, keys, name, **kw):
         w = torch.cat([sd[k + ".weight"] for k in keys], 0)
         b = torch.cat([sd[k + ".bias"] for k in keys], 0)
+        kw.setdefault("lin", True)
         self._add(name, w.reshape(w.shape[0], w.shape[1], 1, 1), b, **kw)
 
     def _ln(self, sd, key):

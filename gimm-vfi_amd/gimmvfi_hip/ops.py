@@ -56,9 +56,11 @@ def V(t, coff=0, c=None):
 class ConvLayer:
     """Packed weights [Cout][KH][KW][cin_pad] (+ float bias / PReLU slope) of one convolution."""
 
-    def __init__(self, rt, w, b, stride=1, pad=None, pad_mode=L.PAD_ZEROS, slope=None, cin_pad=None, wdir=False):
+    def __init__(self, rt, w, b, stride=1, pad=None, pad_mode=L.PAD_ZEROS, slope=None, cin_pad=None, wdir=False, lin=False):
         """wdir: also pack the MFMA-fragment-ordered image (w_layout = 2) of the weights-direct variant of the LDS-DMA
-        kernel -- for the layers of the flow estimators' recurrences (small M, launch time = one workgroup's K chain)."""
+        kernel -- for the layers of the flow estimators' recurrences (small M, launch time = one workgroup's K chain).
+        lin: pack the same image for the row-linear kernel (csrc/conv_lin.hip: 1x1 layers on >= 65536 rows, small K); the layer
+        takes it where gvfi_conv2d_lin_eligible says 1 and the LDS-DMA tiles elsewhere."""
         cout, cin, kh, kw = w.shape
         cp = roundup(cin, rt.VE) if cin_pad is None else cin_pad
         pk = torch.zeros(cout, kh, kw, cp, dtype=torch.float32, device=w.device)
@@ -78,8 +80,10 @@ class ConvLayer:
             wk = torch.gather(wk, 2, src_slot[:, None, :, None].expand(cout, k // bke, 8, rt.VE))
             self.w_glds = wk.permute(1, 0, 2, 3).contiguous().to(rt.tdtype).to(rt.device)   # [chunk][n][slot][ve]
         self.w_frag = None
-        if (wdir and rt.precision in ("bf16", "fp16") and cp % 64 == 0 and pad_mode == L.PAD_ZEROS and kh * kw <= 32
-                and os.environ.get("GVFI_WDIR", "1") != "0"):
+        self.use_wdir = bool(wdir) and os.environ.get("GVFI_WDIR", "1") != "0"
+        self.use_lin = bool(lin) and kh == 1 and kw == 1 and stride == 1 and os.environ.get("GVFI_LIN", "1") != "0"
+        if ((self.use_wdir or self.use_lin) and rt.precision in ("bf16", "fp16") and cp % 64 == 0 and pad_mode == L.PAD_ZEROS
+                and kh * kw <= 32):
             k = kh * kw * cp
             nb = (cout + 31) // 32
             wp = torch.zeros(nb * 32, kh * kw, cp, dtype=torch.float32, device=pk.device)
@@ -345,7 +349,7 @@ class Runtime:
                       and (want == 5 or n * h * w_ >= 65536))
             if want == 5:
                 p.w, p.w_layout = layer.w.data_ptr(), 0
-            elif want in (0, 6) and layer.w_frag is not None and p.c0 % 64 == 0 and p.c1 % 64 == 0 and groups == 1:
+            elif want in (0, 6) and layer.w_frag is not None and layer.use_wdir and p.c0 % 64 == 0 and p.c1 % 64 == 0 and groups == 1:
                 p.w, p.w_layout = layer.w_frag.data_ptr(), 2      # weights-direct variant of the LDS-DMA kernel
                 algo = 2 | (algo & ~15)
                 want = 2
@@ -405,6 +409,11 @@ class Runtime:
         if layer is not None and want == 0 and p.w_layout == 1 and stats is None and self.use_p3x3 \
                 and self.lib.conv2d_p3x3_eligible(C.byref(p)) == 1:
             p.algo = 4 | (algo & ~15)       # halo-staged 3x3 kernel (conv_p3x3.hip) ahead of the LDS-DMA kernel
+        if layer is not None and want in (0, 8) and layer.w_frag is not None and layer.use_lin and groups == 1:
+            keep = (p.w, p.w_layout, p.algo)
+            p.w, p.w_layout, p.algo = layer.w_frag.data_ptr(), 2, 8 | (algo & ~15)
+            if self.lib.conv2d_lin_eligible(C.byref(p)) < (1 if want == 0 else 2):
+                p.w, p.w_layout, p.algo = keep          # not a row-linear problem (few rows, other epilogue): the tile kernels
         if layer is not None and want == 0 and small3:
             keep = (p.w, p.w_layout)
             p.w, p.w_layout = layer.w.data_ptr(), 0
@@ -433,6 +442,7 @@ class Runtime:
                 self.last_stats_fused = True
             else:
                 p.stats = None
+        self.last_algo = p.algo & 15         # (tests: which kernel family an explicit request really got)
         if self.ev_log is None:
             self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
         else:
@@ -447,7 +457,7 @@ class Runtime:
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
             kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel",
-                     6: "conv_igemm_glds_kernel[wdir]", 7: "conv_col7_kernel"}[plan[0]]
+                     6: "conv_igemm_glds_kernel[wdir]", 7: "conv_col7_kernel", 8: "conv_lin_kernel"}[plan[0]]
             tag = f"{kname}<{ {L.F32: 'float', L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"

@@ -100,6 +100,7 @@ typedef struct {
                                          * 5 = its mid-channel sibling (gvfi_conv2d_p3x3s);         *
                                          * 7 = column kernel of the 7x7 few-channel layers          *
                                          * (gvfi_conv2d_col7);                                       *
+                                         * 8 = row-linear kernel (gvfi_conv2d_lin, w_layout 2);      *
                                          * bit 4 "pad16": the caller owns the channel padding of   *
                                          * y and res up to the next 16-byte boundary -- a ragged   *
                                          * last channel group may be accessed in whole 16-byte     *
@@ -145,6 +146,14 @@ int gvfi_conv2d_patch(const gvfi_conv_params* p, void* stream);
  * with the weights as the 16-row operand (Cout padded to 16, not 32).  gvfi_conv2d routes here when
  * gvfi_conv2d_col7_eligible == 1 (algo 0; >= 65536 output pixels, image >= 32 x 32) or with algo = 7 (eligible == 2:
  * runnable); algo = 3 keeps the patch kernel.  fp32 accumulation order differs from the patch kernel (not bit-identical). */
+/* Linear layers (1x1, stride 1) on very many rows with K = c0 + c1 in {128, 192, 256, 512} and Cout <= 512 (K = 128),
+ * <= 256 (K = 192 / 256), <= 128 (K = 512) -- the transformer linears of GIMM-VFI-F's Twins encoders / latent cost encoder
+ * (twins.py:331-546, encoder.py:214-346): weights (w_layout 2, the fragment-ordered image) resident in registers for a
+ * persistent loop over the rows, operands straight from the rows, bias + none / ReLU / GELU + optional residual (16-bit or
+ * float), 16-bit or float output.  bf16 / IEEE half.  Selected with algo = 8; gvfi_conv2d_lin_eligible: 1 = worth routing
+ * (>= 65536 rows), 2 = runnable, 0 = not this kernel's problem. */
+int gvfi_conv2d_lin_eligible(const gvfi_conv_params* p);
+int gvfi_conv2d_lin(const gvfi_conv_params* p, void* stream);
 int gvfi_conv2d_col7_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_col7(const gvfi_conv_params* p, void* stream);
 /* 3x3 stride-1 zero-padded bf16 convolution with Cout % 256 == 0, channel counts % 64 == 0, w_layout 1 and >= 65536

@@ -46,9 +46,9 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     x, w = _rounded(rt, x), _rounded(rt, w)
     dev = _dev(rt)
     lay = ConvLayer(rt, w, b, stride=stride, pad=None if pad is None else (pad, pad),
-                    pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope, wdir=(algo & 15) == 6)
-    if (algo & 15) == 6:
-        assert lay.w_frag is not None, "weights-direct image not packed"
+                    pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope, wdir=(algo & 15) == 6, lin=(algo & 15) == 8)
+    if (algo & 15) in (6, 8):
+        assert lay.w_frag is not None, "fragment-ordered weight image not packed"
     if split is None:
         xa = _to_act(rt, x).to(dev)
         x0, x1 = View(xa, 0, Cin), None
@@ -93,6 +93,8 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
         out.fill_(3.0)
         rt.conv(lay, x0, View(out, coff, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
                 slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile, algo=algo)
+        if (algo & 15) == 8:
+            assert rt.last_algo == 8, "the row-linear kernel declined this problem"
         got = out.float().cpu()
         assert float((got[..., :coff] - 3.0).abs().max()) == 0.0 if coff else True
         assert float((got[..., coff + Cout:] - 3.0).abs().max()) == 0.0        # nothing beyond the slice is written

@@ -103,6 +103,17 @@ CONV_SHAPES = [
     (1, 70, 71, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=6)),
     (1, 8, 33, 8, 32, 7, 7, dict(algo=7, act1=L.ACT_RELU, pad16=True, bf16_only=True)),
     (1, 6, 36, 24, 12, 7, 7, dict(algo=7, pad16=True, bf16_only=True)),
+    # row-linear kernel (conv_lin.hip, algo 8): weights resident in registers, rows streamed; every (K, N) instantiation, ragged
+    # last tile, GELU / ReLU, float residual + float output (the transformer residual streams), 16-bit residual, two sources
+    (1, 1, 75, 128, 128, 1, 1, dict(algo=8, coff=8, bf16_only=True)),
+    (1, 1, 70, 128, 256, 1, 1, dict(algo=8, coff=0, act1=L.ACT_GELU, bf16_only=True)),
+    (1, 1, 40, 128, 384, 1, 1, dict(algo=8, coff=8, with_res=True, res_f32=True, out_f32=True, bf16_only=True)),
+    (1, 1, 37, 128, 512, 1, 1, dict(algo=8, coff=0, act1=L.ACT_GELU, bf16_only=True)),
+    (1, 1, 33, 192, 128, 1, 1, dict(algo=8, coff=8, split=64, bf16_only=True)),
+    (1, 1, 65, 192, 256, 1, 1, dict(algo=8, coff=0, with_res=True, bf16_only=True)),
+    (1, 1, 64, 256, 128, 1, 1, dict(algo=8, coff=8, act1=L.ACT_RELU, bf16_only=True)),
+    (1, 1, 31, 256, 192, 1, 1, dict(algo=8, coff=0, out_f32=True, bf16_only=True)),
+    (2, 3, 17, 512, 128, 1, 1, dict(algo=8, coff=8, with_res=True, res_f32=True, out_f32=True, bf16_only=True)),
     # halo-staged 3x3 kernel (conv_p3x3.hip): ragged 16 x 16 tiles, two sources / two channel chunks, both epilogues, two Cout tiles
     (1, 17, 19, 64, 256, 3, 3, dict(algo=4, act1=L.ACT_PRELU, pad16=True, bf16_only=True)),
     (1, 17, 19, 128, 256, 3, 3, dict(algo=4, split=64, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU, pad16=True, bf16_only=True)),
