@@ -81,7 +81,11 @@ class ConvLayer:
             self.w_glds = wk.permute(1, 0, 2, 3).contiguous().to(rt.tdtype).to(rt.device)   # [chunk][n][slot][ve]
         self.w_frag = None
         self.use_wdir = bool(wdir) and os.environ.get("GVFI_WDIR", "1") != "0"
-        self.use_lin = bool(lin) and kh == 1 and kw == 1 and stride == 1 and os.environ.get("GVFI_LIN", "1") != "0"
+        # (measured in round 4, profiles/r4_lin_kernel_ab.txt: the row-linear kernel is SLOWER than the LDS-DMA tiles on every one of
+        # GIMM-VFI-F's linears -- 80 vs 60 us for 128 -> 128 on 229 k rows, 180 vs 190 frames/s end to end: an MFMA operand is 16 bytes
+        # of ONE row per lane, i.e. 64 cache lines per load instruction straight from global memory, where the LDS-DMA tile copies
+        # whole rows coalesced.  Off unless GVFI_LIN=1.)
+        self.use_lin = bool(lin) and kh == 1 and kw == 1 and stride == 1 and os.environ.get("GVFI_LIN", "0") == "1"
         if ((self.use_wdir or self.use_lin) and rt.precision in ("bf16", "fp16") and cp % 64 == 0 and pad_mode == L.PAD_ZEROS
                 and kh * kw <= 32):
             k = kh * kw * cp
@@ -412,7 +416,8 @@ class Runtime:
         if layer is not None and want in (0, 8) and layer.w_frag is not None and layer.use_lin and groups == 1:
             keep = (p.w, p.w_layout, p.algo)
             p.w, p.w_layout, p.algo = layer.w_frag.data_ptr(), 2, 8 | (algo & ~15)
-            if self.lib.conv2d_lin_eligible(C.byref(p)) < (1 if want == 0 else 2):
+            el = self.lib.conv2d_lin_eligible(C.byref(p))
+            if not (el == 1 or (want == 8 and el == 2)):
                 p.w, p.w_layout, p.algo = keep          # not a row-linear problem (few rows, other epilogue): the tile kernels
         if layer is not None and want == 0 and small3:
             keep = (p.w, p.w_layout)

@@ -5,6 +5,8 @@ real libgimmvfi_hip.so on the GPU) and compares with an independent torch / orac
 """
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -45,8 +47,17 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     slope = torch.rand(Cout, generator=g) * 0.3 + 0.1
     x, w = _rounded(rt, x), _rounded(rt, w)
     dev = _dev(rt)
-    lay = ConvLayer(rt, w, b, stride=stride, pad=None if pad is None else (pad, pad),
-                    pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope, wdir=(algo & 15) == 6, lin=(algo & 15) == 8)
+    keep_lin = os.environ.get("GVFI_LIN")
+    if (algo & 15) == 8:
+        os.environ["GVFI_LIN"] = "1"       # (the row-linear kernel is off by default: measured slower, profiles/r4_lin_kernel_ab.txt)
+    try:
+        lay = ConvLayer(rt, w, b, stride=stride, pad=None if pad is None else (pad, pad),
+                        pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope, wdir=(algo & 15) == 6, lin=(algo & 15) == 8)
+    finally:       # the switch is read when the layer is packed; leave the process environment as it was
+        if keep_lin is None:
+            os.environ.pop("GVFI_LIN", None)
+        else:
+            os.environ["GVFI_LIN"] = keep_lin
     if (algo & 15) in (6, 8):
         assert lay.w_frag is not None, "fragment-ordered weight image not packed"
     if split is None:
