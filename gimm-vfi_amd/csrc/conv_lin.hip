@@ -24,13 +24,26 @@ struct LinArgs {
     int nb_tot;         // 32-feature blocks of the weight image (ceil(Cout / 32))
 };
 
-// NBW: feature blocks per wave; KS: k-steps of 16 (K = 16 KS = c0 + c1); G: token groups of 32 per tile
-template <typename T, int NBW, int KS, int G>
+// NBW: feature blocks per wave; KS: k-steps of 16 (K = 16 KS = c0 + c1); G: token groups of 32 per tile.
+// STAGE: the rows of a tile travel global -> registers -> LDS as COALESCED 16-byte chunks (consecutive lanes = consecutive
+// chunks of a row), double-buffered across the persistent loop, and the MFMA operands are ds_read_b128 of a padded tile (row
+// pitch an odd multiple of 16 bytes: the 32 rows of a fragment read fall into distinct bank groups).  Without it (first
+// version, measured: profiles/r4_lin_kernel_ab.txt) every lane loads 16 bytes of ITS row straight from global memory -- 64
+// cache lines per load instruction -- and the kernel is slower than the LDS-DMA tiles it was meant to beat.
+template <typename T, int NBW, int KS, int G, bool STAGE>
 __global__ void __launch_bounds__(256) conv_lin_kernel(LinArgs a) {
     const gvfi_conv_params& p = a.p;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    constexpr int AR = KS < 16 ? KS : 16;           // operand ring depth (k-steps)
+    constexpr int TT = 32 * G;                      // tokens per tile
+    constexpr int K = 16 * KS;
+    constexpr int PITCH = K * 2 + 16;               // LDS bytes per staged row
+    constexpr int CPR = K / 8;                      // 16-byte chunks per row
+    constexpr int NCH = TT * CPR / 256;             // chunks per thread and tile
+    static_assert((TT * CPR) % 256 == 0, "tile chunks must divide over the workgroup");
+    constexpr int AR = KS < 16 ? KS : 16;           // operand ring depth of the un-staged form
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE ? 2 * TT * PITCH : 16];
     // ---- this wave's weight fragments: (block nb, k-step ks) = fragment ((ks / 4) * nb_tot + nb) * 4 + ks % 4 of the image
     uint4 wreg[NBW][KS];
     const uint4* wf = (const uint4*)p.w;
@@ -45,13 +58,42 @@ __global__ void __launch_bounds__(256) conv_lin_kernel(LinArgs a) {
     }
     const T* __restrict__ x0 = (const T*)p.x0;
     const T* __restrict__ x1 = (const T*)p.x1;
-    const long long ntiles = (a.rows + 32 * G - 1) / (32 * G);
+    const long long ntiles = (a.rows + TT - 1) / TT;
+    // staged form: chunk c = tid + 256 i of a tile = (row c / CPR, 16-byte column c % CPR)
+    auto chunk_src = [&](long long t, int i) -> const uint4* {
+        const int c = tid + 256 * i;
+        const int r = c / CPR, k = (c - r * CPR) * 8;
+        long long row = t * TT + r;
+        row = row < a.rows ? row : a.rows - 1;
+        return (const uint4*)(k < p.c0 ? x0 + row * p.ld0 + k : x1 + row * p.ld1 + (k - p.c0));
+    };
+    auto chunk_dst = [&](int buf, int i) -> uint4* {
+        const int c = tid + 256 * i;
+        const int r = c / CPR, col = c - r * CPR;
+        return (uint4*)(lds + buf * (TT * PITCH) + r * PITCH + col * 16);
+    };
+    uint4 nxt[STAGE ? NCH : 1];
+    int cur = 0;
+    if (STAGE) {
+        if ((long long)blockIdx.x < ntiles) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) nxt[i] = *chunk_src(blockIdx.x, i);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) *chunk_dst(0, i) = nxt[i];
+        }
+        __syncthreads();
+    }
     for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         long long row[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const long long r = t * (32 * G) + 32 * g + n;
+            const long long r = t * TT + 32 * g + n;
             row[g] = r < a.rows ? r : a.rows - 1;          // tail lanes recompute the last row, never store
+        }
+        const long long tn = t + gridDim.x;
+        if (STAGE && tn < ntiles) {                         // the next tile's rows: requested now, written to LDS after the MFMAs
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) nxt[i] = *chunk_src(tn, i);
         }
         auto a_src = [&](int g, int ks) -> const uint4* {
             const int k = 16 * ks + 8 * h;
@@ -64,24 +106,44 @@ __global__ void __launch_bounds__(256) conv_lin_kernel(LinArgs a) {
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][g][r] = 0.f;
-        uint4 areg[G][AR];
+        if (STAGE) {
+            const unsigned char* tb = lds + cur * (TT * PITCH);
 #pragma unroll
-        for (int ks = 0; ks < AR; ++ks)
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) areg[g][ks] = *a_src(g, ks);
+                for (int g = 0; g < G; ++g) {
+                    const uint4 av = *(const uint4*)(tb + (32 * g + n) * PITCH + (16 * ks + 8 * h) * 2);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+                    for (int j = 0; j < NBW; ++j) Mma2<T>::run(acc[j][g], wreg[j][ks], av);
+                }
+            }
+        } else {
+            uint4 areg[G][AR];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
+            for (int ks = 0; ks < AR; ++ks)
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) Mma2<T>::run(acc[j][g], wreg[j][ks], areg[g][ks % AR]);
-                if (ks + AR < KS) areg[g][ks % AR] = *a_src(g, ks + AR);
+                for (int g = 0; g < G; ++g) areg[g][ks] = *a_src(g, ks);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) Mma2<T>::run(acc[j][g], wreg[j][ks], areg[g][ks % AR]);
+                    if (ks + AR < KS) areg[g][ks % AR] = *a_src(g, ks + AR);
+                }
+            }
+        }
+        if (STAGE) {
+            // (the other buffer was last read one tile ago: every wave has passed the barrier that ended that tile)
+            if (tn < ntiles) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) *chunk_dst(cur ^ 1, i) = nxt[i];
             }
         }
         // ---- epilogue: y = act1(acc + bias) (+ res); register r of block nb = feature 32 nb + (r & 3) + 8 (r >> 2) + 4 h
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const long long r_ = t * (32 * G) + 32 * g + n;
+            const long long r_ = t * TT + 32 * g + n;
             if (r_ >= a.rows) continue;
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
@@ -123,6 +185,10 @@ __global__ void __launch_bounds__(256) conv_lin_kernel(LinArgs a) {
                     }
                 }
             }
+        }
+        if (STAGE) {
+            __syncthreads();        // the next tile is in LDS, and nobody reads this tile's buffer any more
+            cur ^= 1;
         }
     }
 }
@@ -172,8 +238,13 @@ extern "C" int gvfi_conv2d_lin(const gvfi_conv_params* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
 #define GVFI_LIN(NBW_, KS_, G_)                                                                                             \
     do {                                                                                                                    \
-        if (p.dtype == GVFI_F16) { GVFI_LAUNCH_COOP((conv_lin_kernel<f16_t, NBW_, KS_, G_>), dim3(grid), dim3(256), st, a); }  \
-        else { GVFI_LAUNCH_COOP((conv_lin_kernel<bf16_t, NBW_, KS_, G_>), dim3(grid), dim3(256), st, a); }                 \
+        if (p.algo & 32) {      /* A/B: the un-staged first version */                                                      \
+            if (p.dtype == GVFI_F16) { GVFI_LAUNCH_COOP((conv_lin_kernel<f16_t, NBW_, KS_, G_, false>), dim3(grid), dim3(256), st, a); }  \
+            else { GVFI_LAUNCH_COOP((conv_lin_kernel<bf16_t, NBW_, KS_, G_, false>), dim3(grid), dim3(256), st, a); }                 \
+        } else {                                                                                                            \
+            if (p.dtype == GVFI_F16) { GVFI_LAUNCH_COOP((conv_lin_kernel<f16_t, NBW_, KS_, G_, true>), dim3(grid), dim3(256), st, a); }   \
+            else { GVFI_LAUNCH_COOP((conv_lin_kernel<bf16_t, NBW_, KS_, G_, true>), dim3(grid), dim3(256), st, a); }                  \
+        }                                                                                                                   \
     } while (0)
     switch (var) {
         case 1082: GVFI_LIN(1, 8, 2); break;
