@@ -84,7 +84,8 @@ class ConvLayer:
         # (measured in round 4, profiles/r4_lin_kernel_ab.txt: the row-linear kernel is SLOWER than the LDS-DMA tiles on every one of
         # GIMM-VFI-F's linears -- 80 vs 60 us for 128 -> 128 on 229 k rows, 180 vs 190 frames/s end to end: an MFMA operand is 16 bytes
         # of ONE row per lane, i.e. 64 cache lines per load instruction straight from global memory, where the LDS-DMA tile copies
-        # whole rows coalesced.  Off unless GVFI_LIN=1.)
+        # whole rows coalesced; with the rows staged through LDS (v2) 69.8 us / 183.8 frames/s: then the 8-byte output pieces of 32
+        # different rows per store instruction bind.  Off unless GVFI_LIN=1.)
         self.use_lin = bool(lin) and kh == 1 and kw == 1 and stride == 1 and os.environ.get("GVFI_LIN", "0") == "1"
         if ((self.use_wdir or self.use_lin) and rt.precision in ("bf16", "fp16") and cp % 64 == 0 and pad_mode == L.PAD_ZEROS
                 and kh * kw <= 32):
