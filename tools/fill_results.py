@@ -15,7 +15,7 @@ names = {"configs[2]": "R 2K 2048×1088 DS 0.5, 8× (`configs[2]`, per GPU)", "c
 for c in d.get("configs", []):
     rows.append((names[c["baseline_config"]], c["value"], c["ms_per_step"], c["roofline"], r3[c["baseline_config"]]))
 tab = ["**All configurations of the metric, one MI355X, one `bench.py` run** (`" + sys.argv[1] + "`; box-to-box spread of the same",
-       "build ≈ 2 %, so gains are quoted from same-box A/Bs, `profiles/HISTORY.md`):", "",
+       "build 2–4 %, so gains are quoted from same-box A/Bs, `profiles/HISTORY.md`):", "",
        "| configuration | frames/s | ms/step | dominant kernel: achieved / peak | whole path / peak | end of round 3 |", "|---|---|---|---|---|---|"]
 for n, v, ms, rf, old in rows:
     path = rf.get("path", {}).get("frac")
