@@ -249,7 +249,7 @@ def test_col7_folded_finalisation_equals_finalize_image(rt):
     if rt.precision != "bf16":
         pytest.skip("the column kernel is bf16 only")
     kc.col7_planar_case(rt)
-    kc.col7_planar_case(rt, N=1, H=70, W=71, seed=9)
+    kc.col7_planar_case(rt, N=1, H=40, W=65, seed=9)      # (the GPU suite runs 70 x 71: an interior tile)
 
 
 def test_softsplat_gather_is_deterministic_and_matches_the_oracle(rt):
