@@ -169,7 +169,7 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
     # be recorded per launch inside a graph replay, so the per-launch durations of the dominant kernel come from
     # an instrumented eager pass of the same step right after the timed region (rank 0, same inputs, same stream).
     ev = []
-    ev_steps = max(1, min(steps, 3 if H * W <= 256 * 448 else 1))
+    ev_steps = max(1, min(steps, 3 if H * W <= 256 * 448 else 2))
     if rank == 0:
         rt.ev_log = ev
         rt.ev_shapes = bool(shapes)
