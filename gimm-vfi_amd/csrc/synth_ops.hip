@@ -147,11 +147,13 @@ extern "C" int gvfi_combine_warps(const float* img4_0, const float* img4_1, cons
 // ~4.6 ms of the 19 ms per timestep.  Per-channel arithmetic is that of resize_nhwc_kernel (mul * (ly.w0*(lx.w0*v00 +
 // lx.w1*v01) + ly.w1*(lx.w0*v10 + lx.w1*v11))) followed by that of combine_warps_kernel, so the results are bit-equal to
 // the separate passes; with H == Hf (rscale = inv = 1) the interpolation weights are exactly (1, 0).
-// STAGE (up-sampling by >= 2, Wf a multiple of the block): a block is 256 consecutive pixels of ONE full-resolution row; the
-// <= 130 x 2 decoder pixels its bilinear taps touch are copied to LDS once (3 float4 loads per thread instead of 24 through
-// the texture path: at 4K, 7 timesteps, the kernel was 3.6 ms at 2.3x its L1-path bound) and the taps are LDS reads.  The
-// values read are the same, so the results are bit-identical to the direct form.
-#define CWU_SPAN 130
+// STAGE (up-sampling by >= 2, Wf a multiple of 64, Hf of 4): a block is a 64 x 4 tile of full-resolution pixels, one row per
+// wave.  The <= 34 x 4 decoder pixels its bilinear taps touch are copied to LDS once (the taps become LDS reads), and -- what
+// matters: the 24 image taps per pixel bind this kernel, profiles/r4_combine_bound_probe.txt -- the four rows of a tile share
+// their source rows in the CU's L1 (5 source rows per sample instead of 4 x 2 when every block was one 256-pixel row segment).
+// The values read are the same, so the results are bit-identical to the direct form.
+#define CWU_SX 34
+#define CWU_SY 4
 template <typename T, bool STAGE>
 __global__ void __launch_bounds__(256) combine_warps_up_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
                                         const float* __restrict__ dec, int ldd, int H, int W, float rscale, float inv,
@@ -160,21 +162,25 @@ __global__ void __launch_bounds__(256) combine_warps_up_kernel(const float* __re
                                         int src_B) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long HWf = (long long)Hf * Wf;
-    __shared__ __attribute__((aligned(16))) float sdec[STAGE ? 2 * CWU_SPAN * 24 : 4];
-    int sx0 = 0;
+    __shared__ __attribute__((aligned(16))) float sdec[STAGE ? CWU_SY * CWU_SX * 24 : 4];
+    int sx0 = 0, sy0 = 0;
     if (STAGE) {
-        // (Wf % 256 == 0: the block lies in one row of one image, and total is a multiple of the block)
-        const long long idx0 = (long long)blockIdx.x * 256;
-        const long long pix0 = idx0 % HWf, b0 = idx0 / HWf;
-        const int xb = (int)(pix0 % Wf), yb = (int)(pix0 / Wf);
-        const Lerp lyb = src_index(yb, rscale, H);
+        // block -> tile (b0, rows 4 tyi .. +3, columns 64 txi .. +63); thread -> pixel (row = wave, column = lane)
+        const int bx = Wf / 64, by = Hf / 4;
+        const long long blk = blockIdx.x;
+        const int txi = (int)(blk % bx), tyi = (int)((blk / bx) % by);
+        const long long b0 = blk / ((long long)bx * by);
+        const int xb = 64 * txi, yb = 4 * tyi;
+        idx = (b0 * Hf + yb + (threadIdx.x >> 6)) * (long long)Wf + xb + (threadIdx.x & 63);
         sx0 = src_index(xb, rscale, W).i0;
-        const int nsx = src_index(xb + 255, rscale, W).i1 - sx0 + 1;       // <= CWU_SPAN (host: inv >= 2)
-        for (int u = threadIdx.x; u < 2 * nsx * 6; u += 256) {
+        sy0 = src_index(yb, rscale, H).i0;
+        const int nsx = src_index(xb + 63, rscale, W).i1 - sx0 + 1;        // <= CWU_SX (host: inv >= 2)
+        const int nsy = src_index(yb + 3, rscale, H).i1 - sy0 + 1;         // <= CWU_SY
+        for (int u = threadIdx.x; u < nsy * nsx * 6; u += 256) {
             const int r = u / (nsx * 6), v = u - r * (nsx * 6);
             const int px = v / 6, q = v - px * 6;
-            const float* src = dec + ((b0 * H + (r ? lyb.i1 : lyb.i0)) * (long long)W + sx0 + px) * ldd + 4 * q;
-            *(float4*)(sdec + (r * CWU_SPAN + px) * 24 + 4 * q) = *(const float4*)src;
+            const float* src = dec + ((b0 * H + sy0 + r) * (long long)W + sx0 + px) * ldd + 4 * q;
+            *(float4*)(sdec + (r * CWU_SX + px) * 24 + 4 * q) = *(const float4*)src;
         }
         __syncthreads();
     }
@@ -182,10 +188,10 @@ __global__ void __launch_bounds__(256) combine_warps_up_kernel(const float* __re
     const long long pix = idx % HWf, b = idx / HWf;
     const int x = (int)(pix % Wf), y = (int)(pix / Wf);
     const Lerp ly = src_index(y, rscale, H), lx = src_index(x, rscale, W);
-    const float* p00 = STAGE ? sdec + (lx.i0 - sx0) * 24 : dec + ((b * H + ly.i0) * (long long)W + lx.i0) * ldd;
-    const float* p01 = STAGE ? sdec + (lx.i1 - sx0) * 24 : dec + ((b * H + ly.i0) * (long long)W + lx.i1) * ldd;
-    const float* p10 = STAGE ? sdec + (CWU_SPAN + lx.i0 - sx0) * 24 : dec + ((b * H + ly.i1) * (long long)W + lx.i0) * ldd;
-    const float* p11 = STAGE ? sdec + (CWU_SPAN + lx.i1 - sx0) * 24 : dec + ((b * H + ly.i1) * (long long)W + lx.i1) * ldd;
+    const float* p00 = STAGE ? sdec + ((ly.i0 - sy0) * CWU_SX + lx.i0 - sx0) * 24 : dec + ((b * H + ly.i0) * (long long)W + lx.i0) * ldd;
+    const float* p01 = STAGE ? sdec + ((ly.i0 - sy0) * CWU_SX + lx.i1 - sx0) * 24 : dec + ((b * H + ly.i0) * (long long)W + lx.i1) * ldd;
+    const float* p10 = STAGE ? sdec + ((ly.i1 - sy0) * CWU_SX + lx.i0 - sx0) * 24 : dec + ((b * H + ly.i1) * (long long)W + lx.i0) * ldd;
+    const float* p11 = STAGE ? sdec + ((ly.i1 - sy0) * CWU_SX + lx.i1 - sx0) * 24 : dec + ((b * H + ly.i1) * (long long)W + lx.i1) * ldd;
     float d[24];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -251,8 +257,8 @@ extern "C" int gvfi_combine_warps_up(const float* img4_0, const float* img4_1, c
     const float inv = (float)((double)Hf / (double)H);           // torch: scale_factor = 1 / ds_factor, flows x the same
     const float rscale = (float)(1.0 / ((double)Hf / (double)H));
     const long long total = (long long)B * Hf * Wf;
-    // staged form: whole rows of 256-pixel blocks, up-sampling by 2 or more (<= 130 decoder pixels per block row), ldd == 24
-    const bool stage = GVFI_BLOCK == 256 && (Wf % 256) == 0 && Hf >= 2 * H && ldd == 24;
+    // staged form: 64 x 4 pixel tiles, up-sampling by 2 or more (<= 34 x 4 decoder pixels per tile), ldd == 24
+    const bool stage = GVFI_BLOCK == 256 && (Wf % 64) == 0 && (Hf % 4) == 0 && Hf >= 2 * H && ldd == 24;
     if (stage) {
         GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((combine_warps_up_kernel<T, true>), grid1d(total), dim3(256),
                                                 (hipStream_t)stream, img4_0, img4_1, dec, ldd, H, W, rscale, inv, (T*)act,

@@ -260,9 +260,10 @@ def test_softsplat_gather_is_deterministic_and_matches_the_oracle(rt):
 def test_combine_warps_up_equals_separate_passes(rt):
     for scale in (1, 2, 4):
         kc.combine_warps_up_case(rt, scale=scale)
-    # full-resolution rows that are whole 256-pixel blocks: the decoder taps are staged through LDS
+    # full-resolution frames made of whole 64 x 4 tiles: the staged form (decoder taps through LDS, one tile row per wave)
     kc.combine_warps_up_case(rt, B=2, H=6, W=64, scale=4)
-    kc.combine_warps_up_case(rt, B=1, H=5, W=128, scale=2)
+    kc.combine_warps_up_case(rt, B=1, H=6, W=128, scale=2)
+    kc.combine_warps_up_case(rt, B=1, H=7, W=48, scale=4)
 
 
 def test_softsplat_native_op_contract(rt):
