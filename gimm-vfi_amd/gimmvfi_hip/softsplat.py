@@ -60,9 +60,13 @@ def softsplat(tenIn, tenFlow, tenMetric, strMode, return_norm=False):
     (default / "addeps": + 1e-7, "zeroeps": 0 -> 1, "clipeps": clip at 1e-7).  return_norm: (numerator, normaliser)."""
     kind, _, eps = strMode.partition("-")
     assert kind in _KINDS, strMode
-    # "sum" / "avg" take no suffix: the reference only recognises the bare words (softsplat.py:289-296) and with a suffix
-    # silently computes something else (no weight channel, yet the last INPUT channel as the normaliser) -- rejected here
-    assert kind in ("linear", "softmax") or eps == "", f"softsplat: mode {strMode!r}: 'sum' / 'avg' take no eps suffix"
+    # "sum-<anything>" is the plain splatted sum in the reference too (softsplat.py:289-296,322: no weight channel, no normalisation,
+    # the metric is not even looked at), so it is accepted and means "sum".  "avg-<suffix>" is the one odd corner: the reference
+    # only appends the ones channel for the bare word, yet normalises for every "avg-*" -- by the LAST INPUT CHANNEL; nothing
+    # can rely on that, so it is rejected instead of reproduced
+    assert kind != "avg" or eps == "", f"softsplat: mode {strMode!r}: 'avg' takes no eps suffix"
+    if kind == "sum" and eps != "":
+        tenMetric = None
     assert (tenMetric is None) == (kind in ("sum", "avg")), f"mode {kind!r}: metric {'not ' if tenMetric is None else ''}given"
     if kind == "sum":
         weight = None

@@ -122,6 +122,18 @@ def round_frames(blocks, hosts, N, num_pairs):
                 yield "flow", j * (N - 1) + i, pics[jj * (N - 1) + i]
 
 
+def load_checkpoint(model, load_path):
+    """Reference src/video_Nx.py:99-115.  A GIMM-VFI checkpoint is {"state_dict": ...} loaded strict=True; a path containing
+    "ours" is the reference's legacy branch: a flat dict whose `module.feature_bone.*` keys are renamed to `frame_encoder.*`
+    (every other key dropped) and loaded strict=False -- on the GIMM-VFI models, which have no `frame_encoder`, that loads
+    nothing, exactly as in the reference; the (missing, unexpected) key lists are returned for the caller / tests."""
+    ckpt = torch.load(load_path, map_location="cpu")
+    if "ours" in load_path:
+        ckpt = {k.replace("module.feature_bone", "frame_encoder"): v for k, v in ckpt.items() if "feature_bone" in k}
+        return model.load_state_dict(ckpt, strict=False)
+    return model.load_state_dict(ckpt["state_dict"], strict=True)
+
+
 def main(argv=None):
     args, extra_args = parse_args(argv)
     set_seed(args.seed)
@@ -141,8 +153,7 @@ def main(argv=None):
         config.arch["precision"] = args.precision
     model, _ = create_model(config.arch)
     if args.load_path != "":
-        ckpt = torch.load(args.load_path, map_location="cpu")
-        model.load_state_dict(ckpt["state_dict"], strict=True)
+        load_checkpoint(model, args.load_path)
     elif args.random_init:
         from gimmvfi_hip.params import random_state_dict_for
 

@@ -223,3 +223,38 @@ def test_synthetic_pairs_are_seeded_and_quantised():
     assert float(a.min()) >= 0 and float(a.max()) <= 1
     assert torch.equal(torch.round(a * 255), a * 255 + 0 * a) or float((torch.round(a * 255) - a * 255).abs().max()) < 1e-4
     assert not torch.equal(a[0], a[1])
+
+
+def test_cli_checkpoint_branches(tmp_path):
+    """src/video_Nx.py:99-115: {"state_dict": ...} strict=True, and the legacy branch for paths containing "ours"
+    (module.feature_bone.* -> frame_encoder.*, every other key dropped, strict=False)."""
+    sys.path.insert(0, SRC)
+    try:
+        import video_Nx
+    finally:
+        sys.path.remove(SRC)
+
+    class Legacy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.frame_encoder = torch.nn.Linear(3, 2)
+            self.other = torch.nn.Linear(2, 2)
+
+    m = Legacy()
+    other0 = m.other.weight.detach().clone()
+    w = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    p_ours = str(tmp_path / "ours_legacy.pth")
+    torch.save({"module.feature_bone.weight": w, "module.feature_bone.bias": torch.ones(2), "module.other.weight": torch.zeros(2, 2)}, p_ours)
+    r = video_Nx.load_checkpoint(m, p_ours)
+    assert torch.equal(m.frame_encoder.weight, w) and torch.equal(m.other.weight, other0)
+    assert sorted(r.missing_keys) == ["other.bias", "other.weight"] and not r.unexpected_keys
+    p_std = str(tmp_path / "gimmvfi.pth")
+    sd = {k: v + 1 for k, v in Legacy().state_dict().items()}
+    torch.save({"state_dict": sd}, p_std)
+    video_Nx.load_checkpoint(m, p_std)
+    assert torch.equal(m.other.weight, sd["other.weight"])
+    bad = dict(sd)
+    bad.pop("other.bias")
+    torch.save({"state_dict": bad}, p_std)
+    with pytest.raises(RuntimeError):
+        video_Nx.load_checkpoint(m, p_std)

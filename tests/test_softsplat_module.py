@@ -109,9 +109,27 @@ def test_wrapper_error_behaviour():
         ss.softsplat(x, flow, metric, "median")
     with pytest.raises(AssertionError):
         ss.softsplat_func.apply(x, flow)               # CPU tensors: softsplat.py:439-440 `assert False`
-    for bad in ("sum-addeps", "avg-zeroeps"):          # the reference only knows the bare words; with a suffix it silently
-        with pytest.raises(AssertionError):            # divides by the last INPUT channel -- rejected
-            ss.softsplat(x, flow, None, bad)
+    with pytest.raises(AssertionError):                # "avg-<suffix>": the reference divides by the last INPUT channel -- rejected
+        ss.softsplat(x, flow, None, "avg-zeroeps")
+
+
+@pytest.mark.parametrize("metric_given", [False, True])
+def test_sum_with_a_suffix_is_the_plain_sum(monkeypatch, metric_given):
+    """softsplat.py:286-352: only the bare word "sum" asserts `tenMetric is None`; "sum-<anything>" appends no weight channel and
+    is never normalised, i.e. it IS the splatted sum, with or without a metric."""
+    from gimmvfi_hip import softsplat as ss
+
+    monkeypatch.setattr(ss, "softsplat_func", _HostsimSplat)
+    x, flow, metric = _inputs(seed=6)
+    got = ss.softsplat(x, flow, metric if metric_given else None, "sum-addeps")
+    want = ss.softsplat(x, flow, None, "sum")
+    # (two runs of the float-atomic scatter: same sums up to the order of the additions)
+    assert got.shape == x.shape and float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    if rh.reference_available():
+        rh.load_reference_modules()
+        ref_mod = sys.modules[rh._PKG + ".generalizable_INR.modules.softsplat"]
+        ref = ref_mod.softsplat(x, flow, metric if metric_given else None, "sum-addeps")
+        assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_unknown_eps_suffix_leaves_the_normaliser_untouched(monkeypatch):

@@ -7,6 +7,7 @@
 #   bench            the default bench line (headline + every BASELINE configuration)
 #   shapes-<cfg>     per-conv-shape table of one configuration (cfg: r448 r2k r4k f448 f4k)
 #   prof-<cfg>       rocprofv3 --kernel-trace summary (tools/rocpd_stats.py) of one configuration
+#   timeline-<cfg>   wall-clock structure of one step (first start / last end per kernel, GPU-busy union; tools/phase_timeline.py)
 #   pmc-p3x3         PMC passes of the hot 3x3 kernel (SQ + GRBM | FETCH_SIZE | WRITE_SIZE, separate passes)
 #   pmc-wdir         PMC passes of the weights-direct recurrence kernel (SQ x2 | TCC | TCP | FETCH_SIZE | WRITE_SIZE)
 #   hbm-<cfg>        HBM bytes per kernel (FETCH_SIZE / WRITE_SIZE passes over a bench run, joined with prof-<cfg>'s durations)
@@ -35,6 +36,8 @@ for step in "$@"; do
     shapes-*) c=${step#shapes-}; timeout 400 python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) --shapes $O/conv_shapes_$c.md > $O/bench_$c.json 2> $O/bench_$c.err; head -12 $O/conv_shapes_$c.md | cut -c1-160;;
     prof-*) c=${step#prof-}; timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$c -o run -- python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/prof_$c.log 2>&1
       python tools/rocpd_stats.py $O/prof_$c $O/kernel_stats_$c.md > /dev/null; rm -rf $O/prof_$c; head -14 $O/kernel_stats_$c.md | cut -c1-160;;
+    timeline-*) c=${step#timeline-}; timeout 400 rocprofv3 --kernel-trace -d $O/tl_$c -o run -- python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/tl_$c.log 2>&1
+      python tools/phase_timeline.py $O/tl_$c prep_images $O/phase_timeline_$c.md > /dev/null; rm -rf $O/tl_$c; head -3 $O/phase_timeline_$c.md | cut -c1-220;;
     pmc-p3x3)
       p() { n=$1; shift; rm -rf $O/pmc_$n; ONLYP3=1 timeout 150 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$n -o run -- python tools/conv_bench.py bf16 "final.resblock 256->256 3x3 @256" > $O/pmc_$n.log 2>&1; }
       p mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS; p fetch FETCH_SIZE; p write WRITE_SIZE

@@ -15,7 +15,12 @@ def main(path, marker="prep_images", out=None):
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
     if len(marks) < 3:
         raise SystemExit(f"marker {marker!r} found {len(marks)} times")
-    a, b = marks[-3], marks[-2]          # a complete step that is followed by another one (a graph replay of the timed region)
+    # a complete step that is followed by another one.  bench.py --steps K --warmup W runs: 1 eager warm-up, W + K graph replays,
+    # then 2-3 instrumented eager passes (lanes serial, one event pair per launch) -- so the default, the step in the middle of the
+    # marker list, is a graph replay of the timed region; $TIMELINE_STEP picks another one
+    import os
+    k = int(os.environ.get("TIMELINE_STEP", str(len(marks) // 2)))
+    a, b = marks[k], marks[k + 1]
     step = rows[a:b]
     t0 = step[0][1]
     wall = max(r[2] for r in step) - t0
@@ -40,6 +45,11 @@ def main(path, marker="prep_images", out=None):
     txt = "\n".join(lines)
     if out:
         open(out, "w").write(txt + "\n")
+        # the raw launch sequence of the step (start offset, duration in us) next to the summary: launch gaps, lane overlap
+        with open(out.rsplit(".", 1)[0] + "_raw.csv", "w") as f:
+            f.write("start_us,dur_us,kernel\n")
+            for n, s_, e in step:
+                f.write(f"{(s_ - t0) / 1e3:.2f},{(e - s_) / 1e3:.2f},{n.split('(')[0][:70]}\n")
     print(txt)
 
 
