@@ -38,6 +38,11 @@ def build(verbose=True):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(_compile, srcs))
+    # objects of sources that no longer exist (a deleted kernel file) are pruned: the library is linked from `objs` only, but a
+    # stale object in the cache directory reads as product code that nobody can find the source of
+    for f in os.listdir(OBJ_DIR):
+        if f.endswith(".o") and os.path.join(OBJ_DIR, f) not in objs:
+            os.remove(os.path.join(OBJ_DIR, f))
     if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

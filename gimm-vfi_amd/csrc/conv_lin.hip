@@ -203,7 +203,9 @@ static int lin_variant(int K, int N) {
     return 0;
 }
 
-// 1 = gvfi_conv2d routes this problem here (algo 0 with the fragment-ordered weight image); 2 = runnable on request (algo 8)
+// 1 = a many-row problem this kernel was built for, 2 = runnable but latency-sized.  gvfi_conv2d never routes here by itself:
+// the kernel runs on an explicit algo 8 only (the Python host asks for it when GVFI_LIN=1 -- off by default: measured slower
+// than the LDS-DMA tiles, profiles/r4_lin_kernel_ab.txt)
 extern "C" int gvfi_conv2d_lin_eligible(const gvfi_conv_params* pp) {
     const gvfi_conv_params& p = *pp;
     if (p.dtype != GVFI_BF16 && p.dtype != GVFI_F16) return 0;

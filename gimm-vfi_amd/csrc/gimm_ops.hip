@@ -323,22 +323,44 @@ __global__ void softsplat_gather_kernel(const T* __restrict__ lat, int ldl, cons
             for (int q = CAP - 4; q < CAP; ++q) a[q] = NONE;
         }
     } else {
-        // ... longer lists (many sources converging on one cell): repeated selection of the next larger index
+        // ... longer lists (many sources converging on one cell): every walk over the four lists selects the next CAP larger
+        // indices (the same insertion network, restricted to indices above the last one consumed), so a target with cnt
+        // sources costs cnt / CAP walks -- O(cnt^2 / CAP) dependent loads instead of one walk per source (a
+        // degenerate flow field that collapses thousands of sources into one cell was a latency cliff).  Same ascending order
+        // of additions as the short path: bit-identical sums.
         int last = -1;
-        for (int k = 0; k < cnt; ++k) {
-            int best = NONE;
+        for (int done = 0; done < cnt; done += CAP) {
+#pragma unroll
+            for (int k = 0; k < CAP; ++k) a[k] = NONE;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 int s = hs[c4];
                 while (s >= 0) {
-                    if (s > last && s < best) best = s;
+                    if (s > last) {
+                        int e = s;
+#pragma unroll
+                        for (int k = 0; k < CAP; ++k) {
+                            const int lo = e < a[k] ? e : a[k];
+                            e = e < a[k] ? a[k] : e;
+                            a[k] = lo;
+                        }
+                    }
                     s = nx[s];
                 }
             }
-            Src r;
-            fetch(best, r);
-            accumulate(best, r);
-            last = best;
+#pragma unroll
+            for (int u0 = 0; u0 < CAP; u0 += 4) {
+                if (done + u0 >= cnt) break;
+                Src r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fetch(a[u0 + u] != NONE ? a[u0 + u] : a[0], r[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (done + u0 + u < cnt) {
+                        accumulate(a[u0 + u], r[u]);
+                        last = a[u0 + u];
+                    }
+            }
         }
     }
     float nrm = acc[C];

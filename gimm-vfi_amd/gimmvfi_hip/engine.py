@@ -67,13 +67,12 @@ class Engine:
         self.t_batch_pix = int(float(os.environ.get("GVFI_T_BATCH_PIX", "4.1e6")))
         # softmax splat as a deterministic gather over per-cell source lists (csrc/gimm_ops.hip); 0 = the float-atomic scatter
         self.splat_gather = os.environ.get("GVFI_SPLAT_GATHER", "1") != "0"
-        # everything behind the encoders that does not depend on the flow -- BidirCorrBlock's volumes, the context projections and
-        # the t-independent up-sampling stacks of both decoders (HBM-bound full-resolution layers) -- as one more parallel launch
-        # sequence beside the update iterations (latency chains that leave the matrix pipe 28 % busy, profiles/r4_wdir_pmc.json);
-        # 0 = after the recurrence, on the main stream.
-        # Built and A/B'd in round 4 (profiles/r4_side_lane_ab.txt: 347.6 vs 348.3 frames/s at 448x256, 111.8 vs 111.5 at 2K, 96.4 vs
-        # 97.1 at 4K -- nothing: the recurrence's workgroups already hold the CUs' LDS / wave slots), so it stays off
-        self.side_branch = os.environ.get("GVFI_SIDE_BRANCH", "0") != "0"
+        # (round 4 built a third launch lane beside the recurrence for everything behind the encoders that does not depend on the
+        # flow -- BidirCorrBlock's volumes, the context projections, the decoders' t-independent up-sampling stacks -- and measured
+        # it neutral: 347.6 vs 348.3 frames/s at 448x256, 111.8 vs 111.5 at 2K, 96.4 vs 97.1 at 4K, profiles/r4_side_lane_ab.txt;
+        # the switch also left side-stream allocations un-recorded on the main stream, so it is gone: that work
+        # runs after the recurrence on the main stream)
+        self._tb_mem = {}
         self.layers = {}
         self._build(sd)
 
@@ -290,8 +289,8 @@ class Engine:
         return torch.cat([torch.arange(B, device=device), torch.arange(1, B + 1, device=device)])
 
     def _raft(self, imgA, B, iters, taps, seq=False, side=None):
-        """side(fmap, cfeats): optional launch sequence that only needs the encoders' outputs; it runs as one more parallel
-        lane beside the update iterations (or after them when lanes are off)."""
+        """side(fmap, cfeats): the caller's launch sequence that only needs the encoders' outputs; it runs behind the update
+        iterations on the main stream."""
         rt, Ls = self.rt, self.layers
         n = 2 * B
         H, W = imgA.shape[1:3]
@@ -415,15 +414,11 @@ class Engine:
         # of the recurrence under-fills the chip (M = n*h8*w8 rows -> 224-448 workgroups with serial phases), so
         # independent sequences overlap each other's prologues, tails and epilogues.  Same arithmetic per image.
         k = 1 if taps is not None else max(1, min(self.raft_lanes, n))
-        ks = k + (1 if (side is not None and taps is None and self.side_branch) else 0)
-        with rt.lanes(ks) as lanes:
-            if ks > k:
-                with lanes[k]:
-                    side(fmap, cfeats)
+        with rt.lanes(k) as lanes:
             for i in range(k):
                 with lanes[i]:
                     chain(i * n // k, (i + 1) * n // k)
-        if side is not None and ks == k:
+        if side is not None:
             side(fmap, cfeats)
         rt.conv(Ls[u + ".mask.0"], hA, fh, act1=A.ACT_RELU)
         mask = rt.f32(n, h8, w8, 576)
@@ -603,8 +598,7 @@ class Engine:
         HW = H * W
 
         # ---- cal_bidirection_flow (gimmvfi_r.py:126-156)
-        # t-independent decoder front ends, hoisted out of the timestep loop -- and, where the flow estimator offers a parallel
-        # lane (`front`), out of the critical path altogether
+        # t-independent decoder front ends, hoisted out of the timestep loop
         pre = {}
 
         def front(feat4_, feat8_):
@@ -637,7 +631,7 @@ class Engine:
 
         out = {k: [] for k in ("imgt_pred", "other_pred", "flowt0_pred", "flowt1_pred", "ninrflow", "flowt")}
         T = len(t)
-        G = max(1, min(T, self.t_batch_pix // max(B * HW, 1)))      # timesteps per synthesis batch
+        G = self._timesteps_per_batch(T, B, HW, Hf * Wf)            # timesteps per synthesis batch
         for i0 in range(0, T, G):
             g = min(G, T - i0)
             flow_all = rt.f32(g * B, H, W, 2)                       # [t][b] order
@@ -673,11 +667,33 @@ class Engine:
         out["nflow"] = nflow
         return out
 
+    # activation bytes one timestep of a synthesis batch keeps alive, per pixel: ~6 KB at the working resolution (the 256-channel
+    # decoder stacks), and at the frame resolution cw 32 + cb 48 + o4 16 + mean4 16 + f01 / f11 48 + pred 12 + the output clones 60
+    _T_BYTES_WORK, _T_BYTES_FULL = 6144, 240
+
+    def _timesteps_per_batch(self, T, B, HW, HfWf):
+        """How many timesteps of a pair run through frame synthesis as one batch: GVFI_T_BATCH_PIX working pixels at most, and
+        at most what 60 % of the device memory that is free when the signature is first seen holds (a smaller or shared GPU
+        degrades to the per-timestep loop instead of running out of memory).  Cached per signature: the capture
+        pass of a hipGraph must take the same decision as its warm-up pass, and may not query the device."""
+        G = max(1, min(T, self.t_batch_pix // max(B * HW, 1)))
+        if G > 1 and self.rt.on_gpu:
+            key = (T, B, HW, HfWf)
+            lim = self._tb_mem.get(key)
+            if lim is None and not torch.cuda.is_current_stream_capturing():
+                free, _ = torch.cuda.mem_get_info(self.rt.device)
+                free += torch.cuda.memory_reserved(self.rt.device) - torch.cuda.memory_allocated(self.rt.device)
+                per_t = B * (HW * self._T_BYTES_WORK + HfWf * self._T_BYTES_FULL)
+                lim = self._tb_mem[key] = max(1, int(0.6 * free) // per_t)
+            if lim is not None:
+                G = min(G, lim)
+        return G
+
     def _flow(self, imgA, B, iters, taps, seq=False, front=None):
         """Bidirectional flow + what frame synthesis needs from the flow estimator (gimmvfi_r.py:126-141): flows
         [B,H,W,2] f32 of both directions, the two correlation pyramids of BidirCorrBlock, context features at 1/4
         (128 ch) and 1/8 (256 ch) for both frames.  front(feat4, feat8): the caller's flow-independent work on the context
-        features; with the projections and the volumes it forms the side lane of Engine._raft."""
+        features; with the projections and the volumes it is the `side` sequence of Engine._raft."""
         rt, Ls = self.rt, self.layers
         n = 2 * B
         H, W = imgA.shape[1:3]

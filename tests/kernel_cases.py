@@ -570,8 +570,9 @@ def col7_planar_case(rt, N=2, H=37, W=45, seed=8):
 def splat_gather_case(rt, B=2, H=12, W=20, converge=False):
     """The list-based gather form of the softmax splat (gvfi_softsplat_lists + gvfi_softsplat_gather): both directions in one
     launch, the same edge cases as splat_case, against the oracle; bit-identical over repeated runs (one writer per output,
-    fixed order of additions); converge: all sources of a 6 x 6 block land in ONE cell (lists longer than the register
-    array -> the repeated-selection branch)."""
+    fixed order of additions); converge: all sources of a 6 x 6 block (True) or of a converge x (converge + 2) block land in ONE
+    cell (lists longer than the register array -> the chunked-selection branch: 36 = 4 full walks + half a one; 9 x 11 = 99
+    sources = 12 walks + 3 sources)."""
     g = torch.Generator().manual_seed(15)
     dev = _dev(rt)
     C = 16
@@ -584,10 +585,12 @@ def splat_gather_case(rt, B=2, H=12, W=20, converge=False):
     t = torch.tensor([0.3, 0.75])[:B]
     if converge:
         ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-        for d in range(2):       # pixels (2..7, 3..8) of image 0 all move to (5.3, 6.6) at this direction's time scale
+        bh, bw = (6, 6) if converge is True else (int(converge), int(converge) + 2)
+        assert 2 + bh <= H and 3 + bw <= W
+        for d in range(2):       # pixels (2..2+bh-1, 3..3+bw-1) of image 0 all move to (5.3, 6.6) at this direction's time scale
             ts0 = float((1 - t[0]) if d else t[0])
-            flow[d][0, 0, 2:8, 3:9] = (6.6 - xs[2:8, 3:9]) / ts0
-            flow[d][0, 1, 2:8, 3:9] = (5.3 - ys[2:8, 3:9]) / ts0
+            flow[d][0, 0, 2:2 + bh, 3:3 + bw] = (6.6 - xs[2:2 + bh, 3:3 + bw]) / ts0
+            flow[d][0, 1, 2:2 + bh, 3:3 + bw] = (5.3 - ys[2:2 + bh, 3:3 + bw]) / ts0
     z = [torch.rand(B, 1, H, W, generator=g) + 0.5 for _ in range(2)]
     latcat = rt.act(B, H, W, 64, zero=True)
     for d in range(2):

@@ -98,8 +98,9 @@ def test_engine_f_sim_token_chains_equal_the_separate_launches(sd_f, monkeypatch
 
 
 def test_engine_f_sim_token_path_equals_the_four_launches(sd_f, monkeypatch):
-    """One launch per decoder iteration for the whole flow-token path (gvfi_token_path, default) against the four launches it
-    replaces (GVFI_F_TOKPATH=0: look-up | chain | attention | chain), same emulated engine, two iterations: bit-identical
+    """One launch per decoder iteration for the whole flow-token path (gvfi_token_path, GVFI_F_TOKPATH=1 -- OFF by default: measured
+    slower, profiles/r4_tokpath_ab_v2.txt) against the four launches it replaces (the default, GVFI_F_TOKPATH=0: look-up | chain |
+    attention | chain), same emulated engine, two iterations: bit-identical
     flows and frames."""
     import torch
 

@@ -250,6 +250,7 @@ def test_col7_folded_finalisation_equals_finalize_image(rt):
 def test_softsplat_gather_is_deterministic_and_matches_the_oracle(rt):
     kc.splat_gather_case(rt)
     kc.splat_gather_case(rt, converge=True)
+    kc.splat_gather_case(rt, converge=9)
     kc.splat_gather_case(rt, B=2, H=64, W=96)
 
 

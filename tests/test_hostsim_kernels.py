@@ -255,6 +255,7 @@ def test_col7_folded_finalisation_equals_finalize_image(rt):
 def test_softsplat_gather_is_deterministic_and_matches_the_oracle(rt):
     kc.splat_gather_case(rt)
     kc.splat_gather_case(rt, converge=True)
+    kc.splat_gather_case(rt, converge=9)
 
 
 def test_combine_warps_up_equals_separate_passes(rt):
