@@ -214,13 +214,18 @@ class Engine:
         rt, Ls = self.rt, self.layers
         n, H, W = x.shape[:3]
         inst = norm == "instance"
+        # the InstanceNorm statistics of all 15 normalised convolutions live in ONE zero-filled arena (one fill per encoder
+        # pass instead of one per layer): 64 + 4 x 64 + 5 x 96 + 5 x 128 = 1440 channels x (sum, sum of squares) per image
+        arena = rt.f32(n * 1440 * 2, zero=True) if inst else None
+        used = [0]
 
         def cn(name, src, h, w, cout, res=None, final_relu=True, first=True):
             # conv (+norm) + relu ; for the block's second conv: relu(res + relu(norm(conv)))
             lay = Ls[name]
             if inst:
                 raw = rt.act(n, h, w, cout)
-                stats = rt.f32(n, cout, 2, zero=True)
+                stats = arena[used[0]:used[0] + n * cout * 2].view(n, cout, 2)
+                used[0] += n * cout * 2
                 rt.conv(lay, src, raw, stats=stats)     # statistics fused into the convolution where possible
                 return rt.instnorm(raw, cout, relu=final_relu, res=res, stats=stats if rt.last_stats_fused else None).t
             out = rt.act(n, h, w, cout)
@@ -254,9 +259,13 @@ class Engine:
         rt = self.rt
         P8 = h8 * w8
         vol = rt.f32(n * P8, P8)
-        out = View(vol.view(n, h8, w8, P8))
-        rt.conv(None, fa, out, groups=n, w_group_stride=P8 * fb.shape[-1], w_raw=fb, cout=P8,
-                out_scale=1.0 / math.sqrt(256.0))
+        out = vol.view(n, h8, w8, P8)
+        # fb = one tensor of n partner maps, or a list of (first image, count, tensor) pieces: the bidirectional callers pair image
+        # i with image i +- B of the SAME tensor, which is two launches on its halves instead of a concatenated copy of it
+        pieces = fb if isinstance(fb, list) else [(0, n, fb)]
+        for i0, cnt, wt in pieces:
+            rt.conv(None, fa[i0:i0 + cnt], View(out[i0:i0 + cnt]), groups=cnt, w_group_stride=P8 * wt.shape[-1], w_raw=wt, cout=P8,
+                    out_scale=1.0 / math.sqrt(256.0))
         pyr = [vol]
         hh, ww = h8, w8
         for _ in range(3):
@@ -327,8 +336,7 @@ class Engine:
         rt.conv(Ls["cnet.out_inp"], c128, View(xbuf, 0, 128), act1=A.ACT_RELU)
         # correlation pyramids: direction 0->1 for images [0,B), 1->0 for [B,2B)
         # correlation pyramids of both directions in one grouped GEMM: image i against its partner (i +- B)
-        fswap = torch.cat([fmap[B:], fmap[:B]], 0)
-        pyr_ab = self._corr_pyramids(fmap, fswap, n, h8, w8)
+        pyr_ab = self._corr_pyramids(fmap, [(0, B, fmap[B:]), (B, B, fmap[:B])], n, h8, w8)
         pyr_a = [p[:B * h8 * w8] for p in pyr_ab]
         if taps is not None:
             taps["r01_fmap1"] = fmap[:B]
@@ -338,8 +346,8 @@ class Engine:
             taps["r01_corr_l3"] = pyr_a[3]
         coords = rt.coords_init(n, h8, w8)
         coords_alt = rt.f32(n, h8, w8, 2)
-        corrf = rt.act(n, h8, w8, 324, zero=True, pitch=rt.cp64(324), zero_pad_only=True)
-        flow8 = rt.act(n, h8, w8, 2, zero=True)
+        corrf = rt.act(n, h8, w8, 324, zero=True, pitch=rt.cp64(324), zero_pad_only=True, once="raft.corrf")
+        flow8 = rt.act(n, h8, w8, 2, zero=True, once="raft.flow8")
         c1 = rt.act(n, h8, w8, 256)
         corflo = rt.act(n, h8, w8, 256)
         f1 = rt.act(n, h8, w8, 128)
@@ -434,7 +442,7 @@ class Engine:
         rt.conv(Ls[p + ".convc1"], corr, c1, act1=A.ACT_LRELU)
         corflo = rt.act(B, h, w, 256)
         rt.conv(Ls[p + ".convc2"], c1, View(corflo, 0, 192), act1=A.ACT_LRELU)
-        flo = rt.act(B, h, w, 4, zero=True)
+        flo = rt.act(B, h, w, 4, zero=True, once=p + ".flo")
         rt.copy(View(flow4_f32, 0, 4), View(flo, 0, 4), 4)
         f1 = rt.act(B, h, w, 128)
         rt.patch_conv(Ls[p + ".convf1"], View(flo, 0, 4), f1, act1=A.ACT_LRELU)
@@ -532,7 +540,7 @@ class Engine:
         if self.inr_mlp is not None:
             rt.inr_mlp(self.inr_mlp, View(lat, 0, 32), cg, ninr)
         else:
-            xin = rt.act(B, Hc, Wc, 35, zero=True)
+            xin = rt.act(B, Hc, Wc, 35, zero=True, once="inr.xin")
             rt._chk(lib.inr_pack(lat.data_ptr(), lat.shape[-1], 32, cg.data_ptr(), xin.data_ptr(), xin.shape[-1],
                                  xin.shape[-1], B * Hc * Wc, rt.dtype, st()), "inr_pack")
             hcur = View(xin, 0, 35)
@@ -613,7 +621,7 @@ class Engine:
         h4, w4 = H // 4, W // 4
         scaler = rt.f32(B, zero=True)
         rt._chk(lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), B, HW, st()), "flow_absmax")
-        nfA = rt.act(n, H, W, 2, zero=True)
+        nfA = rt.act(n, H, W, 2, zero=True, once="nfA")
         nflow = rt.f32(B, 2, 2, H, W)
         rt._chk(lib.flow_normalize(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), nfA.data_ptr(), nfA.shape[-1],
                                    nfA.shape[-1], nflow.data_ptr(), B, H, W, rt.dtype, st()), "flow_normalize")
@@ -717,7 +725,7 @@ class Engine:
 
     def _bidir_pyramids(self, g, B, h8, w8):
         """BidirCorrBlock (raft/corr.py:23-45): volume + transposed volume, each with its pooled pyramid."""
-        pyr2 = self._corr_pyramids(g, torch.cat([g[B:], g[:B]], 0), 2 * B, h8, w8)
+        pyr2 = self._corr_pyramids(g, [(0, B, g[B:]), (B, B, g[:B])], 2 * B, h8, w8)
         pyr = [p[:B * h8 * w8] for p in pyr2]       # corr
         pyrT = [p[B * h8 * w8:] for p in pyr2]      # corr_T (raft/corr.py:32)
         return pyr, pyrT
@@ -765,11 +773,11 @@ class Engine:
         rt._chk(lib.flow_split_t(flow_t.data_ptr(), tv.data_ptr(), ft0.data_ptr(), ft1.data_ptr(), B, HW, st()),
                 "flow_split_t")
         # quarter-resolution flows  gimmvfi_r.py:242-244 ; fl4in = [F_t0/4, F_t1/4, 0..] doubles as the head residual
-        fl4in = rt.f32(B, h4, w4, 8, zero=True)
+        fl4in = rt.f32(B, h4, w4, 8, zero=True, once="synth.fl4in")
         rt.resize(ft0, 2, 0.25, mul=0.25, out=View(fl4in, 0, 2))
         rt.resize(ft1, 2, 0.25, mul=0.25, out=View(fl4in, 2, 2))
         # ---- NewInitDecoder  fi_components.py:255-276
-        f_in = rt.act(B, h4, w4, 272, zero=True, pitch=rt.cp64(272), zero_pad_only=True)
+        f_in = rt.act(B, h4, w4, 272, zero=True, pitch=rt.cp64(272), zero_pad_only=True, once="synth.f_in")
         rt.warp(up8[:sb], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
         rt.warp(up8[sb:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
         rt.copy(View(fl4in, 0, 4), View(f_in, 256, 4), 4)
@@ -782,7 +790,7 @@ class Engine:
         rt.conv(Ls[p + ".0.0"], f_in, x, act1=A.ACT_PRELU)
         for i in (1, 2, 3):
             x = self._resblock(f"{p}.{i}", x, 128)
-        st4 = rt.f32(B, h4, w4, 8, zero=True)    # [flowt0_4(2) flowt1_4(2) mask_4(1) pad]
+        st4 = rt.f32(B, h4, w4, 8, zero=True, once="synth.st4")    # [flowt0_4(2) flowt1_4(2) mask_4(1) pad]
         rt.conv(Ls["init.head5"], x, View(st4, 0, 5), res=View(fl4in, 0, 5))
         ft_4 = rt.act(B, h4, w4, 128)
         rt.conv(Ls["init.ft"], x, ft_4)
@@ -810,7 +818,7 @@ class Engine:
         c0, c1 = rt.f32(B, h8, w8, 2), rt.f32(B, h8, w8, 2)
         rt._chk(lib.lookup_coords(fl0.data_ptr(), fl1.data_ptr(), tv.data_ptr(), c0.data_ptr(), c1.data_ptr(), B, h8,
                                   w8, st()), "lookup_coords")
-        corr = rt.act(B, h8, w8, 648, zero=True, pitch=rt.cp64(648), zero_pad_only=True)
+        corr = rt.act(B, h8, w8, 648, zero=True, pitch=rt.cp64(648), zero_pad_only=True, once="synth.corr")
         rt.corr_lookup(pyr, c0, View(corr, 0, 324), B, h8, w8, h8, w8, src_n=0 if sb == B else sb)
         rt.corr_lookup(pyrT, c1, View(corr, 324, 324), B, h8, w8, h8, w8, src_n=0 if sb == B else sb)
         flow_lr = rt.f32(B, h8, w8, 4)
@@ -818,7 +826,7 @@ class Engine:
         rt.copy(fl1, View(flow_lr, 2, 2), 2)
         net_lr = rt.resize(ft_4, 128, 0.5).t
         self._amt_update("amt_update4_low", net_lr, flow_lr, corr, B, h8, w8, st4, ft_4, low=True)
-        corr_up = rt.act(B, h4, w4, 648, zero=True, pitch=rt.cp64(648), zero_pad_only=True)
+        corr_up = rt.act(B, h4, w4, 648, zero=True, pitch=rt.cp64(648), zero_pad_only=True, once="synth.corr_up")
         rt.resize(View(corr, 0, 648), 648, 2.0, out=View(corr_up, 0, 648))
         flow4 = rt.f32(B, h4, w4, 4)
         rt.copy(View(st4, 0, 4), flow4, 4)
@@ -829,7 +837,7 @@ class Engine:
         fl0u = rt.resize(View(st4, 0, 2), 2, 4.0, mul=4.0).t
         fl1u = rt.resize(View(st4, 2, 2), 2, 4.0, mul=4.0).t
         mku = rt.resize(mask_4, 1, 4.0).t
-        fin = rt.act(B, H, W, 273, zero=True, pitch=rt.cp64(273), zero_pad_only=True)
+        fin = rt.act(B, H, W, 273, zero=True, pitch=rt.cp64(273), zero_pad_only=True, once="synth.fin")
         rt.resize(ft_4, 128, 4.0, out=View(fin, 0, 128))
         rt.warp(up4[:sb], 64, fl0u, View(fin, 128, 64))
         rt.warp(up4[sb:], 64, fl1u, View(fin, 192, 64))
@@ -863,7 +871,7 @@ class Engine:
         rt._chk(lib.combine_warps_up(i0f.data_ptr(), i1f.data_ptr(), dec.data_ptr(), 24, H, W, cw.data_ptr(), cw.shape[-1],
                                      cw.shape[-1], mean4.data_ptr(), f01.data_ptr(), f11.data_ptr(), B, 0 if sb == B else sb, Hf, Wf,
                                      rt.dtype, st()), "combine_warps_up")
-        cb = rt.act(B, Hf, Wf, 18, zero=True)
+        cb = rt.act(B, Hf, Wf, 18, zero=True, once="synth.cb")
         # (pad16: cb's channels 18..23 and o4's / mean4's channel 3 are padding owned here -> whole 16-byte stores)
         rt.conv(Ls["amt_comb_block.0"], View(cw, 0, 9), View(cb, 0, 18), act1=A.ACT_PRELU, pad16=True, algo=rt.comb_algo)
         o4 = rt.f32(B, Hf, Wf, 4)

@@ -514,10 +514,11 @@ class EngineF(Engine):
         P8 = h8 * w8
         ctx_rows = context.view(n * P8, 256)
         # all-pairs cost volume of both directions (encoder.py:489-506; no 1/sqrt(d)): image i against its partner
-        fswap = torch.cat([fmap[B:], fmap[:B]], 0)
+        # (two launches on the halves of fmap instead of a swapped copy of it)
         vol = rt.f32(n * P8, P8)
-        rt.conv(None, fmap, View(vol.view(n, h8, w8, P8)), groups=n, w_group_stride=P8 * fmap.shape[-1], w_raw=fswap,
-                cout=P8)
+        vv = vol.view(n, h8, w8, P8)
+        for i0, wt in ((0, fmap[B:]), (B, fmap[:B])):
+            rt.conv(None, fmap[i0:i0 + B], View(vv[i0:i0 + B]), groups=B, w_group_stride=P8 * fmap.shape[-1], w_raw=wt, cout=P8)
         mem = self._cost_encoder(vol, ctx_rows, n, B, h8, w8, taps)
         if taps is not None:
             taps["f01_ffeat"] = fmap[:B]
@@ -567,13 +568,13 @@ class EngineF(Engine):
         kvm = tok._linear(ca + ".kv", mem_tok)                      # [n*K*P8, 128] = [key(64) | value(64)]
         coords = rt.coords_init(n, h8, w8)
         coords_alt = rt.f32(n, h8, w8, 2)
-        corr = rt.act(n, h8, w8, 145, zero=True, pitch=max(rt.cp64(145), 192))    # [cost_global(64) | cost_forward(81) | 0 ...]
+        corr = rt.act(n, h8, w8, 145, zero=True, pitch=max(rt.cp64(145), 192), once="ffdec.corr")    # [cost_global(64) | cost_forward(81) | 0 ...]
         # (mixed policy: the token path fills its own copy in its activation type, converted once per iteration)
-        corr_t = corr if tok is self else rtt.act(n, h8, w8, 145, zero=True, pitch=max(rtt.cp64(145), 192))
-        flow8 = rt.act(n, h8, w8, 2, zero=True)
+        corr_t = corr if tok is self else rtt.act(n, h8, w8, 145, zero=True, pitch=max(rtt.cp64(145), 192), once="ffdec.corr_t")
+        flow8 = rt.act(n, h8, w8, 2, zero=True, once="ffdec.flow8")
         X = rt.act(n, h8, w8, 256)          # [motion(126) flow(2) | aggregated motion(128)]   gru.py:150-152
         mfc = rt.act(n, h8, w8, 128)
-        vT = torch.zeros((n, 1, 128, P8p), dtype=rt.tdtype, device=rt.device)
+        vT = rt.act(n, 1, 128, P8, zero=True, pitch=P8p, once="ffdec.vT")      # (columns P8 .. P8p: K padding of the aggregation GEMM)
         c1 = rt.act(n, h8, w8, 256)
         corflo = rt.act(n, h8, w8, 256)
         f1 = rt.act(n, h8, w8, 128)

@@ -271,6 +271,8 @@ class Runtime:
         self.last_stats_fused = False
         self.last_planar = False
         self.fold_finalize = os.environ.get("GVFI_FOLD_FINALIZE", "1") != "0"   # A/B switch: finalize_image inside the last 7x7 layer
+        self.zero_once = os.environ.get("GVFI_ZERO_ONCE", "1") != "0"           # A/B switch: persistent zero-once buffers (act(once=...))
+        self._once = {}
 
     def sibling(self, precision):
         """A runtime of another precision over the same library and device (GIMM-VFI-F's float flow-estimator stages)."""
@@ -296,12 +298,21 @@ class Runtime:
         """Channel count padded to one K chunk of the LDS-DMA convolution (128 bytes: 64 bf16 / 32 f32)."""
         return roundup(c, 8 * self.VE)
 
-    def act(self, n, h, w, c, zero=None, pitch=None, zero_pad_only=False):
+    def act(self, n, h, w, c, zero=None, pitch=None, zero_pad_only=False, once=None):
         """Activation tensor in the runtime element type with padded channel pitch.  zero_pad_only: the caller
         writes every real channel [0, c) before the tensor is read, so only the pad channels are cleared (the 320-pitch
-        decoder input at full resolution is 587 MB per timestep -- clearing all of it was a 76 us memset)."""
+        decoder input at full resolution is 587 MB per timestep -- clearing all of it was a 76 us memset).
+        once: a call-site name -- the zero state is only ever needed ONCE (pad channels nobody writes, channels every forward
+        overwrites before reading): the tensor is then a persistent buffer of this runtime, zero-filled when it is first
+        created and handed out again for the same (name, shape) -- no fill kernel per forward (round 5: the 33 ATen fills /
+        copies of a captured forward were 0.2 ms of its 23 ms at 448x256, 0.9 ms at 4K).  Intermediates only: the next
+        forward overwrites them."""
         cpad = self.cp(c) if pitch is None else pitch
         z = (cpad != c) if zero is None else zero
+        if z and once is not None:
+            t = self._zero_once(once, (n, h, w, cpad), self.tdtype)
+            if t is not None:
+                return t
         if z and zero_pad_only and cpad > c:
             t = torch.empty((n, h, w, cpad), dtype=self.tdtype, device=self.device)
             t[..., c:].zero_()
@@ -309,8 +320,25 @@ class Runtime:
         f = torch.zeros if z else torch.empty
         return f((n, h, w, cpad), dtype=self.tdtype, device=self.device)
 
-    def f32(self, *shape, zero=False):
+    def f32(self, *shape, zero=False, once=None):
+        if zero and once is not None:
+            t = self._zero_once(once, tuple(shape), torch.float32)
+            if t is not None:
+                return t
         return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.device)
+
+    def _zero_once(self, name, shape, dtype):
+        """The persistent zero-initialised buffer (name, shape, dtype) of this runtime, or None when it cannot be created
+        right now (switch off; first seen inside a hipGraph capture -- the warm-up pass of a capture creates it before)."""
+        if not self.zero_once:
+            return None
+        key = (name, shape, dtype)
+        t = self._once.get(key)
+        if t is None:
+            if self.on_gpu and torch.cuda.is_current_stream_capturing():
+                return None
+            t = self._once[key] = torch.zeros(shape, dtype=dtype, device=self.device)
+        return t
 
     def _chk(self, rc, name):
         self.n_launch += 1

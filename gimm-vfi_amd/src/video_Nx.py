@@ -162,6 +162,9 @@ def main(argv=None):
     elif args.eval:
         raise ValueError("--load-path must be specified in evaluation or resume mode")
     model = model.to(device).eval()
+    # every output of a forward is turned into uint8 frames / flow pictures on the launch stream before the next forward is
+    # enqueued (frames_to_u8, compose_sbs, flow_to_image below), so the graph's own output tensors are used without clones
+    model.static_outputs = True
 
     img_list = sorted(os.listdir(args.source_path))
     num_pairs = len(img_list) - 1
