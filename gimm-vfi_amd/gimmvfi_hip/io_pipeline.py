@@ -234,17 +234,27 @@ class VideoSink:
     ``put`` blocks once workers + 32 frames are waiting (bounded memory) -- and ffmpeg, when present, encodes them at
     close.  ``total``: number of frames, known up front."""
 
+    @staticmethod
+    def uses_cv2(frame_hw, use_cv2=None):
+        """Whether a sink for frames of this size encodes through cv2.VideoWriter (needs the raw frames, in order) or writes
+        PNG files (independent, may arrive already encoded: put_png).  Same answer on every rank of a node: the multi-GPU
+        CLI picks its result path with it."""
+        try:
+            import cv2  # noqa: F401
+        except Exception:
+            return False
+        h, w = frame_hw
+        return max(h, w // 2) <= 2048 and use_cv2 is not False
+
     def __init__(self, path, fps, total, frame_hw, use_cv2=None, png_workers=None):
         import os
 
         self.path, self.fps, self.total = path, fps, total
-        try:
+        cv2 = None
+        if VideoSink.uses_cv2(frame_hw, use_cv2):
             import cv2
-        except Exception:
-            cv2 = None
         h, w = frame_hw
-        big = max(h, w // 2) > 2048
-        self.cv2 = cv2 if (cv2 is not None and not big and use_cv2 is not False) else None
+        self.cv2 = cv2
         self.written = 0
         self.err = None
         self._lock = threading.Condition()
@@ -274,6 +284,28 @@ class VideoSink:
             self.err = self.err or e
         finally:
             self.png_slots.release()
+
+    def _write_png(self, index, data):
+        import os
+
+        try:
+            with open(os.path.join(self.frame_dir, f"{index:04d}.png"), "wb") as f:
+                f.write(data)
+            with self._lock:
+                self.written += 1
+        except Exception as e:
+            self.err = self.err or e
+        finally:
+            self.png_slots.release()
+
+    def put_png(self, index, data):
+        """PNG sink only: a frame that arrives already encoded (the multi-GPU CLI: every rank encodes its own frames,
+        gimmvfi_hip/shard.py:BytesGather) -- this sink just writes the file."""
+        assert self.cv2 is None and 0 <= index < self.total
+        if self.err is not None:
+            raise self.err
+        self.png_slots.acquire()
+        self.png_pool.submit(self._write_png, index, bytes(data))
 
     def put(self, index, frame):
         assert 0 <= index < self.total
