@@ -146,8 +146,12 @@ def hot_kernel_clock(dev):
     x = torch.randn(N, H, W, C, device=dev).to(rt.tdtype)
     out = rt.act(N, H, W, C)
     st = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
-    for _ in range(3):
+    for _ in range(2):
         rt.conv(lay, View(x, 0, C), out, act1=L.ACT_RELU, algo=4)
+    for _ in range(2):      # (the PROF instantiation is a kernel of its own: its first launch pays the code load)
+        rt.conv(lay, View(x, 0, C), out, act1=L.ACT_RELU, algo=4 + 256 * 128, aux1=st)
+    torch.cuda.synchronize()
+    st.zero_()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

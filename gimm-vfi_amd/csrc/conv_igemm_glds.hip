@@ -60,16 +60,11 @@ struct ConvArgs2 {
 // LDS ring of the same depth costs 8 KB per stage.  The loads are ordinary loads (the compiler places their counted
 // s_waitcnt); the counted waits of the A pieces include them (every wave issues A_INSTR + NI*KK operations per chunk, in
 // that order, fenced by the asm statements around them).
+// The kernel body: workgroup `bid` (of the problem's own grid) and weight group `g` of problem `a`.  Two entry points call it:
+// conv_igemm_glds_kernel (one problem per launch) and conv_igemm_glds_pair_kernel (two independent problems of the same
+// variant in ONE launch, see below).
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE, int PPS = 1, bool BDIR = false>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
-#ifndef GVFI_HOSTSIM
-    // the 64 x 128 weights-direct tile is budgeted for three workgroups per CU (<= 168 registers per wave): the recurrence
-    // runs two independent launch sequences, and a free slot lets the other sequence's next kernel start its prologue
-    // under this one's K loop
-    __attribute__((amdgpu_waves_per_eu((GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 1,
-                                       (GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 8)))
-#endif
-    conv_igemm_glds_kernel(ConvArgs2 a) {
+__device__ __forceinline__ void conv_igemm_glds_body(const ConvArgs2& a, const int bid, const int g) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int VE = Elem<T>::VE;
     constexpr int RB = KB;                         // LDS row bytes = one K chunk of one tile row
@@ -109,12 +104,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
                  "s"(a.Ktot), "s"(a.howo_mul), "s"(a.howo_sh), "s"(a.wo_mul), "s"(a.wo_sh), "s"(p.bias), "s"(p.act1), "s"(p.act2),
                  "s"(p.slope1), "s"(p.slope2), "s"(p.epi_mode));
 #endif
-    // ---- XCD-aware tile order (blockIdx.x round-robins over the 8 XCDs)
-    const int bid = blockIdx.x;
+    // ---- XCD-aware tile order (the workgroup index round-robins over the 8 XCDs)
     const int v = (bid & 7) * a.per_xcd + (bid >> 3);
     if (v >= a.MT * a.NT) return;
     const int mt = v / a.NT, nt = v - mt * a.NT;
-    const int g = blockIdx.z;
 
     const int tid = threadIdx.x;
     // profiling only (algo bit 8+7): wave 0 of every workgroup stamps s_memtime at the phase boundaries into
@@ -957,6 +950,59 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
 #endif
 }
 
+#ifndef GVFI_HOSTSIM
+// the 64 x 128 weights-direct tile is budgeted for three workgroups per CU (<= 168 registers per wave) in the GVFI_WDIR_OCC3
+// build: the recurrence runs two independent launch sequences, and a free slot lets the other sequence's next kernel start
+// its prologue under this one's K loop
+#define GVFI_GLDS_KERNEL_ATTRS                                                                                        \
+    __attribute__((amdgpu_waves_per_eu((GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 1,                     \
+                                       (GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 8)))
+#else
+#define GVFI_GLDS_KERNEL_ATTRS
+#endif
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE, int PPS = 1, bool BDIR = false>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) GVFI_GLDS_KERNEL_ATTRS conv_igemm_glds_kernel(ConvArgs2 a) {
+    conv_igemm_glds_body<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE, PPS, BDIR>(a, (int)blockIdx.x, (int)blockIdx.z);
+}
+// Two INDEPENDENT convolutions in one launch (round 5): workgroups [0, grid_a) run problem a, the rest problem b.  For the
+// branches of the flow estimators' motion encoder (raft/update.py:94-112: convc1 || convf1, convc2 || convf2): the small
+// flow-branch layers (224 workgroups, a third of a CU slot each) ride in the shadow of the correlation-branch layers instead of
+// costing a launch of their own on the iteration's critical path.  Same body, same arithmetic: bit-identical to two launches.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE, int PPS = 1, bool BDIR = false>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) GVFI_GLDS_KERNEL_ATTRS conv_igemm_glds_pair_kernel(ConvArgs2 a, ConvArgs2 b) {
+    const int ga = a.per_xcd * 8;           // (a multiple of 8: the XCD round-robin phase of problem b's workgroups is kept)
+    const int bx = (int)blockIdx.x;
+    if (bx < ga) conv_igemm_glds_body<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE, PPS, BDIR>(a, bx, 0);
+    else conv_igemm_glds_body<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE, PPS, BDIR>(b, bx - ga, 0);
+}
+
+template <int BM, int BN>
+static void fill_args(const gvfi_conv_params& p, ConvArgs2& a, int bke) {
+    a.p = p;
+    a.chunks0 = p.c0 / bke;
+    a.chunks_tap = (p.c0 + p.c1) / bke;
+    a.KT = p.KH * p.KW * a.chunks_tap;
+    a.Ktot = (long long)p.KH * p.KW * (p.c0 + p.c1);
+    const int groups = p.groups > 0 ? p.groups : 1;
+    a.Mg = (int)(((long long)p.N * p.Ho * p.Wo) / groups);
+    a.MT = cdiv(a.Mg, BM);
+    a.NT = cdiv(p.Cout, BN);
+    a.per_xcd = cdiv((long long)a.MT * a.NT, 8);
+    gvfi_magic_div((unsigned)(p.Ho * p.Wo), a.howo_mul, a.howo_sh);
+    gvfi_magic_div((unsigned)p.Wo, a.wo_mul, a.wo_sh);
+    a.dbg = (p.algo >> 8) & 0xff;   // profiling switches: algo bits 8.. (8 = no epilogue, 16 = no K loop)
+}
+
+template <typename T>
+static int launch_glds_pair(const gvfi_conv_params& pa, const gvfi_conv_params& pb, hipStream_t stream) {
+    ConvArgs2 a, b;
+    fill_args<64, 128>(pa, a, 128 / (int)sizeof(T));
+    fill_args<64, 128>(pb, b, 128 / (int)sizeof(T));
+    dim3 grid((a.per_xcd + b.per_xcd) * 8, 1, 1);
+    GVFI_LAUNCH_COOP((conv_igemm_glds_pair_kernel<T, 64, 128, 1, 4, 128, 4, false, 1, true>), grid, dim3(256), stream, a, b);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB, int NSTAGE, bool PIPE = false, int PPS = 1, bool BDIR = false>
 static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     constexpr int BKE = KB / (int)sizeof(T);
@@ -1129,4 +1175,21 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     }
     GLDS_DISPATCH(bf16_t)
 #undef GLDS_DISPATCH
+}
+
+// Two independent convolutions as ONE launch (conv_igemm_glds_pair_kernel).  Both must be problems the weights-direct 64 x 128
+// variant takes (w_layout 2, the same 16-bit dtype, no weight groups, no statistics): 0 = launched; -2 = not such a pair (the
+// caller launches them one by one -- never a different arithmetic path, the pair kernel IS the same body).
+extern "C" int gvfi_conv2d_pair(const gvfi_conv_params* pa, const gvfi_conv_params* pb, void* stream) {
+    const gvfi_conv_params* ps[2] = {pa, pb};
+    int plan[5];
+    for (int i = 0; i < 2; ++i) {
+        const gvfi_conv_params& p = *ps[i];
+        if (p.w_layout != 2 || p.dtype != pa->dtype || p.dtype == GVFI_F32 || p.groups > 1 || p.stats != nullptr) return -2;
+        if (((p.algo & 15) != 2 && (p.algo & 15) != 0) || gvfi_conv2d_glds_plan(&p, plan) != 0) return -2;
+        if (plan[0] != 6 || plan[1] != 64 || plan[2] != 128) return -2;
+        if (((uintptr_t)p.x0 & 15) || ((uintptr_t)p.x1 & 15) || ((uintptr_t)p.w & 15)) return -3;
+    }
+    if (pa->dtype == GVFI_F16) return launch_glds_pair<f16_t>(*pa, *pb, (hipStream_t)stream);
+    return launch_glds_pair<bf16_t>(*pa, *pb, (hipStream_t)stream);
 }

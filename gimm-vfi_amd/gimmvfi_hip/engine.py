@@ -389,13 +389,19 @@ class Engine:
                 # (measured r2: running the flow branch of the motion encoder as a parallel graph branch is worth
                 # nothing -- the CUs already hold the 2 workgroups their LDS admits -- and forks nested inside lanes()
                 # crash hipStreamEndCapture on ROCm 7.0, so the branches are launched in sequence)
-                rt.conv(Ls[u + ".encoder.convc1"], cf, c1_, act1=A.ACT_RELU)
-                rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
                 if fused:
-                    rt.conv(patl.inner, fc, f1_, act1=A.ACT_RELU)
+                    # the two branches of the motion encoder (raft/update.py:94-112) meet only in `conv`: convc1 || convf1 and
+                    # convc2 || convf2 are one launch each (gvfi_conv2d_pair: the flow branch's 224 workgroups are the tail of
+                    # the correlation branch's grid instead of two more launches on the iteration's critical path)
+                    rt.conv_pair(dict(layer=Ls[u + ".encoder.convc1"], x0=cf, out=c1_, act1=A.ACT_RELU),
+                                 dict(layer=patl.inner, x0=fc, out=f1_, act1=A.ACT_RELU))
+                    rt.conv_pair(dict(layer=Ls[u + ".encoder.convc2"], x0=c1_, out=View(cfl, 0, 192), act1=A.ACT_RELU),
+                                 dict(layer=Ls[u + ".encoder.convf2"], x0=f1_, out=View(cfl, 192, 64), act1=A.ACT_RELU))
                 else:
+                    rt.conv(Ls[u + ".encoder.convc1"], cf, c1_, act1=A.ACT_RELU)
+                    rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
                     rt.patch_conv(patl, View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
-                rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
+                    rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.conv"], cfl, View(xb, 128, 126), act1=A.ACT_RELU)
                 hc, hn = ha, hb
                 sc, sn = h32

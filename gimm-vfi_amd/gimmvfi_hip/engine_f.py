@@ -650,13 +650,17 @@ class EngineF(Engine):
                 # GMAUpdateBlock   gru.py:130-160
                 if not fused:
                     rt.flow_pack(co, fl, View(Xs, 126, 2))
-                rt.conv(Ls[u + ".encoder.convc1"], cr, c1_, act1=A.ACT_RELU)
-                rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
                 if fused:
-                    rt.conv(patl.inner, fc, f1_, act1=A.ACT_RELU)
+                    # (as in Engine._raft: the motion encoder's two branches, gru.py:96-116, as one launch per level)
+                    rt.conv_pair(dict(layer=Ls[u + ".encoder.convc1"], x0=cr, out=c1_, act1=A.ACT_RELU),
+                                 dict(layer=patl.inner, x0=fc, out=f1_, act1=A.ACT_RELU))
+                    rt.conv_pair(dict(layer=Ls[u + ".encoder.convc2"], x0=c1_, out=View(cfl, 0, 192), act1=A.ACT_RELU),
+                                 dict(layer=Ls[u + ".encoder.convf2"], x0=f1_, out=View(cfl, 192, 64), act1=A.ACT_RELU))
                 else:
+                    rt.conv(Ls[u + ".encoder.convc1"], cr, c1_, act1=A.ACT_RELU)
+                    rt.conv(Ls[u + ".encoder.convc2"], c1_, View(cfl, 0, 192), act1=A.ACT_RELU)
                     rt.patch_conv(patl, View(fl, 0, 2), f1_, scratch=fc, act1=A.ACT_RELU)
-                rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
+                    rt.conv(Ls[u + ".encoder.convf2"], f1_, View(cfl, 192, 64), act1=A.ACT_RELU)
                 rt.conv(Ls[u + ".encoder.conv"], cfl, View(Xs, 0, 126), act1=A.ACT_RELU)
                 # global motion aggregation: X[128:256] = mf + gamma * attn @ (mf Wv^T)   gma.py:101-115
                 rt.copy(View(Xs, 0, 128), mf, 128)

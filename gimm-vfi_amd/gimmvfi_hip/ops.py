@@ -272,6 +272,7 @@ class Runtime:
         self.last_planar = False
         self.fold_finalize = os.environ.get("GVFI_FOLD_FINALIZE", "1") != "0"   # A/B switch: finalize_image inside the last 7x7 layer
         self.zero_once = os.environ.get("GVFI_ZERO_ONCE", "1") != "0"           # A/B switch: persistent zero-once buffers (act(once=...))
+        self.pair_launch = os.environ.get("GVFI_CONV_PAIR", "1") != "0"         # A/B switch: two independent convolutions per launch
         self._once = {}
 
     def sibling(self, precision):
@@ -348,8 +349,10 @@ class Runtime:
     # ------------------------------------------------------------------ convolution
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
-             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False, planar3=None):
-        """planar3: float (N, 3, Ho, Wo) tensor -- when the column kernel takes this launch (3 float output channels) the result
+             w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False, planar3=None,
+             _defer=False):
+        """_defer: build and route the problem but do not launch it; returns (params, flops, layer meta) for conv_pair.
+        planar3: float (N, 3, Ho, Wo) tensor -- when the column kernel takes this launch (3 float output channels) the result
         leaves finalised, clamp((y + 1) / 2, 0, 1), in planar form there and `out` is NOT written (gvfi_finalize_image folded
         in); ``self.last_planar`` says whether that happened (else the caller finalises `out` itself).
         state_f32 (GRU epilogues, bf16 mode): the recurrent state tensors are float (gvfi_conv_params.state_f32).
@@ -477,6 +480,9 @@ class Runtime:
             else:
                 p.stats = None
         self.last_algo = p.algo & 15         # (tests: which kernel family an explicit request really got)
+        if _defer:
+            cin_real = (layer.cin if layer is not None else x0.c)
+            return p, 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
         if self.ev_log is None:
             self._chk(self.lib.conv2d(C.byref(p), self.stream()), "conv2d")
         else:
@@ -497,6 +503,34 @@ class Runtime:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"
             self.ev_log.append((tag, flops, e0, e1))
         return out
+
+    def conv_pair(self, a, b):
+        """Two independent convolutions (keyword dicts of Runtime.conv) as ONE launch where the library takes the pair
+        (gvfi_conv2d_pair: both on the weights-direct 64 x 128 variant), else one after the other -- the same kernel body
+        either way, bit-identical results.  GVFI_CONV_PAIR=0: always one by one (A/B switch)."""
+        if not self.pair_launch:
+            self.conv(**a)
+            self.conv(**b)
+            return
+        pa, fa = Runtime.conv(self, **a, _defer=True)      # (Runtime.conv: a test runtime may override conv())
+        pb, fb = Runtime.conv(self, **b, _defer=True)
+        if self.ev_log is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = self.lib.conv2d_pair(C.byref(pa), C.byref(pb), self.stream())
+        if rc == -2:      # not a pair of that variant: two launches
+            self._chk(self.lib.conv2d(C.byref(pa), self.stream()), "conv2d")
+            self._chk(self.lib.conv2d(C.byref(pb), self.stream()), "conv2d")
+        else:
+            self._chk(rc, "conv2d_pair")
+        if self.ev_log is not None:
+            e1.record()
+            tag = f"conv_igemm_glds_kernel[wdir-pair]<{ {L.F32: 'float', L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },64,128,kb128,s4>"
+            if self.ev_shapes:
+                la, lb = a["layer"], b["layer"]
+                tag += f" {pa.N}x{pa.H}x{pa.W} {la.cin}->{pa.Cout} {pa.KH}x{pa.KW} || {lb.cin}->{pb.Cout} {pb.KH}x{pb.KW}"
+            self.ev_log.append((tag, fa + fb, e0, e1))
 
     # ------------------------------------------------------------------ thin wrappers
     def resize_planes(self, src, scale):

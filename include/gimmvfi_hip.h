@@ -130,6 +130,14 @@ int gvfi_conv2d_stats_ok(const gvfi_conv_params* p);
 /* the two kernels behind gvfi_conv2d (exposed for A/B measurements) */
 int gvfi_conv2d_glds_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_glds(const gvfi_conv_params* p, void* stream);
+/* Two INDEPENDENT convolutions as ONE launch (csrc/conv_igemm_glds.hip, conv_igemm_glds_pair_kernel): the two branches of the
+ * flow estimators' motion encoder -- convc1 || convf1 and convc2 || convf2 of BasicMotionEncoder (raft/update.py:94-112;
+ * FlowFormer gru.py:96-116) read different inputs and meet only in `conv`.  In the 20 / 32-iteration recurrences every launch is
+ * a latency chain of its own (prologue + K loop + epilogue of one workgroup), so the small flow-branch layers cost a launch
+ * each on the critical path; here their workgroups are the tail of the correlation-branch layer's grid.  Both problems must
+ * be ones the weights-direct 64 x 128 variant takes (w_layout 2, same 16-bit dtype, groups <= 1, no stats): 0 = launched,
+ * -2 = not such a pair (launch them one by one: the pair kernel runs the SAME body -- results are bit-identical). */
+int gvfi_conv2d_pair(const gvfi_conv_params* a, const gvfi_conv_params* b, void* stream);
 /* "Patch" convolution (csrc/conv_patch.hip) for few-channel layers at full resolution that the LDS-DMA kernel cannot
  * take: one source of <= 64 bf16 / 32 f32 channels (multiple of a 16-byte group), <= 64 output channels, filters up to
  * 7x7, stride 1 or 2, zero or reflect padding, standard epilogue -- the combination block of multi_flow_combine

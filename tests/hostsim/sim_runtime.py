@@ -67,6 +67,12 @@ class SimRuntime(Runtime):
     def sibling(self, precision):
         return SimRuntime(precision, self.emulate_conv)
 
+    def conv_pair(self, a, b):
+        if self.emulate_conv:
+            return super().conv_pair(a, b)
+        self.conv(**a)       # the torch statement of a launch has no notion of a shared grid
+        self.conv(**b)
+
     def conv(self, layer, x0, out, x1=None, act1=L.ACT_NONE, res=None, act2=L.ACT_NONE, out_scale=1.0,
              slope1=None, slope2=None, epi=L.EPI_STD, y2=None, aux0=None, aux1=None, groups=1,
              w_group_stride=0, w_raw=None, cout=None, tile=0, algo=0, stats=None, pad16=False, state_f32=False, planar3=None):

@@ -142,6 +142,44 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     return err
 
 
+def conv_pair_case(rt, N=1, H=9, W=12, shapes=((64, 256, 1, 1), (128, 128, 1, 1)), seed=0, expect_pair=True):
+    """gvfi_conv2d_pair (two independent weights-direct convolutions in one launch: the branches of the motion encoder,
+    raft/update.py:94-112) against the same two problems launched one by one: bit-identical outputs, nothing else written.
+    shapes: (Cin, Cout, KH, KW) of problem a / b.  expect_pair False: a pair the library declines (-2) -> the host falls back
+    to two launches, same results."""
+    g = torch.Generator().manual_seed(seed)
+    dev = _dev(rt)
+    probs = []
+    for Cin, Cout, KH, KW in shapes:
+        w = _rounded(rt, torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5)
+        lay = ConvLayer(rt, w, torch.randn(Cout, generator=g), wdir=expect_pair)
+        x = torch.randn(N, H, W, Cin, generator=g).to(rt.tdtype).to(dev)
+        probs.append((lay, x, Cout))
+    outs = {}
+    for mode in ("pair", "single"):
+        ys = [torch.full((N, H, W, c + 16), 3.0, dtype=rt.tdtype, device=dev) for _, _, c in probs]
+        kw = [dict(layer=lay, x0=View(x, 0, x.shape[-1]), out=View(y, 8, c), act1=L.ACT_RELU) for (lay, x, c), y in zip(probs, ys)]
+        if mode == "pair":
+            keep = rt.pair_launch
+            rt.pair_launch = True
+            n0 = rt.n_launch
+            rt.conv_pair(kw[0], kw[1])
+            launches = rt.n_launch - n0
+            rt.pair_launch = keep
+            assert launches == (1 if expect_pair else 2), launches
+        else:
+            rt.conv(**kw[0])
+            rt.conv(**kw[1])
+        outs[mode] = [y.float().cpu() for y in ys]
+    for a, b, (lay, x, c) in zip(outs["pair"], outs["single"], probs):
+        assert torch.equal(a, b)
+        assert float((a[..., :8] - 3.0).abs().max()) == 0.0 and float((a[..., 8 + c:] - 3.0).abs().max()) == 0.0
+        wt = lay.w.float().cpu()[..., :x.shape[-1]].permute(0, 3, 1, 2)
+        ref = F.relu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt, lay.b.cpu(), padding=(wt.shape[2] // 2, wt.shape[3] // 2)))
+        err = float((a[..., 8:8 + c].permute(0, 3, 1, 2) - ref).abs().max())
+        assert err <= tol(rt, float(ref.abs().max()) + 1.0), err
+
+
 def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, with_res=False, act2=L.ACT_NONE, out_scale=1.0, seed=0, variant=0, algo_new=4, ld_extra=8):
     """The halo-staged 3x3 kernel (conv_p3x3.hip, algo 4) walks K in the LDS-DMA kernel's order and shares its epilogue
     arithmetic: the two must agree bit for bit."""

@@ -170,6 +170,16 @@ def test_gru_epilogues(rt):
         kc.gru_case(rt, kh=1, kw=5, seed=8, state_f32=True)
 
 
+def test_conv_pair_launch_equals_two_launches(rt):
+    if rt.precision != "bf16":
+        pytest.skip("the pair launch exists for the 16-bit weights-direct variant")
+    kc.conv_pair_case(rt)
+    kc.conv_pair_case(rt, N=8, H=32, W=56, shapes=((384, 256, 1, 1), (128, 128, 1, 1)), seed=1)      # convc1 || convf1 of a RAFT lane
+    kc.conv_pair_case(rt, N=8, H=32, W=56, shapes=((256, 192, 3, 3), (128, 64, 3, 3)), seed=2)       # convc2 || convf2
+    kc.conv_pair_case(rt, N=1, H=68, W=128, shapes=((256, 192, 3, 3), (128, 64, 3, 3)), seed=3)      # one 2K / 4K lane
+    kc.conv_pair_case(rt, shapes=((32, 40, 1, 1), (64, 24, 3, 3)), seed=4, expect_pair=False)
+
+
 def test_corr_volume_grouped_gemm(rt):
     kc.corr_volume_case(rt)
     kc.corr_volume_case(rt, B=2, h=32, w=56, C=256, seed=3)

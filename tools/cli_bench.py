@@ -1,7 +1,9 @@
 """End-to-end throughput of the CLI (PNG decode -> pad -> H2D -> model -> D2H -> colour-coding), synthetic frames.
-usage: python tools/cli_bench.py [n_frames] [W] [H] [N] [DS_SCALE] [GPUS]
+usage: python tools/cli_bench.py [n_frames] [W] [H] [N] [DS_SCALE] [GPUS] [dry]
 With GPUS > 1 the CLI is started under torch.distributed.run on this node (one rank per GPU, free port), as
-scripts/video_Nx.sh does."""
+scripts/video_Nx.sh does.  `dry` (7th argument): GVFI_CLI_DRY=1 -- the multi-GPU result path rehearsed on ONE GPU: rank 0 is
+real, ranks 1.. are CPU stand-ins that decode, compose, ENCODE and gather like real ranks (gloo); prints every rank's host
+seconds (GVFI_CLI_TIMING).  Never a throughput figure of the model."""
 import os
 import subprocess
 import sys
@@ -22,6 +24,7 @@ def main():
     N = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     ds = sys.argv[5] if len(sys.argv) > 5 else "1.0"
     gpus = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    dry = len(sys.argv) > 7 and sys.argv[7] == "dry"
     from gimmvfi_hip.synth import synthetic_pairs
 
     with tempfile.TemporaryDirectory() as d:
@@ -37,7 +40,7 @@ def main():
 
             import torch
 
-            if torch.cuda.device_count() < gpus:
+            if torch.cuda.device_count() < gpus and not dry:
                 sys.exit(f"cli_bench: {gpus} GPUs requested, {torch.cuda.device_count()} visible")
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
@@ -47,10 +50,13 @@ def main():
         cmd = launcher + [os.path.join(ROOT, "gimm-vfi_amd", "src", "video_Nx.py"), "--source-path", src,
                "--output-path", out, "--N", str(N), "--ds-factor", ds, "-m",
                os.path.join(ROOT, "gimm-vfi_amd", "configs", "gimmvfi", "gimmvfi_r_arb.yaml"), "--random-init", "--eval"]
+        env = dict(os.environ)
+        if dry:
+            env.update(GVFI_CLI_DRY="1", GVFI_CLI_TIMING="1")
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
-        print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("[video_Nx]")), r.stderr[-300:] if r.returncode else "")
+        print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("[video_Nx]")), r.stderr[-1500:] if r.returncode else "")
         print(f"CLI: {n} frames {W}x{H}, {N}x, DS_SCALE {ds}, {gpus} GPU(s) -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
               f"(incl. process start, model build, graph capture, PNG/video writing)")
 

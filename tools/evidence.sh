@@ -12,6 +12,9 @@
 #   pmc-wdir         PMC passes of the weights-direct recurrence kernel (SQ x2 | TCC | TCP | FETCH_SIZE | WRITE_SIZE)
 #   hbm-<cfg>        HBM bytes per kernel (FETCH_SIZE / WRITE_SIZE passes over a bench run, joined with prof-<cfg>'s durations)
 #   cli-2k, cli-448  end-to-end CLI throughput incl. PNG decode and video writing (tools/cli_bench.py)
+#   cli-2k-dry8      the 8-rank CLI result path rehearsed on one GPU (rank 0 real, 7 CPU stand-in ranks; per-rank host seconds)
+#   ab-<ENVVAR>      same-box A/B of a 0/1 environment switch on the R and F 448x256 headlines (two repetitions each)
+#   fpolicy          GIMM-VFI-F precision policies of the flow estimator against the hardest reference fixture (tools/f_policy_diag.py)
 #   dry-<cfg>        bench.py --gpus 2 --dry: the sharded step's bookkeeping with real frame shapes on one GPU
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; shift; mkdir -p $O
@@ -52,7 +55,15 @@ for step in "$@"; do
       for ctr in FETCH_SIZE WRITE_SIZE; do rm -rf $O/hbm_$ctr; timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/hbm_$ctr -o run -- python bench.py --configs none --no-cpu-baseline --steps 3 --warmup 1 $(cfg_args $c) > $O/hbm_$ctr.log 2>&1; done
       python tools/pmc_table.py $O/kernel_stats_$c.md $O/hbm_table_$c.md $O/hbm_FETCH_SIZE $O/hbm_WRITE_SIZE > /dev/null; rm -rf $O/hbm_FETCH_SIZE $O/hbm_WRITE_SIZE; head -16 $O/hbm_table_$c.md | cut -c1-170;;
     cli-2k) GVFI_CLI_TIMING=1 timeout 300 python tools/cli_bench.py 33 2048 1088 8 0.5 > $O/cli_bench_2k.txt 2>&1; cut -c1-300 $O/cli_bench_2k.txt;;
+    cli-2k-dry8) timeout 400 python tools/cli_bench.py 65 2048 1088 8 0.5 8 dry > $O/cli_bench_2k_dry8.txt 2>&1; cut -c1-400 $O/cli_bench_2k_dry8.txt;;
     cli-448) timeout 200 python tools/cli_bench.py 65 448 256 2 > $O/cli_bench_448.txt 2>&1; grep -E "video_Nx|CLI:" $O/cli_bench_448.txt | cut -c1-300;;
+    ab-*)   # ab-<ENVVAR>: same-box A/B of a switch (0 / 1 / 0 / 1) on the R and F 448x256 headlines, graph replay only
+      v=${step#ab-}; : > $O/ab_$v.txt
+      for rep in 1 2; do for val in 0 1; do for mdl in r f; do
+        line=$(env $v=$val timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --model $mdl --details $O/ab_tmp.json 2>/dev/null | tail -1)
+        echo "$v=$val model=$mdl $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_$v.txt
+      done; done; done; cat $O/ab_$v.txt;;
+    fpolicy) timeout 600 python tools/f_policy_diag.py demo2k_ds050 "--policies=dec:f16;enc,dec:f16;cost,dec:f16;enc,cost,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy.txt 2>&1; cut -c1-260 $O/f_policy.txt | tail -8;;
     dry-*) c=${step#dry-}; timeout 400 python bench.py --gpus 2 --dry --steps 3 --warmup 1 $(cfg_args $c) > $O/dry_$c.json 2> $O/dry_$c.err; tail -1 $O/dry_$c.json | cut -c1-700;;
     *) echo "unknown step $step";;
   esac
