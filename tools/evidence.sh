@@ -63,6 +63,14 @@ for step in "$@"; do
         line=$(env $v=$val timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --model $mdl --details $O/ab_tmp.json 2>/dev/null | tail -1)
         echo "$v=$val model=$mdl $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_$v.txt
       done; done; done; cat $O/ab_$v.txt;;
+    fpolicy-all) timeout 900 python tools/f_policy_diag.py "--policies=dec:f16;enc:f16,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy_all.txt 2>&1; cut -c1-250 $O/f_policy_all.txt | tail -14;;
+    fpol-bench)   # speed of the candidate GIMM-VFI-F policies, graph replay, same box: 448x256 B=8 and 4K DS 0.25 8x
+      : > $O/fpol_bench.txt
+      for pol in "dec:f16" "enc:f16,dec:f16" "enc:f16,cost:f16,dec:f16" "dec:f16"; do
+        for cfg in f448 f4k; do
+          line=$(timeout 400 python bench.py --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --flow-precision "$pol" --details $O/ab_tmp.json 2>/dev/null | tail -1)
+          echo "$cfg $pol $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/fpol_bench.txt
+        done; done; cat $O/fpol_bench.txt;;
     fpolicy) timeout 600 python tools/f_policy_diag.py demo2k_ds050 "--policies=dec:f16;enc,dec:f16;cost,dec:f16;enc,cost,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy.txt 2>&1; cut -c1-260 $O/f_policy.txt | tail -8;;
     dry-*) c=${step#dry-}; timeout 400 python bench.py --gpus 2 --dry --steps 3 --warmup 1 $(cfg_args $c) > $O/dry_$c.json 2> $O/dry_$c.err; tail -1 $O/dry_$c.json | cut -c1-700;;
     *) echo "unknown step $step";;
