@@ -1,4 +1,5 @@
-// MFMA attention for the small-key-set attentions of FlowFormer's Twins / cost encoders (bf16, head dimension 16 or 32):
+// MFMA attention for the small-key-set attentions of FlowFormer's Twins / cost encoders (bf16 or -- round 5, the "enc:f16"
+// stage of GIMM-VFI-F's precision policy -- IEEE half operands: same layouts, the f16 MFMA; head dimension 16 or 32):
 //   * gvfi_attn_global_mfma: NQ queries against M <= 128 keys per group (globally sub-sampled attention twins.py:870-925,
 //     430-546: M = 112 at 448x256; any row layout gvfi_attn_global addresses);
 //   * gvfi_attn_window_mfma: the 7x7 locally grouped attention (twins.py:814-867, 331-427): 49 queries x 49 keys per window,
@@ -41,19 +42,19 @@ __device__ __forceinline__ uint4 at_zero4() {
     z.x = z.y = z.z = z.w = 0u;
     return z;
 }
-__device__ __forceinline__ uint4 at_pack8(const float* f) {
+template <typename T> __device__ __forceinline__ uint4 at_pack8(const float* f) {
     uint4 u;
-    u.x = pack_bf16x2(f[0], f[1]);
-    u.y = pack_bf16x2(f[2], f[3]);
-    u.z = pack_bf16x2(f[4], f[5]);
-    u.w = pack_bf16x2(f[6], f[7]);
+    u.x = pack16x2<T>(f[0], f[1]);
+    u.y = pack16x2<T>(f[2], f[3]);
+    u.z = pack16x2<T>(f[4], f[5]);
+    u.w = pack16x2<T>(f[6], f[7]);
     return u;
 }
 // key (within a block of 32) of accumulator register r in lane half h / of slot e of k-step t (16 keys) in lane half h
 __device__ __forceinline__ int at_key_of_reg(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // soft-max over the keys of one query block + P V; NKB key blocks of 32 (compile-time bound, nkb of them live)
-template <int HD, int NKB>
+template <typename T, int HD, int NKB>
 __device__ __forceinline__ void attn_block(const uint4 (&kf)[NKB][HD / 16], const uint4 (&vf)[2 * NKB], const uint4 (&qf)[HD / 16],
                                            int nkb, int M, int h, float scale_log2e, f32x16& o, float& inv_sum) {
     f32x16 s[NKB];
@@ -63,7 +64,7 @@ __device__ __forceinline__ void attn_block(const uint4 (&kf)[NKB][HD / 16], cons
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         if (kb < nkb) {
 #pragma unroll
-            for (int ks = 0; ks < HD / 16; ++ks) s[kb] = mfma_bf16_32x32x16(kf[kb][ks], qf[ks], s[kb]);
+            for (int ks = 0; ks < HD / 16; ++ks) Mma2<T>::run(s[kb], kf[kb][ks], qf[ks]);
         }
     }
     float m = -INFINITY;
@@ -96,23 +97,24 @@ __device__ __forceinline__ void attn_block(const uint4 (&kf)[NKB][HD / 16], cons
                 float pv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pv[e] = s[kb][8 * t + e];
-                o = mfma_bf16_32x32x16(vf[2 * kb + t], at_pack8(pv), o);
+                Mma2<T>::run(o, vf[2 * kb + t], at_pack8<T>(pv));
             }
         }
     }
 }
 // O^T registers of a lane (one query; head channels (r&3) + 8*(r>>2) + 4h) -> HD/8 stores of 4 channels
-template <int HD> __device__ __forceinline__ void attn_store(const f32x16& o, float inv_sum, bf16_t* op, int h) {
+template <typename T, int HD> __device__ __forceinline__ void attn_store(const f32x16& o, float inv_sum, bf16_t* op, int h) {
 #pragma unroll
     for (int g = 0; g < HD / 8; ++g) {
         uint2 u;
-        u.x = pack_bf16x2(o[4 * g + 0] * inv_sum, o[4 * g + 1] * inv_sum);
-        u.y = pack_bf16x2(o[4 * g + 2] * inv_sum, o[4 * g + 3] * inv_sum);
+        u.x = pack16x2<T>(o[4 * g + 0] * inv_sum, o[4 * g + 1] * inv_sum);
+        u.y = pack16x2<T>(o[4 * g + 2] * inv_sum, o[4 * g + 3] * inv_sum);
         *(uint2*)(op + 8 * g + 4 * h) = u;
     }
 }
 
-template <int HD> __global__ void __launch_bounds__(256) attn_global_mfma_kernel(AttnGArgs a) {
+// (T: the 16-bit operand type -- bf16_t or f16_t; the argument blocks carry raw 16-bit pointers either way)
+template <typename T, int HD> __global__ void __launch_bounds__(256) attn_global_mfma_kernel(AttnGArgs a) {
     constexpr int NKB = 4, KS = HD / 16;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -155,12 +157,12 @@ template <int HD> __global__ void __launch_bounds__(256) attn_global_mfma_kernel
         for (int ks = 0; ks < KS; ++ks) qf[ks] = valid ? *(const uint4*)(qp + ks * 16) : at_zero4();
         f32x16 o;
         float inv;
-        attn_block<HD, NKB>(kf, vf, qf, nkb, a.M, h, a.scale_log2e, o, inv);
-        if (valid) attn_store<HD>(o, inv, a.o + (g1 * a.ob1 + g0 * a.ob0 + (long long)i * a.os) * a.ldo + head * HD, h);
+        attn_block<T, HD, NKB>(kf, vf, qf, nkb, a.M, h, a.scale_log2e, o, inv);
+        if (valid) attn_store<T, HD>(o, inv, a.o + (g1 * a.ob1 + g0 * a.ob0 + (long long)i * a.os) * a.ldo + head * HD, h);
     }
 }
 
-template <int HD> __global__ void __launch_bounds__(256) attn_window_mfma_kernel(AttnWArgs a) {
+template <typename T, int HD> __global__ void __launch_bounds__(256) attn_window_mfma_kernel(AttnWArgs a) {
     constexpr int NKB = 2, KS = HD / 16, WS = 7, NK = WS * WS;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -193,7 +195,7 @@ template <int HD> __global__ void __launch_bounds__(256) attn_window_mfma_kernel
                 float f[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = a.kpad[pos * C + head * HD + ks * 16 + 8 * h + e];
-                kf[kb][ks] = at_pack8(f);
+                kf[kb][ks] = at_pack8<T>(f);
             }
         }
 #pragma unroll
@@ -205,10 +207,10 @@ template <int HD> __global__ void __launch_bounds__(256) attn_window_mfma_kernel
                 f[e] = 0.f;
                 if (vp < NK && c < HD) {
                     const long long vr = row_of(vp);
-                    f[e] = vr >= 0 ? bf2f(a.v[vr * a.ldv + head * HD + c]) : a.vpad[vp * C + head * HD + c];
+                    f[e] = vr >= 0 ? cvt16<T>(a.v[vr * a.ldv + head * HD + c]) : a.vpad[vp * C + head * HD + c];
                 }
             }
-            vf[2 * kb + t] = at_pack8(f);
+            vf[2 * kb + t] = at_pack8<T>(f);
         }
     }
 #pragma unroll
@@ -220,23 +222,23 @@ template <int HD> __global__ void __launch_bounds__(256) attn_window_mfma_kernel
         for (int ks = 0; ks < KS; ++ks) qf[ks] = qr >= 0 ? *(const uint4*)(a.q + qr * a.ldq + head * HD + ks * 16 + 8 * h) : at_zero4();
         f32x16 o;
         float inv;
-        attn_block<HD, NKB>(kf, vf, qf, NKB, NK, h, a.scale_log2e, o, inv);
-        if (qr >= 0) attn_store<HD>(o, inv, a.o + qr * a.ldo + head * HD, h);
+        attn_block<T, HD, NKB>(kf, vf, qf, NKB, NK, h, a.scale_log2e, o, inv);
+        if (qr >= 0) attn_store<T, HD>(o, inv, a.o + qr * a.ldo + head * HD, h);
     }
 }
 
-// 1 when gvfi_attn_global / gvfi_attn_window take the MFMA kernels for these arguments (bf16 only)
+// 1 when gvfi_attn_global / gvfi_attn_window take the MFMA kernels for these arguments (bf16 / IEEE half)
 extern "C" int gvfi_attn_mfma_ok(int window, int M, int NQ, int head_dim, int ws, int dtype) {
-    if (dtype != GVFI_BF16 || (head_dim != 16 && head_dim != 32)) return 0;
+    if ((dtype != GVFI_BF16 && dtype != GVFI_F16) || (head_dim != 16 && head_dim != 32)) return 0;
     if (window) return ws == 7;
     return M >= 9 && M <= 128 && NQ >= 16;
 }
 
-extern "C" int gvfi_attn_global_mfma(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
-                                     const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
-                                     long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
-                                     int head_dim, float scale, void* stream) {
-    if (!gvfi_attn_mfma_ok(0, M, NQ, head_dim, 0, GVFI_BF16) || G0 <= 0 || G1 <= 0) return -2;
+static int attn_global_mfma_t(int dtype, const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
+                              const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
+                              long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
+                              int head_dim, float scale, void* stream) {
+    if (!gvfi_attn_mfma_ok(0, M, NQ, head_dim, 0, dtype) || G0 <= 0 || G1 <= 0) return -2;
     if ((((uintptr_t)q | (uintptr_t)k) & 15) || (((uintptr_t)out) & 7) || (ldq % 8) || (ldk % 8) || (ldo % 4)) return -3;
     AttnGArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)out;
@@ -254,15 +256,34 @@ extern "C" int gvfi_attn_global_mfma(const void* q, int ldq, long long qb1, long
     a.nchunk = (nqb + a.qb_per_task - 1) / a.qb_per_task;
     const long long tasks = groups * a.nchunk;
     const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
-    if (head_dim == 16) { GVFI_LAUNCH_COOP(attn_global_mfma_kernel<16>, grid, block, (hipStream_t)stream, a); }
-    else { GVFI_LAUNCH_COOP(attn_global_mfma_kernel<32>, grid, block, (hipStream_t)stream, a); }
+    if (dtype == GVFI_F16) {
+        if (head_dim == 16) { GVFI_LAUNCH_COOP((attn_global_mfma_kernel<f16_t, 16>), grid, block, (hipStream_t)stream, a); }
+        else { GVFI_LAUNCH_COOP((attn_global_mfma_kernel<f16_t, 32>), grid, block, (hipStream_t)stream, a); }
+    } else {
+        if (head_dim == 16) { GVFI_LAUNCH_COOP((attn_global_mfma_kernel<bf16_t, 16>), grid, block, (hipStream_t)stream, a); }
+        else { GVFI_LAUNCH_COOP((attn_global_mfma_kernel<bf16_t, 32>), grid, block, (hipStream_t)stream, a); }
+    }
     return (int)hipGetLastError();
 }
-
-extern "C" int gvfi_attn_window_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
-                                     const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
+extern "C" int gvfi_attn_global_mfma(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
+                                     const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
+                                     long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
                                      int head_dim, float scale, void* stream) {
-    if (!gvfi_attn_mfma_ok(1, 49, 49, head_dim, ws, GVFI_BF16)) return -2;
+    return attn_global_mfma_t(GVFI_BF16, q, ldq, qb1, qb0, qs, k, ldk, v, ldv, kb1, kb0, ks, out, ldo, ob1, ob0, os, G1, G0, NQ, M, heads,
+                              head_dim, scale, stream);
+}
+extern "C" int gvfi_attn_global_mfma_f16(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
+                                         const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
+                                         long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
+                                         int head_dim, float scale, void* stream) {
+    return attn_global_mfma_t(GVFI_F16, q, ldq, qb1, qb0, qs, k, ldk, v, ldv, kb1, kb0, ks, out, ldo, ob1, ob0, os, G1, G0, NQ, M, heads,
+                              head_dim, scale, stream);
+}
+
+static int attn_window_mfma_t(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
+                              const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
+                              int head_dim, float scale, void* stream) {
+    if (!gvfi_attn_mfma_ok(1, 49, 49, head_dim, ws, dtype)) return -2;
     if ((((uintptr_t)q | (uintptr_t)k) & 15) || (((uintptr_t)out) & 7) || (ldq % 8) || (ldk % 8) || (ldo % 4)) return -3;
     AttnWArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kpad = kpad; a.vpad = vpad; a.o = (bf16_t*)out;
@@ -271,7 +292,22 @@ extern "C" int gvfi_attn_window_mfma(const void* q, int ldq, const void* k, int 
     a.scale_log2e = scale * 1.44269504088896341f;
     const long long tasks = (long long)n_img * a.nwx * a.nwy * heads;
     const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
-    if (head_dim == 16) { GVFI_LAUNCH_COOP(attn_window_mfma_kernel<16>, grid, block, (hipStream_t)stream, a); }
-    else { GVFI_LAUNCH_COOP(attn_window_mfma_kernel<32>, grid, block, (hipStream_t)stream, a); }
+    if (dtype == GVFI_F16) {
+        if (head_dim == 16) { GVFI_LAUNCH_COOP((attn_window_mfma_kernel<f16_t, 16>), grid, block, (hipStream_t)stream, a); }
+        else { GVFI_LAUNCH_COOP((attn_window_mfma_kernel<f16_t, 32>), grid, block, (hipStream_t)stream, a); }
+    } else {
+        if (head_dim == 16) { GVFI_LAUNCH_COOP((attn_window_mfma_kernel<bf16_t, 16>), grid, block, (hipStream_t)stream, a); }
+        else { GVFI_LAUNCH_COOP((attn_window_mfma_kernel<bf16_t, 32>), grid, block, (hipStream_t)stream, a); }
+    }
     return (int)hipGetLastError();
+}
+extern "C" int gvfi_attn_window_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
+                                     const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
+                                     int head_dim, float scale, void* stream) {
+    return attn_window_mfma_t(GVFI_BF16, q, ldq, k, ldk, v, ldv, kpad, vpad, out, ldo, n_img, H, W, ws, heads, head_dim, scale, stream);
+}
+extern "C" int gvfi_attn_window_mfma_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
+                                         const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
+                                         int head_dim, float scale, void* stream) {
+    return attn_window_mfma_t(GVFI_F16, q, ldq, k, ldk, v, ldv, kpad, vpad, out, ldo, n_img, H, W, ws, heads, head_dim, scale, stream);
 }

@@ -1082,8 +1082,10 @@ extern "C" int gvfi_conv2d_glds_plan(const gvfi_conv_params* pp, int* plan) {
     }
     int tile = p.tile_hint & 1023, bm = (p.tile_hint >> 10) & 1023;
     const int ns_hint = (p.tile_hint >> 20) & 15;   // ring depth override (0 = auto), 128-byte chunks only
-    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256 && p.dtype != GVFI_F16) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
-    if (p.dtype == GVFI_F16 && tile >= 256) tile = 128;
+    if (tile == 0) tile = (p.Cout >= 192 && M >= 256 * 256) ? 256 : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
+    // (IEEE half: the 8-wave tile is instantiated for 128-byte chunks of the chunk-major weight image only -- round 5, the many-row
+    // linears of GIMM-VFI-F's Twins encoders under the "enc:f16" policy)
+    if (p.dtype == GVFI_F16 && tile >= 256 && (p.w_layout == 0 || kb != 128 || (p.algo & 128))) tile = 128;
     tile = tile >= 256 ? 256 : (tile >= 128 ? 128 : (tile >= 64 ? 64 : 32));
     int k = 64, ns = 2;
     if (tile == 256) k = p.w_layout == 0 ? 64 : 128;
@@ -1165,7 +1167,8 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
     if (p.dtype == GVFI_F16) {
         // IEEE-half operands: the tiles of the flow estimators' recurrence (small M); everything else of that size takes the
         // 128-wide 4-wave tiles
-        if (tile == 256 || k != 128) return -7;
+        if (k != 128) return -7;
+        if (tile == 256) return launch_glds<f16_t, 256, 256, 2, 4, 128, 2, true, 4>(p, st);
         if (tile == 128) {
             if (bm == 64) return launch_glds<f16_t, 64, 128, 2, 2, 128, 2>(p, st);
             return launch_glds<f16_t, 128, 128, 2, 2, 128, 2>(p, st);

@@ -419,9 +419,10 @@ __global__ void attn_window_kernel(const T* __restrict__ q, int ldq, const T* __
 extern "C" int gvfi_attn_window(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
                                 const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
                                 int head_dim, float scale, int dtype, void* stream) {
-    // bf16, head dimension 16 / 32, 7x7 windows: one wave per (window, head) on the matrix pipe (attn_mfma.hip)
+    // bf16 / IEEE half, head dimension 16 / 32, 7x7 windows: one wave per (window, head) on the matrix pipe (attn_mfma.hip)
     if (attn_mfma_enabled() && gvfi_attn_mfma_ok(1, ws * ws, ws * ws, head_dim, ws, dtype)) {
-        const int rc = gvfi_attn_window_mfma(q, ldq, k, ldk, v, ldv, kpad, vpad, out, ldo, n_img, H, W, ws, heads, head_dim, scale, stream);
+        const int rc = (dtype == GVFI_F16 ? gvfi_attn_window_mfma_f16 : gvfi_attn_window_mfma)(q, ldq, k, ldk, v, ldv, kpad, vpad, out, ldo, n_img,
+                                                                                               H, W, ws, heads, head_dim, scale, stream);
         if (rc != -3) return rc;      // (-3: a pointer / pitch the vector loads cannot take -> scalar kernel)
     }
     const long long total = (long long)n_img * H * W * heads;
@@ -470,8 +471,9 @@ extern "C" int gvfi_attn_global(const void* q, int ldq, long long qb1, long long
                                 int head_dim, float scale, int dtype, void* stream) {
     if (G0 <= 0 || NQ <= 0 || M <= 0) return -2;
     if (attn_mfma_enabled() && gvfi_attn_mfma_ok(0, M, NQ, head_dim, 0, dtype)) {
-        const int rc = gvfi_attn_global_mfma(q, ldq, qb1, qb0, qs, k, ldk, v, ldv, kb1, kb0, ks, out, ldo, ob1, ob0, os, G1, G0, NQ, M,
-                                             heads, head_dim, scale, stream);
+        const int rc = (dtype == GVFI_F16 ? gvfi_attn_global_mfma_f16 : gvfi_attn_global_mfma)(q, ldq, qb1, qb0, qs, k, ldk, v, ldv, kb1, kb0, ks, out,
+                                                                                               ldo, ob1, ob0, os, G1, G0, NQ, M, heads, head_dim, scale,
+                                                                                               stream);
         if (rc != -3) return rc;
     }
     const long long total = G1 * G0 * NQ * heads;

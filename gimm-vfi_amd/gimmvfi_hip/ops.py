@@ -274,6 +274,10 @@ class Runtime:
         self.zero_once = os.environ.get("GVFI_ZERO_ONCE", "1") != "0"           # A/B switch: persistent zero-once buffers (act(once=...))
         self.pair_launch = os.environ.get("GVFI_CONV_PAIR", "1") != "0"         # A/B switch: two independent convolutions per launch
         self._once = {}
+        # PROFILING ONLY (results are garbage): the kernel's phase-skip switches on every weights-direct launch of the recurrences --
+        # 8 = no epilogue, 16 = no K loop, 24 = neither: how much of the recurrence's wall time is the fixed per-launch cost
+        # (launch + prologue [+ epilogue]) and how much the contraction (tools/evidence.sh wdir-floor, profiles/r5_wdir_floor.txt)
+        self.wdir_dbg = int(os.environ.get("GVFI_WDIR_DBG", "0")) & 24
 
     def sibling(self, precision):
         """A runtime of another precision over the same library and device (GIMM-VFI-F's float flow-estimator stages)."""
@@ -387,7 +391,7 @@ class Runtime:
                 p.w, p.w_layout = layer.w.data_ptr(), 0
             elif want in (0, 6) and layer.w_frag is not None and layer.use_wdir and p.c0 % 64 == 0 and p.c1 % 64 == 0 and groups == 1:
                 p.w, p.w_layout = layer.w_frag.data_ptr(), 2      # weights-direct variant of the LDS-DMA kernel
-                algo = 2 | (algo & ~15)
+                algo = 2 | (algo & ~15) | (self.wdir_dbg << 8)
                 want = 2
             elif want in (0, 2, 4) and aligned and not (algo & 128):
                 p.w, p.w_layout = layer.w_glds.data_ptr(), 1

@@ -352,7 +352,7 @@ int gvfi_attn_global(const void* q, int ldq, long long qb1, long long qb0, long 
                      const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
                      long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
                      int head_dim, float scale, int dtype, void* stream);
-/* MFMA forms of the two attentions (csrc/attn_mfma.hip; bf16, head_dim 16 or 32): one wave per (group, head) keeps the key
+/* MFMA forms of the two attentions (csrc/attn_mfma.hip; bf16 -- IEEE half: the _f16 entry points below --, head_dim 16 or 32): one wave per (group, head) keeps the key
  * fragments and the transposed value fragments in registers and walks blocks of 32 queries -- S^T = K Q^T, soft-max in
  * registers, O^T = V^T P^T, no LDS.  gvfi_attn_global (M in 9..128, NQ >= 16) and gvfi_attn_window (ws == 7) route here by
  * themselves when gvfi_attn_mfma_ok says 1 (environment GVFI_ATTN_MFMA=0 keeps the scalar kernels); -3 = a pointer or pitch
@@ -365,6 +365,17 @@ int gvfi_attn_global_mfma(const void* q, int ldq, long long qb1, long long qb0, 
 int gvfi_attn_window_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
                           const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
                           int head_dim, float scale, void* stream);
+/* the same two kernels on IEEE-half operands (v_mfma_f32_32x32x16_f16; q / k / v / out are GVFI_F16 tensors): the Twins encoders
+ * of GIMM-VFI-F when the precision policy runs the stage "enc" in half ("enc:f16", round 5: their bf16 operand rounding costs
+ * the two hardest reference fixtures 2 - 2.5 dB, profiles/r5_f_policy_enc_cost.txt).  gvfi_attn_global / gvfi_attn_window route
+ * here for dtype GVFI_F16. */
+int gvfi_attn_global_mfma_f16(const void* q, int ldq, long long qb1, long long qb0, long long qs, const void* k, int ldk,
+                              const void* v, int ldv, long long kb1, long long kb0, long long ks, void* out, int ldo,
+                              long long ob1, long long ob0, long long os, long long G1, int G0, int NQ, int M, int heads,
+                              int head_dim, float scale, void* stream);
+int gvfi_attn_window_mfma_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* kpad,
+                              const float* vpad, void* out, int ldo, int n_img, int H, int W, int ws, int heads,
+                              int head_dim, float scale, void* stream);
 /* out = [x | ctx[cimg(im)]] (+ positional code of the window position (enc_mode 1) or grid position (2)) for the
  * context-aware attention of the cost encoder (twins.py:366-395, 465-493); cimg reproduces the reference's
  * context.repeat() tiling over (batch, latent token): nb = pairs per direction, K = latent tokens */

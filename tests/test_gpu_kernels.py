@@ -294,6 +294,8 @@ F16_CONVS = [
     (1, 8, 10, 128, 130, 1, 5, dict(tile=128 | (64 << 10), split=64, act1=L.ACT_RELU)),
     (1, 9, 11, 128, 24, 3, 3, dict(out_f32=True)),
     (1, 9, 12, 64, 40, 3, 3, dict(act1=L.ACT_LRELU)),
+    (1, 1, 300, 128, 256, 1, 1, dict(act1=L.ACT_GELU, tile=256)),            # 8-wave 256 x 256 tile on half operands (round 5: "enc:f16")
+    (1, 9, 19, 64, 200, 3, 3, dict(tile=256, act1=L.ACT_PRELU, with_res=True, res_f32=True, coff=8)),
     (1, 8, 10, 128, 130, 1, 5, dict(algo=6, split=64, act1=L.ACT_RELU)),
     (1, 6, 20, 128, 96, 1, 1, dict(algo=6, act1=L.ACT_GELU)),
     (1, 7, 9, 64, 200, 1, 5, dict(algo=6, tile=256, act1=L.ACT_RELU)),

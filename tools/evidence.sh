@@ -63,6 +63,12 @@ for step in "$@"; do
         line=$(env $v=$val timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --model $mdl --details $O/ab_tmp.json 2>/dev/null | tail -1)
         echo "$v=$val model=$mdl $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_$v.txt
       done; done; done; cat $O/ab_$v.txt;;
+    wdir-floor)   # what bounds the recurrence: the same graph with the weights-direct launches' K loop / epilogue skipped (garbage results)
+      : > $O/wdir_floor.txt
+      for dbg in 0 16 8 24 0; do for lanes in 2 1; do
+        line=$(GVFI_WDIR_DBG=$dbg GVFI_RAFT_LANES=$lanes timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --details $O/ab_tmp.json 2>/dev/null | tail -1)
+        echo "GVFI_WDIR_DBG=$dbg lanes=$lanes $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/wdir_floor.txt
+      done; done; cat $O/wdir_floor.txt;;
     fpolicy-all) timeout 900 python tools/f_policy_diag.py "--policies=dec:f16;enc:f16,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy_all.txt 2>&1; cut -c1-250 $O/f_policy_all.txt | tail -14;;
     fpol-bench)   # speed of the candidate GIMM-VFI-F policies, graph replay, same box: 448x256 B=8 and 4K DS 0.25 8x
       : > $O/fpol_bench.txt
