@@ -202,7 +202,7 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
     model = model.to(dev).eval()
     # the step converts the frames to uint8 on the launch stream right behind the forward, before the next one is enqueued: the
     # graph's own output tensors are read in place (GIMMVFI_R.static_outputs), no defensive clones of the whole return dict
-    model.static_outputs = True
+    model.static_outputs = os.environ.get("GIMMVFI_STATIC_OUTPUTS", "1") != "0"       # (=0: A/B switch, tools/evidence.sh ab-host)
     x = synthetic_pairs(B, H, W, seed=100 + rank).to(dev)
     # src/video_Nx.py:164-181: one coordinate grid / timestep per inserted frame, flow at ds x resolution
     coords = [(model.sample_coord_input(B, (H, W), [i / NI], device=dev, upsample_ratio=c["ds"]), None) for i in range(1, NI)]
@@ -322,7 +322,7 @@ def main():
                     help="r = GIMM-VFI-R (RAFT flow estimator, BASELINE.json configs[1], the default bench line); "
                          "f = GIMM-VFI-F (FlowFormer flow estimator, configs[3])")
     ap.add_argument("--flow-precision", default=None,
-                    help="(--model f) precision policy of the flow estimator: 'dec:f16' (model default: decoder with IEEE-half operands, "
+                    help="(--model f) precision policy of the flow estimator: 'f16' (model default: the flow estimator on IEEE-half operands, "
                          ">= 40 dB against the reference everywhere), 'bf16', 'dec' (float decoder), 'fp32', or a stage list -- "
                          "GIMMVFI_F.__init__")
     ap.add_argument("--configs", default="auto", choices=["auto", "all", "none"],

@@ -46,12 +46,15 @@ def parse_flow_policy(spec):
     """flow_precision -> {stage: "fp32" | "fp16"} for the stages that leave bf16.  Stages: enc (Twins encoders + channel
     convertor), cost (cost volume + latent cost encoder), and of the 32-iteration decoder tok (flow token: 81-tap cost
     look-up, token encoder, cross-attention against the cost memory -> cost_global) and upd (GMA update block: motion
-    encoder, aggregation, ConvGRU, flow head); dec = tok + upd.  Grammar: "bf16" (none), "fp32" (all four in float), or a
-    comma list of stage[:type] with type f16 (IEEE half operands, bf16 speed) or fp32 (default), e.g. "dec:f16"."""
+    encoder, aggregation, ConvGRU, flow head); dec = tok + upd.  Grammar: "bf16" (none), "fp32" (all four in float), "f16"
+    (all four on IEEE-half operands: the model default since round 5), or a comma list of stage[:type] with type f16 (IEEE
+    half operands, bf16 speed) or fp32 (default), e.g. "dec:f16"."""
     if spec in (None, "", "bf16"):
         return {}
     if spec == "fp32":
         return {st: "fp32" for st in FLOW_STAGES}
+    if spec in ("f16", "fp16"):
+        return {st: "fp16" for st in FLOW_STAGES}
     pol = {}
     for item in (y.strip() for y in spec.split(",")):
         if not item:

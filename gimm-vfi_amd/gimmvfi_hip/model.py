@@ -275,14 +275,16 @@ class GIMMVFI_F(GIMMVFI_R):
         encoder), tok / upd (flow-token path / GMA update block of the 32-iteration decoder; dec = both); type f16 = IEEE
         half operands (same MFMA rate as bf16, 11 instead of 8 significand bits) or fp32 (exact-f32 MFMA, the default
         type); "fp32" alone = all stages in float, "bf16" = none.  Default: config.flow_precision,
-        $GIMMVFI_F_FLOW_PRECISION, else "dec:f16".  Measured against the reference's own outputs
-        (profiles/r3_f_policy.md): the update block is the one stage whose bf16 operand rounding shows in the frames when
-        the flows are large -- all-bf16 32.3-39.8 dB at 2K / 4K with 40-50 px flows (>= 52 dB once the flows stay below
-        10 px), "dec:f16" 41.4-50.7 dB at the same speed (177.9 vs 179.7 frames/s at 448x256, B = 8), "dec" (float)
-        42.9-51.9 dB at half the speed (90 frames/s).  DESIGN.md section 9."""
+        $GIMMVFI_F_FLOW_PRECISION, else "f16" (= "enc:f16,cost:f16,dec:f16": the whole flow estimator on IEEE-half operands).
+        Measured against the reference's own outputs (profiles/r3_f_policy.md, r5_f_policy_enc_cost.txt, r5_f_policy_all.txt):
+        the update block is the stage whose bf16 operand rounding moves the flow by pixels when the flows are large -- all-bf16
+        32.3-39.8 dB at 2K / 4K with 40-50 px flows (>= 52 dB once the flows stay below 10 px), "dec:f16" 41.6-50.4 dB at the
+        same speed; the Twins encoders' rounding costs the two hardest fixtures another 2 - 2.7 dB: "f16" 43.7-53.0 dB at
+        -1.2 % (448x256, B = 8) / -0.3 % (4K) once the MFMA attentions and the 8-wave tile run on half operands (round 5);
+        "dec" (float decoder) 42.9-51.9 dB at half the speed, "fp32" 46.2 dB on the hardest fixture.  DESIGN.md section 9."""
         super().__init__(config, precision)
         cfg_fp = _cfg_get(config, "flow_precision")
-        self.flow_precision = flow_precision or cfg_fp or os.environ.get("GIMMVFI_F_FLOW_PRECISION", "dec:f16")
+        self.flow_precision = flow_precision or cfg_fp or os.environ.get("GIMMVFI_F_FLOW_PRECISION", "f16")
 
     def _make_engine(self, runtime):
         return self._engine_cls(runtime, self.state_dict(), flow_precision=self.flow_precision)

@@ -131,6 +131,7 @@ def test_engine_f_sim_flow_precision_policy(sd_f):
 
     assert parse_flow_policy("bf16") == {} and parse_flow_policy("fp32") == {s: "fp32" for s in ("enc", "cost", "tok", "upd")}
     assert parse_flow_policy("cost, dec") == {"cost": "fp32", "tok": "fp32", "upd": "fp32"}
+    assert parse_flow_policy("f16") == {st: "fp16" for st in ("enc", "cost", "tok", "upd")}
     assert parse_flow_policy("dec:f16") == {"tok": "fp16", "upd": "fp16"} and parse_flow_policy("upd:f16,enc") == {"upd": "fp16", "enc": "fp32"}
     for bad in ("decoder", "dec:f8"):
         with pytest.raises(ValueError):
@@ -144,7 +145,7 @@ def test_engine_f_sim_flow_precision_policy(sd_f):
     # every stage-boundary conversion of the launch list: float encoder, the default (half decoder), a float token path feeding a
     # half update block (the single-stage policies "tok" / "upd" exercise the same conversions; they ran here until the CPU
     # suite needed trimming)
-    for pol in ("enc", "dec:f16", "upd:f16,tok"):
+    for pol in ("enc", "dec:f16", "upd:f16,tok", "f16"):        # ("f16": the model default since round 5)
         part = EngineF(SimRuntime("bf16"), sd_f, flow_precision=pol).forward(x, coords, ts, iters=None)
         assert psnr(part["imgt_pred"][0], gold["imgt_pred_0"]) > 40.0, pol
     # an fp32 engine ignores the policy (everything is float already)

@@ -69,6 +69,12 @@ for step in "$@"; do
         line=$(GVFI_WDIR_DBG=$dbg GVFI_RAFT_LANES=$lanes timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --details $O/ab_tmp.json 2>/dev/null | tail -1)
         echo "GVFI_WDIR_DBG=$dbg lanes=$lanes $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/wdir_floor.txt
       done; done; cat $O/wdir_floor.txt;;
+    ab-host)   # same-box A/B of the round-5 host-side changes (zero-once buffers + graph-static outputs) at 448x256 and 4K
+      : > $O/ab_host.txt
+      for rep in 1 2; do for val in 0 1; do for cfg in r448 r4k; do
+        line=$(GVFI_ZERO_ONCE=$val GIMMVFI_STATIC_OUTPUTS=$val timeout 400 python bench.py --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --details $O/ab_tmp.json 2>/dev/null | tail -1)
+        echo "zero_once=static_outputs=$val $cfg $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_host.txt
+      done; done; done; cat $O/ab_host.txt;;
     fpolicy-all) timeout 900 python tools/f_policy_diag.py "--policies=dec:f16;enc:f16,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy_all.txt 2>&1; cut -c1-250 $O/f_policy_all.txt | tail -14;;
     fpol-bench)   # speed of the candidate GIMM-VFI-F policies, graph replay, same box: 448x256 B=8 and 4K DS 0.25 8x
       : > $O/fpol_bench.txt

@@ -10,7 +10,7 @@ rows = [("R 448×256, 8 pairs, t = 0.5 (`configs[1]`, the driver's headline)", d
 r3 = {"configs[2]": "93.6", "configs[2]/[4] frame size: R at 4K DS 0.25": "82.4", "configs[3]": "183.4–190.7", "configs[4]": "58.0",
       "configs[1] in fp32 mode (the reference's own arithmetic)": "—"}
 names = {"configs[2]": "R 2K 2048×1088 DS 0.5, 8× (`configs[2]`, per GPU)", "configs[2]/[4] frame size: R at 4K DS 0.25": "R 4K 4096×2176 DS 0.25, 8×",
-         "configs[3]": "F 448×256, 8 pairs (`configs[3]`), default policy `dec:f16`", "configs[4]": "F 4K DS 0.25, 8× (`configs[4]`, per GPU)",
+         "configs[3]": "F 448×256, 8 pairs (`configs[3]`), default policy `f16`", "configs[4]": "F 4K DS 0.25, 8× (`configs[4]`, per GPU)",
          "configs[1] in fp32 mode (the reference's own arithmetic)": "R 448×256, 8 pairs, **fp32 mode** (exact-f32 MFMA: the reference's own arithmetic)"}
 for c in d.get("configs", []):
     rows.append((names[c["baseline_config"]], c["value"], c["ms_per_step"], c["roofline"], r3[c["baseline_config"]]))
