@@ -126,12 +126,25 @@ class ResultDrain:
         # image encoding: numpy / PIL release the GIL) runs in a small pool so that it keeps up with the GPU
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.pending = []
+        self._free = {}                      # (shape, dtype) -> recycled pinned host buffers
+        self._pool_lock = threading.Lock()
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
-    def submit(self, key, tensors, post):
+    def _pinned(self, t):
+        """A pinned host buffer for a copy of `t`: from the free list of recycled buffers of that shape, else a new one
+        (hipHostMalloc of a 100 MB buffer costs milliseconds of the submitting thread -- the CLI's main loop)."""
+        key = (tuple(t.shape), t.dtype)
+        with self._pool_lock:
+            lst = self._free.get(key)
+            if lst:
+                return lst.pop()
+        return torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+
+    def submit(self, key, tensors, post, recycle=False):
         """Returns the event that marks the end of the D2H copies (None on CPU): a caller that re-uses `tensors` as
-        staging buffers waits for it before overwriting them."""
+        staging buffers waits for it before overwriting them.  recycle: `post` is DONE with the host tensors when it returns
+        (it keeps no views of them) -- their pinned buffers go back to a free list for later submits."""
         self.slots.acquire()
         if self.err is None:
             # a post() that already failed (sink.put, an encoder) surfaces at the next submit, not only at finish(): the GPU
@@ -151,20 +164,25 @@ class ResultDrain:
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(done)
                 for t in tensors:
-                    h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+                    h = self._pinned(t) if recycle else torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
                     h.copy_(t, non_blocking=True)
                     hosts.append(h)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
-            self.q.put((key, hosts, ev, post, tensors))     # `tensors` kept alive until the copy has completed
+            self.q.put((key, hosts, ev, (post, recycle), tensors))     # `tensors` kept alive until the copy has completed
         else:
-            self.q.put((key, [t.clone() for t in tensors], None, post, None))
+            self.q.put((key, [t.clone() for t in tensors], None, (post, False), None))
         return ev
 
     def _post(self, post, hosts):
+        post, recycle = post
         try:
             return post(*hosts)
         finally:
+            if recycle:
+                with self._pool_lock:
+                    for h in hosts:
+                        self._free.setdefault((tuple(h.shape), h.dtype), []).append(h)
             self.slots.release()
 
     def _run(self):

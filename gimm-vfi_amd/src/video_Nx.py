@@ -232,9 +232,10 @@ def main(argv=None):
     # Result path of the multi-GPU run.  PNG sinks (no OpenCV, or frames beyond the mp4v writer): every rank ENCODES its own
     # frames on its own host threads and the collective moves the compressed bytes (shard.BytesGather) -- rank 0 only writes
     # files.  OpenCV sinks need the raw frames in order on rank 0: the raw uint8 gather (shard.RoundGather) stays.
-    encoded = world > 1 and not (VideoSink.uses_cv2((H0, 2 * W0)) or VideoSink.uses_cv2((H0, W0)))
+    # (one GPU takes the same encode path -- its sink then only writes files too, and the pinned D2H buffers are recycled)
+    encoded = not (VideoSink.uses_cv2((H0, 2 * W0)) or VideoSink.uses_cv2((H0, W0)))
     gatherer = shard.RoundGather(rank, world) if (world > 1 and not encoded) else None
-    bgather = shard.BytesGather(rank, world, xdev) if encoded else None
+    bgather = shard.BytesGather(rank, world, xdev) if (encoded and world > 1) else None
     LAG = 2           # rounds between a forward and the exchange of its encoded frames: the encode threads' head start
     from concurrent.futures import Future, ThreadPoolExecutor
     enc_pool = ThreadPoolExecutor(max_workers=max(2, min(32, ncpu // max(1, world)))) if encoded else None
@@ -246,7 +247,7 @@ def main(argv=None):
         sinks = (VideoSink(os.path.join(args.output_path, "output.mp4"), N * 2, num_pairs * N, (H0, 2 * W0)),
                  VideoSink(os.path.join(args.output_path, "flow.mp4"), N * 2, num_pairs * (N - 1), (H0, W0)))
 
-    prof = {"decode_wait": 0.0, "enqueue": 0.0, "submit": 0.0, "post": 0.0, "exchange": 0.0} if os.environ.get("GVFI_CLI_TIMING") else None
+    prof = {"decode_wait": 0.0, "forward": 0.0, "enqueue": 0.0, "submit": 0.0, "post": 0.0, "exchange": 0.0} if os.environ.get("GVFI_CLI_TIMING") else None
 
     def post(blocks):
         """blocks: [(first pair, pairs)] of the tensors handed to the drain, in order (one per contributing rank)."""
@@ -301,14 +302,22 @@ def main(argv=None):
 
     def deliver(kk, failed):
         """(encoded path) exchange of round kk's encoded frames; returns True when the run is to stop (some rank failed)."""
-        payload = None
+        payload, entries = None, None
         if not failed:
             try:
-                payload = shard.pack_entries(enc_futs[kk].result(timeout=600))
+                entries = enc_futs[kk].result(timeout=600)
+                if world > 1:
+                    payload = shard.pack_entries(entries)
             except BaseException as e:      # noqa: BLE001
                 failed = e
         if rank == 0 and not failed and sinks is not None:
             failed = sinks[0].err or sinks[1].err or False
+        if world == 1:          # one rank: its own encoded frames go straight to the sinks
+            if failed:
+                return failed
+            for kind, idx, data in entries:
+                sinks[0 if kind == "out" else 1].put_png(idx, data)
+            return False
         got, stop = bgather.exchange(payload, abort=bool(failed))
         if stop:
             return failed or True
@@ -352,6 +361,9 @@ def main(argv=None):
                                 [i * 1 / N * torch.ones(b, device=device, dtype=torch.float) for i in range(1, N)])
                         coord_inputs, timesteps = coord_cache[key]
                         out = model.forward_sequence(frames, coord_inputs, t=timesteps, ds_factor=None if ds_factor == 1.0 else ds_factor)
+                        if prof is not None:        # (host time of the graph launch: input copies + hipGraphLaunch)
+                            prof["forward"] += time.perf_counter() - tp
+                            tp = time.perf_counter()
                         preds = torch.stack([padder.unpad(out["imgt_pred"][i]) for i in range(N - 1)], 1)       # [b, N-1, 3, H, W]
                         pred_u8 = rt.frames_to_u8(preds.reshape(-1, *preds.shape[2:]).contiguous()).reshape(b, N - 1, H0, W0, 3)
                         # [orig | interp] video frames from the frames already resident (reference: a second decode + cv2.hconcat per frame)
@@ -377,7 +389,7 @@ def main(argv=None):
                 if failure is not None:
                     raise failure
                 if b > 0:
-                    drain.submit(k, [comp_u8, pics_u8], post_encode((j0, b), fut))
+                    drain.submit(k, [comp_u8, pics_u8], post_encode((j0, b), fut), recycle=True)
                 else:
                     fut.set_result([])
             except BaseException as e:      # noqa: BLE001
@@ -422,7 +434,7 @@ def main(argv=None):
             if b > 0:
                 drain.submit(k, [comp_u8, pics_u8], post([(j0, b)]))
         if prof is not None:
-            prof["exchange" if world > 1 else "submit"] += time.perf_counter() - tp
+            prof["exchange"] += time.perf_counter() - tp
     if world > 1 and not encoded and not stopped:
         # (raw path) a failure of the LAST round's gather / submit still has to reach the other ranks
         if shard.any_abort(failure is not None, xdev, world):
