@@ -145,7 +145,7 @@ def test_engine_f_sim_flow_precision_policy(sd_f):
     # every stage-boundary conversion of the launch list: float encoder, the default (half decoder), a float token path feeding a
     # half update block (the single-stage policies "tok" / "upd" exercise the same conversions; they ran here until the CPU
     # suite needed trimming)
-    for pol in ("enc", "dec:f16", "upd:f16,tok", "f16"):        # ("f16": the model default since round 5)
+    for pol in ("dec:f16", "upd:f16,tok", "f16"):        # ("f16": the model default since round 5; a float encoder is part of "fp32" above)
         part = EngineF(SimRuntime("bf16"), sd_f, flow_precision=pol).forward(x, coords, ts, iters=None)
         assert psnr(part["imgt_pred"][0], gold["imgt_pred_0"]) > 40.0, pol
     # an fp32 engine ignores the policy (everything is float already)

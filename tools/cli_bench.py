@@ -56,7 +56,11 @@ def main():
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
-        print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("[video_Nx]")), r.stderr[-1500:] if r.returncode else "")
+        print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("[video_Nx]")))
+        if r.returncode:       # the first traceback of the failing rank(s), not the launcher's summary at the end
+            err = r.stderr
+            i = err.find("Traceback")
+            print(f"CLI FAILED (exit code {r.returncode}):\n" + (err[i:i + 4000] if i >= 0 else err[-3000:]))
         print(f"CLI: {n} frames {W}x{H}, {N}x, DS_SCALE {ds}, {gpus} GPU(s) -> {(n - 1) * (N - 1)} interpolated frames in {dt:.2f} s wall "
               f"(incl. process start, model build, graph capture, PNG/video writing)")
 

@@ -57,6 +57,12 @@ for step in "$@"; do
     cli-2k) GVFI_CLI_TIMING=1 timeout 300 python tools/cli_bench.py 33 2048 1088 8 0.5 > $O/cli_bench_2k.txt 2>&1; cut -c1-300 $O/cli_bench_2k.txt;;
     cli-2k-dry8) timeout 400 python tools/cli_bench.py 65 2048 1088 8 0.5 8 dry > $O/cli_bench_2k_dry8.txt 2>&1; cut -c1-400 $O/cli_bench_2k_dry8.txt;;
     cli-448) timeout 200 python tools/cli_bench.py 65 448 256 2 > $O/cli_bench_448.txt 2>&1; grep -E "video_Nx|CLI:" $O/cli_bench_448.txt | cut -c1-300;;
+    ab-host)   # same-box A/B of the round-5 host-side changes (zero-once buffers + graph-static outputs) at 448x256 and 4K
+      : > $O/ab_host.txt
+      for rep in 1 2; do for val in 0 1; do for cfg in r448 r4k; do
+        line=$(GVFI_ZERO_ONCE=$val GIMMVFI_STATIC_OUTPUTS=$val timeout 400 python bench.py --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --details $O/ab_tmp.json 2>/dev/null | tail -1)
+        echo "zero_once=static_outputs=$val $cfg $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_host.txt
+      done; done; done; cat $O/ab_host.txt;;
     ab-*)   # ab-<ENVVAR>: same-box A/B of a switch (0 / 1 / 0 / 1) on the R and F 448x256 headlines, graph replay only
       v=${step#ab-}; : > $O/ab_$v.txt
       for rep in 1 2; do for val in 0 1; do for mdl in r f; do
@@ -69,12 +75,6 @@ for step in "$@"; do
         line=$(GVFI_WDIR_DBG=$dbg GVFI_RAFT_LANES=$lanes timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --details $O/ab_tmp.json 2>/dev/null | tail -1)
         echo "GVFI_WDIR_DBG=$dbg lanes=$lanes $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/wdir_floor.txt
       done; done; cat $O/wdir_floor.txt;;
-    ab-host)   # same-box A/B of the round-5 host-side changes (zero-once buffers + graph-static outputs) at 448x256 and 4K
-      : > $O/ab_host.txt
-      for rep in 1 2; do for val in 0 1; do for cfg in r448 r4k; do
-        line=$(GVFI_ZERO_ONCE=$val GIMMVFI_STATIC_OUTPUTS=$val timeout 400 python bench.py --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --details $O/ab_tmp.json 2>/dev/null | tail -1)
-        echo "zero_once=static_outputs=$val $cfg $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_host.txt
-      done; done; done; cat $O/ab_host.txt;;
     fpolicy-all) timeout 900 python tools/f_policy_diag.py "--policies=dec:f16;enc:f16,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy_all.txt 2>&1; cut -c1-250 $O/f_policy_all.txt | tail -14;;
     fpol-bench)   # speed of the candidate GIMM-VFI-F policies, graph replay, same box: 448x256 B=8 and 4K DS 0.25 8x
       : > $O/fpol_bench.txt
