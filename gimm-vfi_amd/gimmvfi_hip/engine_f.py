@@ -674,10 +674,13 @@ class EngineF(Engine):
                 hc, hn = ha, hb
                 sc, sn = h32
                 for nn_ in ("1", "2"):
-                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=Xs, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
-                            res=cx["gru.zr" + nn_], state_f32=sf)
-                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=Xs, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
-                            y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
+                    # (as in Engine._raft: one launch per half where the lines of the 1/8 grid fit a workgroup)
+                    if sf or not rt.gru_half(Ls["gru.zr" + nn_], Ls["gru.q" + nn_], hc, Xs, hn, ctx_zr=cx["gru.zr" + nn_],
+                                             ctx_q=cx["gru.q" + nn_], vertical=nn_ == "2"):
+                        rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=Xs, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
+                                res=cx["gru.zr" + nn_], state_f32=sf)
+                        rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=Xs, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
+                                y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
                     hc, hn = hn, hc
                     sc, sn = sn, sc
                 rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)

@@ -86,6 +86,22 @@ class TokenPathParams(C.Structure):
     ]
 
 
+class GruParams(C.Structure):
+    """Mirror of ``gvfi_gru_params`` (include/gimmvfi_hip.h)."""
+
+    _fields_ = [
+        ("dtype", C.c_int),
+        ("h", C.c_void_p), ("ldh", C.c_int),
+        ("x", C.c_void_p), ("ldx", C.c_int), ("cx", C.c_int),
+        ("wzr", C.c_void_p), ("wq", C.c_void_p),
+        ("bzr", C.c_void_p), ("bq", C.c_void_p),
+        ("ctx_zr", C.c_void_p), ("ld_czr", C.c_int),
+        ("ctx_q", C.c_void_p), ("ld_cq", C.c_int),
+        ("out", C.c_void_p), ("ldo", C.c_int),
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("vertical", C.c_int),
+    ]
+
+
 _CTYPES = {
     "int": C.c_int,
     "float": C.c_float,

@@ -273,6 +273,7 @@ class Runtime:
         self.fold_finalize = os.environ.get("GVFI_FOLD_FINALIZE", "1") != "0"   # A/B switch: finalize_image inside the last 7x7 layer
         self.zero_once = os.environ.get("GVFI_ZERO_ONCE", "1") != "0"           # A/B switch: persistent zero-once buffers (act(once=...))
         self.pair_launch = os.environ.get("GVFI_CONV_PAIR", "1") != "0"         # A/B switch: two independent convolutions per launch
+        self.gru_fused = os.environ.get("GVFI_GRU_FUSED", "1") != "0"           # A/B switch: SepConvGRU halves as one launch each
         self._once = {}
         # PROFILING ONLY (results are garbage): the kernel's phase-skip switches on every weights-direct launch of the recurrences --
         # 8 = no epilogue, 16 = no K loop, 24 = neither: how much of the recurrence's wall time is the fixed per-launch cost
@@ -535,6 +536,45 @@ class Runtime:
                 la, lb = a["layer"], b["layer"]
                 tag += f" {pa.N}x{pa.H}x{pa.W} {la.cin}->{pa.Cout} {pa.KH}x{pa.KW} || {lb.cin}->{pb.Cout} {pb.KH}x{pb.KW}"
             self.ev_log.append((tag, fa + fb, e0, e1))
+
+    def gru_half(self, lay_zr, lay_q, h, x, out, ctx_zr=None, ctx_q=None, vertical=False):
+        """One half of the SepConvGRU as ONE launch (gvfi_gru_half, csrc/gru_fused.hip) where the library takes the geometry;
+        returns False when it does not (the caller then runs the two gate convolutions).  h / out: Views of 128 channels, x: View
+        of 128 or 256 channels; lay_zr / lay_q: the wdir-packed ConvLayers of the z | r and q convolutions over [h | x]."""
+        if not self.gru_fused or lay_zr.w_frag is None or lay_q.w_frag is None or self.dtype == L.F32:
+            return False
+        h, x, out = V(h), V(x), V(out)
+        n, hh, ww = h.t.shape[:3]
+        p = L.GruParams()
+        p.dtype = self.dtype
+        p.h, p.ldh = h.ptr, h.ld
+        p.x, p.ldx, p.cx = x.ptr, x.ld, x.c
+        p.wzr, p.wq = lay_zr.w_frag.data_ptr(), lay_q.w_frag.data_ptr()
+        p.bzr = None if lay_zr.b is None else lay_zr.b.data_ptr()
+        p.bq = None if lay_q.b is None else lay_q.b.data_ptr()
+        if ctx_zr is not None:
+            assert ctx_zr.dtype == torch.float32 and ctx_q.dtype == torch.float32
+            p.ctx_zr, p.ld_czr = ctx_zr.data_ptr(), ctx_zr.shape[-1]
+            p.ctx_q, p.ld_cq = ctx_q.data_ptr(), ctx_q.shape[-1]
+        else:
+            p.ctx_zr, p.ld_czr, p.ctx_q, p.ld_cq = None, 0, None, 0
+        p.out, p.ldo = out.ptr, out.ld
+        p.N, p.H, p.W, p.vertical = n, hh, ww, 1 if vertical else 0
+        if h.c != 128 or out.c != 128 or (lay_zr.kh, lay_zr.kw) != ((5, 1) if vertical else (1, 5)) or lay_zr.cin_pad != 128 + x.c \
+                or lay_zr.cout != 256 or lay_q.cout != 128 or self.lib.gru_half_ok(C.byref(p)) != 1:
+            return False
+        if self.ev_log is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._chk(self.lib.gru_half(C.byref(p), self.stream()), "gru_half")
+        if self.ev_log is not None:
+            e1.record()
+            tag = f"gru_half_kernel<{ {L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },64,128,kb128,s4>"
+            if self.ev_shapes:
+                tag += f" {n}x{hh}x{ww} {128 + x.c}->384 {'5x1' if vertical else '1x5'}"
+            self.ev_log.append((tag, 2.0 * n * hh * ww * 384 * 5 * (128 + x.c), e0, e1))
+        return True
 
     # ------------------------------------------------------------------ thin wrappers
     def resize_planes(self, src, scale):

@@ -481,6 +481,30 @@ typedef struct {
 } gvfi_token_path_params;
 int gvfi_token_path(const gvfi_token_path_params* p, void* stream);
 
+/* One half of the SepConvGRU of the flow estimators' update block as ONE launch (csrc/gru_fused.hip; raft/update.py:58-73,
+ * FlowFormer gru.py:130-160): z, r = sigmoid(conv_z / conv_r([h | x])), q = tanh(conv_q([r * h | x])), h' = (1 - z) h + z q with
+ * 1 x 5 (vertical = 0) or 5 x 1 (vertical = 1) filters.  Replaces the gvfi_conv2d pair (GVFI_EPI_GRU_ZR, GVFI_EPI_GRU_Q) of one
+ * half: a workgroup owns whole lines of the image (one row of W <= 64 pixels / two columns of H <= 32), stages their [h | x]
+ * once in LDS and runs the three contractions without barriers; z never leaves registers, r * h never leaves LDS.  Bit-identical
+ * to the two launches.  h [N,H,W,ldh] (128 channels), x [N,H,W,ldx] (cx = 128 or 256 channels: RAFT's [motion | flow] /
+ * FlowFormer's [motion | flow | aggregated motion]), wzr / wq = the fragment-ordered weight images (w_layout 2 of gvfi_conv2d)
+ * of the 256- / 128-output gate convolutions over [h | x], bzr [256] / bq [128] float biases (may be null), ctx_zr [N,H,W,ld_czr]
+ * / ctx_q float pre-activation terms (the context share of the gate convolutions, evaluated once per forward; may be null), out
+ * [N,H,W,ldo] = h'.  dtype GVFI_BF16 / GVFI_F16.  gvfi_gru_half_ok: 1 = this geometry is taken. */
+typedef struct {
+    int dtype;
+    const void* h; int ldh;
+    const void* x; int ldx; int cx;
+    const void* wzr; const void* wq;
+    const float* bzr; const float* bq;
+    const float* ctx_zr; int ld_czr;
+    const float* ctx_q; int ld_cq;
+    void* out; int ldo;
+    int N, H, W, vertical;
+} gvfi_gru_params;
+int gvfi_gru_half_ok(const gvfi_gru_params* p);
+int gvfi_gru_half(const gvfi_gru_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,11 @@ class SimRuntime(Runtime):
     def sibling(self, precision):
         return SimRuntime(precision, self.emulate_conv)
 
+    def gru_half(self, *a, **kw):
+        if not self.emulate_conv:
+            return False     # (the torch statement of the two gate convolutions runs instead: emulating the fused kernel at engine sizes takes hours)
+        return super().gru_half(*a, **kw)
+
     def conv_pair(self, a, b):
         if self.emulate_conv:
             return super().conv_pair(a, b)

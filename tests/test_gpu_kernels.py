@@ -170,6 +170,23 @@ def test_gru_epilogues(rt):
         kc.gru_case(rt, kh=1, kw=5, seed=8, state_f32=True)
 
 
+def test_gru_half_as_one_launch_equals_the_two_gate_convolutions():
+    """csrc/gru_fused.hip on the GPU: the recurrence's real shapes (8 images of 32 x 56, RAFT and FlowFormer widths, bf16 and
+    half) and the ragged / idle-row cases of the emulator test."""
+    from gimmvfi_hip.ops import Runtime
+
+    for prec in ("bf16", "fp16"):
+        rtx = Runtime(L.get(), prec, "cuda:0")
+        kc.gru_fused_case(rtx, N=8, H=32, W=56, vertical=False)
+        kc.gru_fused_case(rtx, N=8, H=32, W=56, vertical=True, seed=1)
+        kc.gru_fused_case(rtx, N=8, H=32, W=56, CX=256, vertical=False, seed=2)
+        kc.gru_fused_case(rtx, N=8, H=32, W=56, CX=256, vertical=True, seed=3)
+        kc.gru_fused_case(rtx, N=1, H=7, W=3, vertical=True, seed=4)
+        kc.gru_fused_case(rtx, N=2, H=2, W=64, vertical=False, seed=5, with_bias=True)
+        kc.gru_fused_case(rtx, N=1, H=32, W=2, vertical=True, seed=6, with_ctx=False)
+    torch.cuda.synchronize()
+
+
 def test_conv_pair_launch_equals_two_launches(rt):
     if rt.precision != "bf16":
         pytest.skip("the pair launch exists for the 16-bit weights-direct variant")

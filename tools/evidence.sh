@@ -78,7 +78,7 @@ for step in "$@"; do
     fpolicy-all) timeout 900 python tools/f_policy_diag.py "--policies=dec:f16;enc:f16,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy_all.txt 2>&1; cut -c1-250 $O/f_policy_all.txt | tail -14;;
     fpol-bench)   # speed of the candidate GIMM-VFI-F policies, graph replay, same box: 448x256 B=8 and 4K DS 0.25 8x
       : > $O/fpol_bench.txt
-      for pol in "dec:f16" "enc:f16,dec:f16" "enc:f16,cost:f16,dec:f16" "dec:f16"; do
+      for pol in "dec:f16" "f16" "enc:f16,cost:f16,dec:f16" "dec:f16" "f16"; do
         for cfg in f448 f4k; do
           line=$(timeout 400 python bench.py --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --flow-precision "$pol" --details $O/ab_tmp.json 2>/dev/null | tail -1)
           echo "$cfg $pol $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/fpol_bench.txt
