@@ -396,7 +396,7 @@ def main():
         traffic, pmc = None, None
         tag = roofline["kernel"]
         pmc_file = {"conv_igemm_glds_kernel<bf16,256,256": ["r2_hotconv_pmc.json"],
-                    "conv_p3x3_kernel<bf16,256,256": ["r4_p3x3_pmc.json", "r2_p3x3_pmc.json"]}
+                    "conv_p3x3_kernel<bf16,256,256": ["r5_p3x3_pmc.json", "r4_p3x3_pmc.json", "r2_p3x3_pmc.json"]}
         cands = next((v for k_, v in pmc_file.items() if tag.startswith(k_)), [])
         pmc_name = next((n_ for n_ in cands if os.path.isfile(os.path.join(ROOT, "profiles", n_))), "none")
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)

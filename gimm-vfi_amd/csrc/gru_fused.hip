@@ -17,6 +17,7 @@
 // gate arithmetic (conv_mma.h: fast_sigmoid / fast_tanh, (acc + context term) + bias) are those of the two launches: the
 // result is bit-identical to them (tests/kernel_cases.py:gru_fused_case, emulator + GPU).
 #include "conv_mma.h"
+#include <type_traits>
 
 struct GruArgs {
     gvfi_gru_params p;
@@ -138,11 +139,13 @@ template <typename T, int CX> __global__ void __launch_bounds__(256) GRU_KERNEL_
         };
 #pragma unroll
         for (int t = 0; t < 5; ++t) load_b(t, t);
-#pragma unroll 1
-        for (int ck = 0; ck < NCH; ++ck) {
+        // (the refill of a slot is UNCONDITIONAL inside the loop and the last channel chunk is a copy of the body without it:
+        // behind a run-time `if` hipcc's counted waits assume the path on which nothing was issued and drain the whole ring at
+        // the end of every channel chunk -- vmcnt(0) in front of the chunk's last MFMAs)
+        auto group = [&](int ck, auto more_tag) {
+            constexpr bool MORE = decltype(more_tag)::value;
             const int pl = (pass == 2 && ck < 2) ? NCH + ck : ck;
             const unsigned char* pb = smem + pl * GRU_PLANE;
-            const bool more = ck + 1 < NCH;
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
 #pragma unroll
@@ -153,10 +156,13 @@ template <typename T, int CX> __global__ void __launch_bounds__(256) GRU_KERNEL_
                     Mma2<T>::run(acc[1], f1, bq[t][kk]);
                 }
                 GVFI_SCHED_BARRIER();
-                if (more) load_b((ck + 1) * 5 + t, t);          // this slot's next occupant: the same tap of the next channel chunk
+                if constexpr (MORE) load_b((ck + 1) * 5 + t, t);          // this slot's next occupant: the same tap of the next channel chunk
                 GVFI_SCHED_BARRIER();
             }
-        }
+        };
+#pragma unroll 1
+        for (int ck = 0; ck + 1 < NCH; ++ck) group(ck, std::true_type{});
+        group(NCH - 1, std::false_type{});
         // (the epilogue's per-element pixel indices and LDS addresses do not depend on the pass: left alone hipcc computes all of
         // them ONCE in front of the pass loop and carries ~130 registers through the three K loops -- occupancy 1.  They are
         // made to depend on values the compiler cannot see through.)
@@ -171,11 +177,14 @@ template <typename T, int CX> __global__ void __launch_bounds__(256) GRU_KERNEL_
         const float bb = bias ? bias[ccol] : 0.f;
         if (pass == 2) __syncthreads();        // every wave is done reading the r * h planes: they become the staging tile [64 rows][128 channels]
         uint16_t* stg = (uint16_t*)(smem + NCH * GRU_PLANE);
+        // the context terms of all 32 elements are requested TOGETHER (one memory round trip; the ring's 80 registers are free
+        // by now) -- fetched four at a time between scheduling fences they cost eight dependent round trips per pass, and the
+        // first GPU A/B of this kernel lost 4 % to the two launches it replaces
+        float cv[2][16];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if ((r & 3) == 0) GVFI_SCHED_BARRIER();      // (four rows at a time: keeps the 32 elements' addresses / loads from all being live at once)
                 const int rr = acc_row_e(r);
                 bool ok;
                 long long pix;
@@ -186,8 +195,16 @@ template <typename T, int CX> __global__ void __launch_bounds__(256) GRU_KERNEL_
                     ok = i * 32 + rr < p.W;
                     pix = img_pix + pix_of(0, i * 32 + rr);
                 }
+                cv[i][r] = ctx ? ctx[(ok ? pix : img_pix) * ldc + ccol] : 0.f;
+            }
+        GVFI_SCHED_BARRIER();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = acc_row_e(r);
                 float v = acc[i][r];
-                if (ctx) v += ctx[(ok ? pix : img_pix) * ldc + ccol];
+                if (ctx) v += cv[i][r];
                 const float t = v + bb;
                 const int row = i * SEGI + rr + 2;
                 if (pass == 0) {
