@@ -273,7 +273,11 @@ class Runtime:
         self.fold_finalize = os.environ.get("GVFI_FOLD_FINALIZE", "1") != "0"   # A/B switch: finalize_image inside the last 7x7 layer
         self.zero_once = os.environ.get("GVFI_ZERO_ONCE", "1") != "0"           # A/B switch: persistent zero-once buffers (act(once=...))
         self.pair_launch = os.environ.get("GVFI_CONV_PAIR", "1") != "0"         # A/B switch: two independent convolutions per launch
-        self.gru_fused = os.environ.get("GVFI_GRU_FUSED", "1") != "0"           # A/B switch: SepConvGRU halves as one launch each
+        # SepConvGRU halves as one launch each (csrc/gru_fused.hip).  Built in round 5, bit-identical to the two gate convolutions,
+        # measured NEUTRAL (profiles/r5_gru_fused_ab_v2.txt: R 362.9 -> 363.8 frames/s, F 194.7 -> 193.9; the kernel itself takes
+        # 35-38 us against 31-32 us for the two launches it replaces: a 64-pixel line tile streams all 384 columns of weights
+        # -- 245 MB from L2 per launch, bound by bytes in flight / latency with one workgroup per CU), so it stays OFF
+        self.gru_fused = os.environ.get("GVFI_GRU_FUSED", "0") == "1"
         self._once = {}
         # PROFILING ONLY (results are garbage): the kernel's phase-skip switches on every weights-direct launch of the recurrences --
         # 8 = no epilogue, 16 = no K loop, 24 = neither: how much of the recurrence's wall time is the fixed per-launch cost

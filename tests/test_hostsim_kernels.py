@@ -182,15 +182,15 @@ def test_gru_epilogues(rt):
 
 def test_gru_half_as_one_launch_equals_the_two_gate_convolutions():
     """Round 5: csrc/gru_fused.hip on the emulator, bf16 and IEEE half, both halves, both x widths, ragged / idle rows."""
-    for prec in ("bf16", "fp16"):
-        rtx = SimRuntime(prec, emulate_conv=True)
-        kc.gru_fused_case(rtx, N=1, H=3, W=20, vertical=False)                            # one row per workgroup, 44 idle rows
-        kc.gru_fused_case(rtx, N=1, H=7, W=3, vertical=True, seed=1)                      # two columns per workgroup, odd W: an empty segment
     rtx = SimRuntime("bf16", emulate_conv=True)
-    kc.gru_fused_case(rtx, N=2, H=2, W=64, vertical=False, seed=2, with_bias=True)         # full rows, biases, two images
+    kc.gru_fused_case(rtx, N=1, H=2, W=20, vertical=False)                                # one row per workgroup, 44 idle rows
+    kc.gru_fused_case(rtx, N=1, H=7, W=3, vertical=True, seed=1)                          # two columns per workgroup, odd W: an empty segment
+    kc.gru_fused_case(rtx, N=2, H=1, W=64, vertical=False, seed=2, with_bias=True)         # full rows, biases, two images
     kc.gru_fused_case(rtx, N=1, H=32, W=2, vertical=True, seed=3, with_ctx=False)          # full columns, no context term
-    kc.gru_fused_case(rtx, N=1, H=2, W=33, CX=256, vertical=False, seed=4)                 # FlowFormer: 256 channels of x (30 K chunks)
-    kc.gru_fused_case(rtx, N=1, H=9, W=2, CX=256, vertical=True, seed=5)
+    kc.gru_fused_case(rtx, N=1, H=1, W=33, CX=256, vertical=False, seed=4)                 # FlowFormer: 256 channels of x (30 K chunks)
+    rth = SimRuntime("fp16", emulate_conv=True)
+    kc.gru_fused_case(rth, N=1, H=9, W=2, CX=256, vertical=True, seed=5)                   # IEEE half operands (FlowFormer's decoder)
+    kc.gru_fused_case(rth, N=1, H=1, W=40, vertical=False, seed=6)
 
 
 def test_conv_pair_launch_equals_two_launches(rt):
