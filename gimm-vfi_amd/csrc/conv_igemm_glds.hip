@@ -271,7 +271,7 @@ __device__ __forceinline__ void conv_igemm_glds_body(const ConvArgs2& a, const i
     static_assert(NT % GROUPS_PER_ROW == 0, "group index must be loop invariant");
     // (GVFI_WDIR_OCC3 variant of the weights-direct tile: fetched after the K loop -- 24 registers less across it; the
     // loads are issued ahead of the accumulator staging and awaited behind its barrier)
-    constexpr bool GC_LATE_WDIR = BDIR && GVFI_WDIR_OCC3;
+    constexpr bool GC_LATE_WDIR = BDIR && (GVFI_WDIR_OCC3 || BM == 128);
     constexpr bool GC_EARLY = NW <= 4 && !GC_LATE_WDIR;
     const int my_cg = tid % GROUPS_PER_ROW;
     const int my_cout0 = n0 + my_cg * 8;
@@ -954,9 +954,13 @@ __device__ __forceinline__ void conv_igemm_glds_body(const ConvArgs2& a, const i
 // the 64 x 128 weights-direct tile is budgeted for three workgroups per CU (<= 168 registers per wave) in the GVFI_WDIR_OCC3
 // build: the recurrence runs two independent launch sequences, and a free slot lets the other sequence's next kernel start
 // its prologue under this one's K loop
+// The 128 x 128 weights-direct tile (round 5) is budgeted for TWO workgroups per CU: unconstrained hipcc takes 317 registers
+// (occupancy 1: the variant lost in round 3); inside 256 -- with the bias / slope fetch moved behind the K loop -- the steady-state
+// K loop is spill-free and 24 scratch accesses remain in the once-per-workgroup tail sequences.  Twice the rows per tile = half
+// the weight stream per pixel, the bound of the recurrences.
 #define GVFI_GLDS_KERNEL_ATTRS                                                                                        \
-    __attribute__((amdgpu_waves_per_eu((GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 1,                     \
-                                       (GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 8)))
+    __attribute__((amdgpu_waves_per_eu((BDIR && BM == 128) ? 2 : ((GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 1),     \
+                                       (BDIR && BM == 128) ? 2 : ((GVFI_WDIR_OCC3 && BDIR && BN == 128 && BM == 64) ? 3 : 8))))
 #else
 #define GVFI_GLDS_KERNEL_ATTRS
 #endif

@@ -283,6 +283,7 @@ class Runtime:
         # 8 = no epilogue, 16 = no K loop, 24 = neither: how much of the recurrence's wall time is the fixed per-launch cost
         # (launch + prologue [+ epilogue]) and how much the contraction (tools/evidence.sh wdir-floor, profiles/r5_wdir_floor.txt)
         self.wdir_dbg = int(os.environ.get("GVFI_WDIR_DBG", "0")) & 24
+        self.wdir_bm128 = os.environ.get("GVFI_WDIR_BM128", "0") == "1"       # A/B switch: 128-row weights-direct tiles (see conv())
 
     def sibling(self, precision):
         """A runtime of another precision over the same library and device (GIMM-VFI-F's float flow-estimator stages)."""
@@ -397,6 +398,10 @@ class Runtime:
             elif want in (0, 6) and layer.w_frag is not None and layer.use_wdir and p.c0 % 64 == 0 and p.c1 % 64 == 0 and groups == 1:
                 p.w, p.w_layout = layer.w_frag.data_ptr(), 2      # weights-direct variant of the LDS-DMA kernel
                 algo = 2 | (algo & ~15) | (self.wdir_dbg << 8)
+                # 128-row tiles for the layers with two 128-column tiles (Cout > 128) while the 64-row grid would exceed half of the
+                # chip's 512 workgroup slots: half the weight stream per pixel, and both lanes' launches co-reside (GVFI_WDIR_BM128)
+                if self.wdir_bm128 and tile == 0 and layer.cout > 128 and 12288 <= n * h * w_ <= 16384:
+                    tile = 128 | (128 << 10)
                 want = 2
             elif want in (0, 2, 4) and aligned and not (algo & 128):
                 p.w, p.w_layout = layer.w_glds.data_ptr(), 1
