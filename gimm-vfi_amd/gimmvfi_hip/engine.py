@@ -72,6 +72,8 @@ class Engine:
         # it neutral: 347.6 vs 348.3 frames/s at 448x256, 111.8 vs 111.5 at 2K, 96.4 vs 97.1 at 4K, profiles/r4_side_lane_ab.txt;
         # the switch also left side-stream allocations un-recorded on the main stream, so it is gone: that work
         # runs after the recurrence on the main stream)
+        self.enc_lanes = os.environ.get("GVFI_ENC_LANES", "0") == "1"
+        self.post_lanes = os.environ.get("GVFI_POST_LANES", "0") == "1"
         self._tb_mem = {}
         self.layers = {}
         self._build(sd)
@@ -316,10 +318,23 @@ class Engine:
             c128, cfeats, _ = self._enc(imgU, fe + ".cnet", "batch", B + 1)
             c128, cfeats = c128[idx], [f[idx] for f in cfeats]
         else:
-            f128, _, (h8, w8) = self._enc(imgA, fe + ".fnet", "instance", n)
-            fmap = rt.act(n, h8, w8, 256)
-            rt.conv(Ls[fe + ".fnet.conv2"], f128, fmap)
-            c128, cfeats, _ = self._enc(imgA, fe + ".cnet", "batch", n)
+            # the two encoders read the same images and meet only in the recurrence: GVFI_ENC_LANES=1 runs them as two parallel
+            # launch sequences (their 1/4- and 1/8-resolution layers launch 224-448 workgroups each).  A/B switch, off until
+            # measured; the context encoder's outputs are allocated on the side stream and handed to the main one explicitly
+            k_enc = 2 if (self.enc_lanes and taps is None and rt.on_gpu) else 1
+            res = {}
+            with rt.lanes(k_enc) as lanes:
+                with lanes[0]:
+                    f128, _, (h8, w8) = self._enc(imgA, fe + ".fnet", "instance", n)
+                    fmap = rt.act(n, h8, w8, 256)
+                    rt.conv(Ls[fe + ".fnet.conv2"], f128, fmap)
+                with lanes[k_enc - 1]:
+                    res["c128"], res["cfeats"], _ = self._enc(imgA, fe + ".cnet", "batch", n)
+            c128, cfeats = res["c128"], res["cfeats"]
+            if k_enc > 1 and rt.ev_log is None and not torch.cuda.is_current_stream_capturing():
+                cur = torch.cuda.current_stream(rt.device)
+                for t_ in (c128, *cfeats):      # (allocated while the side stream was current: the main stream reads them from here on)
+                    (t_.t if isinstance(t_, View) else t_).record_stream(cur)
         hA = rt.act(n, h8, w8, 128)
         hB = rt.act(n, h8, w8, 128)
         xbuf = rt.act(n, h8, w8, 256)     # [inp(128) | motion(126) | flow(2)]  raft/update.py:143-144
@@ -626,9 +641,26 @@ class Engine:
             pre["i0q"] = rt.resize(View(img4[:B], 0, 4), 4, 0.25)   # fi_components.py:265-267
             pre["i1q"] = rt.resize(View(img4[B:], 0, 4), 4, 0.25)
 
-        f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps, seq, front=front)
+        # GVFI_POST_LANES=1 (A/B switch): everything between the recurrence and frame synthesis that does not need the flow -- the
+        # projections, BidirCorrBlock's volumes, the decoders' up-sampling stacks (`front`) -- runs as a second launch sequence beside
+        # the mask head, convex up-sampling, flow normalisation, motion encoder and the per-timestep INR passes, and is joined in
+        # front of the first synthesis batch.  (Round 4 had tried it beside the RECURRENCE, whose workgroups hold every slot: neutral.)
+        self._side_join = None
+        defer = self.post_lanes and taps is None and rt.on_gpu and rt.ev_log is None
+
+        def deferred(fn):
+            def run(*a):
+                cur = torch.cuda.current_stream(rt.device)
+                ss = rt._lane_streams(cur, 1)[0]
+                ss.wait_stream(cur)
+                with torch.cuda.stream(ss):
+                    fn(*a)
+                self._side_join = (cur, ss)
+            return run if defer else fn
+
+        f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps, seq, front=front, wrap_side=deferred)
         if not pre:
-            front(feat4, feat8)
+            deferred(front)(feat4, feat8)
         h4, w4 = H // 4, W // 4
         scaler = rt.f32(B, zero=True)
         rt._chk(lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), B, HW, st()), "flow_absmax")
@@ -674,6 +706,14 @@ class Engine:
                 out["flowt"].append(ft_nchw.squeeze())     # B==1 squeeze quirk, gimmvfi_r.py:364-372
                 tvs.append(tv)
             tv_all = tvs[0] if g == 1 else torch.cat(tvs)
+            if self._side_join is not None:      # the deferred side sequence: joined where its results are first read
+                cur, ss = self._side_join
+                cur.wait_stream(ss)
+                if not torch.cuda.is_current_stream_capturing():
+                    for t_ in (*pyr, *pyrT, feat4, feat8, *pre.values()):     # (allocated on the side stream, read on this one)
+                        (t_.t if isinstance(t_, View) else t_).record_stream(cur)
+                self._side_join = None
+                up8, up4, i0q, i1q = pre["up8"], pre["up4"], pre["i0q"], pre["i1q"]
             pred, f0p, f1p, oth = self._synthesize(g * B, B, H, W, Hf, Wf, img4, img4_full, flow_all, tv_all, up8, up4, i0q, i1q,
                                                    pyr, pyrT, taps, i0, want_aux)
             for k in range(g):
@@ -682,6 +722,9 @@ class Engine:
                 out["flowt0_pred"].append([f[sl] for f in f0p])
                 out["flowt1_pred"].append([f[sl] for f in f1p])
                 out["other_pred"].append([o[sl] for o in oth])
+        if self._side_join is not None:      # (no synthesis batch ran: the side sequence still has to re-join)
+            self._side_join[0].wait_stream(self._side_join[1])
+            self._side_join = None
         out["raft_flow"] = raft_flow
         out["nflow"] = nflow
         return out
@@ -708,7 +751,7 @@ class Engine:
                 G = min(G, lim)
         return G
 
-    def _flow(self, imgA, B, iters, taps, seq=False, front=None):
+    def _flow(self, imgA, B, iters, taps, seq=False, front=None, wrap_side=None):
         """Bidirectional flow + what frame synthesis needs from the flow estimator (gimmvfi_r.py:126-141): flows
         [B,H,W,2] f32 of both directions, the two correlation pyramids of BidirCorrBlock, context features at 1/4
         (128 ch) and 1/8 (256 ch) for both frames.  front(feat4, feat8): the caller's flow-independent work on the context
@@ -731,7 +774,7 @@ class Engine:
             if front is not None:
                 front(so["feat4"], so["feat8"])
 
-        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps, seq, side=side)
+        flow_up, fmap, cfeats, (h8, w8) = self._raft(imgA, B, iters, taps, seq, side=side if wrap_side is None else wrap_side(side))
         return flow_up[:B], flow_up[B:], so["pyr"], so["pyrT"], so["feat4"], so["feat8"], (h8, w8)
 
     def _bidir_pyramids(self, g, B, h8, w8):

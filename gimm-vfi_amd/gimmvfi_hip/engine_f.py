@@ -503,11 +503,25 @@ class EngineF(Engine):
             idx = self._seq_index(B, imgA.device)
             cfeat = [f[idx] for f in self._twins(imgU, fe + ".context_encoder")]
             ff = self._twins(imgU, fe + ".memory_encoder.feat_encoder")[1][idx]
-        else:
-            cfeat = self._twins(imgA, fe + ".context_encoder")
-            ff = self._twins(imgA, fe + ".memory_encoder.feat_encoder")[1]
-        fmap = rt.act(n, h8, w8, 256)
-        rt.conv(Ls[fe + ".memory_encoder.channel_convertor"], ff, fmap)
+            fmap = rt.act(n, h8, w8, 256)
+            rt.conv(Ls[fe + ".memory_encoder.channel_convertor"], ff, fmap)
+            return cfeat, fmap
+        # the two Twins encoders read the same images and meet only in the cost stage: GVFI_ENC_LANES=1 runs them as two parallel
+        # launch sequences (as the RAFT encoders of Engine._raft)
+        k_enc = 2 if (self.enc_lanes and rt.on_gpu) else 1
+        res = {}
+        with rt.lanes(k_enc) as lanes:
+            with lanes[0]:
+                ff = self._twins(imgA, fe + ".memory_encoder.feat_encoder")[1]
+                fmap = rt.act(n, h8, w8, 256)
+                rt.conv(Ls[fe + ".memory_encoder.channel_convertor"], ff, fmap)
+            with lanes[k_enc - 1]:
+                res["cfeat"] = self._twins(imgA, fe + ".context_encoder")
+        cfeat = res["cfeat"]
+        if k_enc > 1 and rt.ev_log is None and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream(rt.device)
+            for t_ in cfeat:
+                (t_.t if isinstance(t_, View) else t_).record_stream(cur)
         return cfeat, fmap
 
     def _ff_cost(self, fmap, context, n, B, h8, w8, taps):
@@ -758,7 +772,7 @@ class EngineF(Engine):
         return flow_up, fmap, cfeat, (h8, w8)
 
 
-    def _flow(self, imgA, B, iters, taps, seq=False, front=None):
+    def _flow(self, imgA, B, iters, taps, seq=False, front=None, wrap_side=None):
         """(front: the caller's flow-independent work -- run by the caller itself here, after the flow estimator.)
         gimmvfi_f.py:114-139: FlowFormer both ways, BidirCorrBlock on its (converted) features, context features
         of the Twins context encoder at 1/4 and 1/8 -- no projections in this model."""
