@@ -72,8 +72,12 @@ class Engine:
         # it neutral: 347.6 vs 348.3 frames/s at 448x256, 111.8 vs 111.5 at 2K, 96.4 vs 97.1 at 4K, profiles/r4_side_lane_ab.txt;
         # the switch also left side-stream allocations un-recorded on the main stream, so it is gone: that work
         # runs after the recurrence on the main stream)
-        self.enc_lanes = os.environ.get("GVFI_ENC_LANES", "0") == "1"
-        self.post_lanes = os.environ.get("GVFI_POST_LANES", "0") == "1"
+        # launch sequences beside each other (round 5; same arithmetic, parallel branches of the hipGraph): the two encoders of the flow
+        # estimator (RAFT fnet || cnet, FlowFormer's two Twins passes), and the flow-independent work behind the recurrence beside
+        # the motion path.  profiles/r5_lanes_ab.txt, same box: R 448x256 351.1 -> 355.5 -> 359.5 frames/s (+1.3 %, +2.4 %), F 190.0 ->
+        # 193.9 -> 194.7, R 4K 100.6 -> 101.9, F 4K 67.7 -> 69.1.  =0: A/B switches
+        self.enc_lanes = os.environ.get("GVFI_ENC_LANES", "1") != "0"
+        self.post_lanes = os.environ.get("GVFI_POST_LANES", "1") != "0"
         self._tb_mem = {}
         self.layers = {}
         self._build(sd)
@@ -655,7 +659,10 @@ class Engine:
                 ss.wait_stream(cur)
                 with torch.cuda.stream(ss):
                     fn(*a)
-                self._side_join = (cur, ss)
+                # the tensors the side sequence READS (allocated on this stream: feature maps, context features) must outlive its
+                # kernels: once the caller drops them the caching allocator -- also the capture pool -- may hand their blocks to a
+                # later allocation on THIS stream with no ordering against the side stream's reads.  They are held until the join.
+                self._side_join = (cur, ss, a)
             return run if defer else fn
 
         f01, f10, pyr, pyrT, feat4, feat8, (h8, w8) = self._flow(imgA, B, iters, taps, seq, front=front, wrap_side=deferred)
@@ -707,7 +714,7 @@ class Engine:
                 tvs.append(tv)
             tv_all = tvs[0] if g == 1 else torch.cat(tvs)
             if self._side_join is not None:      # the deferred side sequence: joined where its results are first read
-                cur, ss = self._side_join
+                cur, ss, _held = self._side_join
                 cur.wait_stream(ss)
                 if not torch.cuda.is_current_stream_capturing():
                     for t_ in (*pyr, *pyrT, feat4, feat8, *pre.values()):     # (allocated on the side stream, read on this one)
