@@ -76,6 +76,7 @@ class Engine:
         # estimator (RAFT fnet || cnet, FlowFormer's two Twins passes), and the flow-independent work behind the recurrence beside
         # the motion path.  profiles/r5_lanes_ab.txt, same box: R 448x256 351.1 -> 355.5 -> 359.5 frames/s (+1.3 %, +2.4 %), F 190.0 ->
         # 193.9 -> 194.7, R 4K 100.6 -> 101.9, F 4K 67.7 -> 69.1.  =0: A/B switches
+        self.synth_lanes = os.environ.get("GVFI_SYNTH_LANES", "0") == "1"
         self.enc_lanes = os.environ.get("GVFI_ENC_LANES", "1") != "0"
         self.post_lanes = os.environ.get("GVFI_POST_LANES", "1") != "0"
         self._tb_mem = {}
@@ -468,15 +469,23 @@ class Engine:
     def _amt_update(self, p, net, flow4_f32, corr, B, h, w, st4, ft_4, low):
         """modules/fi_components.py:199-222.  net: [B,h,w,128] (already down-sampled for the low block)."""
         rt, Ls = self.rt, self.layers
+        # GVFI_SYNTH_LANES=1 (A/B switch): the block's independent branches -- correlation branch || flow branch of its motion
+        # encoder, feature head || flow head -- as two parallel launch sequences (every tensor that crosses a join is allocated
+        # outside the branches; a branch's temporaries live and die on its own stream)
+        k = 2 if (self.synth_lanes and rt.on_gpu) else 1
         c1 = rt.act(B, h, w, 256)
-        rt.conv(Ls[p + ".convc1"], corr, c1, act1=A.ACT_LRELU)
         corflo = rt.act(B, h, w, 256)
-        rt.conv(Ls[p + ".convc2"], c1, View(corflo, 0, 192), act1=A.ACT_LRELU)
         flo = rt.act(B, h, w, 4, zero=True, once=p + ".flo")
-        rt.copy(View(flow4_f32, 0, 4), View(flo, 0, 4), 4)
-        f1 = rt.act(B, h, w, 128)
-        rt.patch_conv(Ls[p + ".convf1"], View(flo, 0, 4), f1, act1=A.ACT_LRELU)
-        rt.conv(Ls[p + ".convf2"], f1, View(corflo, 192, 64), act1=A.ACT_LRELU)
+        with rt.lanes(k) as lanes:
+            with lanes[0]:
+                rt.conv(Ls[p + ".convc1"], corr, c1, act1=A.ACT_LRELU)
+                rt.conv(Ls[p + ".convc2"], c1, View(corflo, 0, 192), act1=A.ACT_LRELU)
+            with lanes[k - 1]:
+                rt.copy(View(flow4_f32, 0, 4), View(flo, 0, 4), 4)
+                f1 = rt.act(B, h, w, 128)
+                rt.patch_conv(Ls[p + ".convf1"], View(flo, 0, 4), f1, act1=A.ACT_LRELU)
+                rt.conv(Ls[p + ".convf2"], f1, View(corflo, 192, 64), act1=A.ACT_LRELU)
+                del f1
         inp = rt.act(B, h, w, 192)          # [inp(188) | flow(4)] ; net(128) is the second conv source
         rt.conv(Ls[p + ".conv"], corflo, View(inp, 0, 188), act1=A.ACT_LRELU)
         rt.copy(View(flow4_f32, 0, 4), View(inp, 188, 4), 4)
@@ -484,22 +493,29 @@ class Engine:
         rt.conv(Ls[p + ".gru.0"], inp, g0, x1=net, act1=A.ACT_LRELU)
         out = rt.act(B, h, w, 192)
         rt.conv(Ls[p + ".gru.2"], g0, out)
-        fh0 = rt.act(B, h, w, 192)
-        rt.conv(Ls[p + ".feat_head.0"], out, fh0, act1=A.ACT_LRELU)
-        lh0 = rt.act(B, h, w, 192)
-        rt.conv(Ls[p + ".flow_head.0"], out, lh0, act1=A.ACT_LRELU)
-        if low:
-            dnet = rt.act(B, h, w, 128)
-            rt.conv(Ls[p + ".feat_head.2"], fh0, dnet)
-            dflow = rt.f32(B, h, w, 4)
-            rt.conv(Ls[p + ".flow_head.2"], lh0, dflow)
-            up = rt.resize(dnet, 128, 2.0)
-            rt.copy(up, ft_4, 128, add=ft_4)
-            upf = rt.resize(dflow, 4, 2.0, mul=2.0)
-            rt.copy(upf, View(st4, 0, 4), 4, add=View(st4, 0, 4))
-        else:
-            rt.conv(Ls[p + ".feat_head.2"], fh0, ft_4, res=ft_4)
-            rt.conv(Ls[p + ".flow_head.2"], lh0, View(st4, 0, 4), res=View(st4, 0, 4))
+        with rt.lanes(k) as lanes:
+            with lanes[0]:
+                fh0 = rt.act(B, h, w, 192)
+                rt.conv(Ls[p + ".feat_head.0"], out, fh0, act1=A.ACT_LRELU)
+                if low:
+                    dnet = rt.act(B, h, w, 128)
+                    rt.conv(Ls[p + ".feat_head.2"], fh0, dnet)
+                    up = rt.resize(dnet, 128, 2.0)
+                    rt.copy(up, ft_4, 128, add=ft_4)
+                else:
+                    rt.conv(Ls[p + ".feat_head.2"], fh0, ft_4, res=ft_4)
+            with lanes[k - 1]:
+                lh0 = rt.act(B, h, w, 192)
+                rt.conv(Ls[p + ".flow_head.0"], out, lh0, act1=A.ACT_LRELU)
+                if low:
+                    dflow = rt.f32(B, h, w, 4)
+                    rt.conv(Ls[p + ".flow_head.2"], lh0, dflow)
+                    upf = rt.resize(dflow, 4, 2.0, mul=2.0)
+                    rt.copy(upf, View(st4, 0, 4), 4, add=View(st4, 0, 4))
+                    del dflow, upf
+                else:
+                    rt.conv(Ls[p + ".flow_head.2"], lh0, View(st4, 0, 4), res=View(st4, 0, 4))
+                del lh0
 
     # ------------------------------------------------------------------ motion INR (shared by GIMM-VFI-R and GIMM)
     def _motion_encode(self, nfA, f01, f10, B, H, W):
