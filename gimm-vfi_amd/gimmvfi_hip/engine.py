@@ -76,7 +76,8 @@ class Engine:
         # estimator (RAFT fnet || cnet, FlowFormer's two Twins passes), and the flow-independent work behind the recurrence beside
         # the motion path.  profiles/r5_lanes_ab.txt, same box: R 448x256 351.1 -> 355.5 -> 359.5 frames/s (+1.3 %, +2.4 %), F 190.0 ->
         # 193.9 -> 194.7, R 4K 100.6 -> 101.9, F 4K 67.7 -> 69.1.  =0: A/B switches
-        self.synth_lanes = os.environ.get("GVFI_SYNTH_LANES", "0") == "1"
+        # ... and the independent branches inside the AMT update blocks (profiles/r5_synth_lanes_ab.txt: R 448x256 356.1 -> 359.2, +0.9 %)
+        self.synth_lanes = os.environ.get("GVFI_SYNTH_LANES", "1") != "0"
         self.enc_lanes = os.environ.get("GVFI_ENC_LANES", "1") != "0"
         self.post_lanes = os.environ.get("GVFI_POST_LANES", "1") != "0"
         self._tb_mem = {}
@@ -323,9 +324,9 @@ class Engine:
             c128, cfeats, _ = self._enc(imgU, fe + ".cnet", "batch", B + 1)
             c128, cfeats = c128[idx], [f[idx] for f in cfeats]
         else:
-            # the two encoders read the same images and meet only in the recurrence: GVFI_ENC_LANES=1 runs them as two parallel
-            # launch sequences (their 1/4- and 1/8-resolution layers launch 224-448 workgroups each).  A/B switch, off until
-            # measured; the context encoder's outputs are allocated on the side stream and handed to the main one explicitly
+            # the two encoders read the same images and meet only in the recurrence: they run as two parallel launch sequences
+            # (their 1/4- and 1/8-resolution layers launch 224-448 workgroups each; GVFI_ENC_LANES=0: A/B switch); the context
+            # encoder's outputs are allocated on the side stream and handed to the main one explicitly
             k_enc = 2 if (self.enc_lanes and taps is None and rt.on_gpu) else 1
             res = {}
             with rt.lanes(k_enc) as lanes:
@@ -469,7 +470,7 @@ class Engine:
     def _amt_update(self, p, net, flow4_f32, corr, B, h, w, st4, ft_4, low):
         """modules/fi_components.py:199-222.  net: [B,h,w,128] (already down-sampled for the low block)."""
         rt, Ls = self.rt, self.layers
-        # GVFI_SYNTH_LANES=1 (A/B switch): the block's independent branches -- correlation branch || flow branch of its motion
+        # (GVFI_SYNTH_LANES=0: A/B switch) the block's independent branches -- correlation branch || flow branch of its motion
         # encoder, feature head || flow head -- as two parallel launch sequences (every tensor that crosses a join is allocated
         # outside the branches; a branch's temporaries live and die on its own stream)
         k = 2 if (self.synth_lanes and rt.on_gpu) else 1
@@ -661,7 +662,7 @@ class Engine:
             pre["i0q"] = rt.resize(View(img4[:B], 0, 4), 4, 0.25)   # fi_components.py:265-267
             pre["i1q"] = rt.resize(View(img4[B:], 0, 4), 4, 0.25)
 
-        # GVFI_POST_LANES=1 (A/B switch): everything between the recurrence and frame synthesis that does not need the flow -- the
+        # (GVFI_POST_LANES=0: A/B switch) everything between the recurrence and frame synthesis that does not need the flow -- the
         # projections, BidirCorrBlock's volumes, the decoders' up-sampling stacks (`front`) -- runs as a second launch sequence beside
         # the mask head, convex up-sampling, flow normalisation, motion encoder and the per-timestep INR passes, and is joined in
         # front of the first synthesis batch.  (Round 4 had tried it beside the RECURRENCE, whose workgroups hold every slot: neutral.)

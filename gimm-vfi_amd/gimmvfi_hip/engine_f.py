@@ -506,8 +506,8 @@ class EngineF(Engine):
             fmap = rt.act(n, h8, w8, 256)
             rt.conv(Ls[fe + ".memory_encoder.channel_convertor"], ff, fmap)
             return cfeat, fmap
-        # the two Twins encoders read the same images and meet only in the cost stage: GVFI_ENC_LANES=1 runs them as two parallel
-        # launch sequences (as the RAFT encoders of Engine._raft)
+        # the two Twins encoders read the same images and meet only in the cost stage: two parallel launch sequences
+        # (as the RAFT encoders of Engine._raft; GVFI_ENC_LANES=0: A/B switch)
         k_enc = 2 if (self.enc_lanes and rt.on_gpu) else 1
         res = {}
         with rt.lanes(k_enc) as lanes:
