@@ -78,6 +78,7 @@ class Engine:
         # 193.9 -> 194.7, R 4K 100.6 -> 101.9, F 4K 67.7 -> 69.1.  =0: A/B switches
         # ... and the independent branches inside the AMT update blocks (profiles/r5_synth_lanes_ab.txt: R 448x256 356.1 -> 359.2, +0.9 %)
         self.synth_lanes = os.environ.get("GVFI_SYNTH_LANES", "1") != "0"
+        self.misc_lanes = os.environ.get("GVFI_MISC_LANES", "0") == "1"      # (A/B switch: two more small fork / joins, see _raft / _synthesize)
         self.enc_lanes = os.environ.get("GVFI_ENC_LANES", "1") != "0"
         self.post_lanes = os.environ.get("GVFI_POST_LANES", "1") != "0"
         self._tb_mem = {}
@@ -349,15 +350,26 @@ class Engine:
         sf = self.gru_state_f32 and rt.precision == "bf16"
         h32A = rt.f32(n, h8, w8, 128) if sf else None
         h32B = rt.f32(n, h8, w8, 128) if sf else None
-        if sf:
-            rt.conv(Ls["cnet.out_net"], c128, h32A, act1=A.ACT_TANH)
-            rt.copy(h32A, hA, 128)
-        else:
-            rt.conv(Ls["cnet.out_net"], c128, hA, act1=A.ACT_TANH)
-        rt.conv(Ls["cnet.out_inp"], c128, View(xbuf, 0, 128), act1=A.ACT_RELU)
-        # correlation pyramids: direction 0->1 for images [0,B), 1->0 for [B,2B)
-        # correlation pyramids of both directions in one grouped GEMM: image i against its partner (i +- B)
-        pyr_ab = self._corr_pyramids(fmap, [(0, B, fmap[B:]), (B, B, fmap[:B])], n, h8, w8)
+        u = fe + ".update_block"
+        # context share of the four gate convolutions (f32, evaluated once): see _build
+        ctx = {key: rt.f32(n, h8, w8, Ls[key + ".ctx"].cout) for key in ("gru.zr1", "gru.q1", "gru.zr2", "gru.q2")}
+        # the matching features feed the correlation pyramids, the context features the initial state / the constant GRU input and
+        # its four pre-activation terms: two independent launch sequences (GVFI_MISC_LANES=1, A/B switch; everything the second
+        # one writes is allocated above)
+        k_pre = 2 if (self.misc_lanes and taps is None and rt.on_gpu) else 1
+        with rt.lanes(k_pre) as lanes:
+            with lanes[k_pre - 1]:
+                if sf:
+                    rt.conv(Ls["cnet.out_net"], c128, h32A, act1=A.ACT_TANH)
+                    rt.copy(h32A, hA, 128)
+                else:
+                    rt.conv(Ls["cnet.out_net"], c128, hA, act1=A.ACT_TANH)
+                rt.conv(Ls["cnet.out_inp"], c128, View(xbuf, 0, 128), act1=A.ACT_RELU)
+                for key in ctx:
+                    rt.conv(Ls[key + ".ctx"], View(xbuf, 0, 128), ctx[key])
+            with lanes[0]:
+                # correlation pyramids of both directions (0->1 for images [0,B), 1->0 for [B,2B)): image i against its partner (i +- B)
+                pyr_ab = self._corr_pyramids(fmap, [(0, B, fmap[B:]), (B, B, fmap[:B])], n, h8, w8)
         pyr_a = [p[:B * h8 * w8] for p in pyr_ab]
         if taps is not None:
             taps["r01_fmap1"] = fmap[:B]
@@ -375,13 +387,6 @@ class Engine:
         zbuf = rt.f32(n, h8, w8, 128) if sf else rt.act(n, h8, w8, 128)
         rh = rt.act(n, h8, w8, 128)
         fh = rt.act(n, h8, w8, 256)
-        u = fe + ".update_block"
-        # context share of the four gate convolutions (f32, evaluated once): see _build
-        ctx = {}
-        for key in ("gru.zr1", "gru.q1", "gru.zr2", "gru.q2"):
-            lay = Ls[key + ".ctx"]
-            ctx[key] = rt.f32(n, h8, w8, lay.cout)
-            rt.conv(lay, View(xbuf, 0, 128), ctx[key])
         fcol = rt.act(n, h8, w8, Ls[u + ".encoder.convf1"].kpad)
         fpart = rt.f32(n, h8, w8, 20)   # 9 taps x 2 partial sums of the flow head (+ pad)
         P8 = h8 * w8
@@ -856,13 +861,17 @@ class Engine:
         rt.resize(ft1, 2, 0.25, mul=0.25, out=View(fl4in, 2, 2))
         # ---- NewInitDecoder  fi_components.py:255-276
         f_in = rt.act(B, h4, w4, 272, zero=True, pitch=rt.cp64(272), zero_pad_only=True, once="synth.f_in")
-        rt.warp(up8[:sb], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
-        rt.warp(up8[sb:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
-        rt.copy(View(fl4in, 0, 4), View(f_in, 256, 4), 4)
-        rt.copy(View(i0q.t, 0, 3), View(f_in, 260, 3), 3)
-        rt.copy(View(i1q.t, 0, 3), View(f_in, 263, 3), 3)
-        rt.warp(View(i0q.t, 0, 3), 3, View(fl4in, 0, 2), View(f_in, 266, 3))
-        rt.warp(View(i1q.t, 0, 3), 3, View(fl4in, 2, 2), View(f_in, 269, 3))
+        k_asm = 2 if (self.misc_lanes and taps is None and rt.on_gpu) else 1      # (the seven writers of f_in's channel slices: two sequences)
+        with rt.lanes(k_asm) as lanes:
+            with lanes[0]:
+                rt.warp(up8[:sb], 128, View(fl4in, 0, 2), View(f_in, 0, 128))
+                rt.copy(View(fl4in, 0, 4), View(f_in, 256, 4), 4)
+                rt.copy(View(i0q.t, 0, 3), View(f_in, 260, 3), 3)
+                rt.warp(View(i0q.t, 0, 3), 3, View(fl4in, 0, 2), View(f_in, 266, 3))
+            with lanes[k_asm - 1]:
+                rt.warp(up8[sb:], 128, View(fl4in, 2, 2), View(f_in, 128, 128))
+                rt.copy(View(i1q.t, 0, 3), View(f_in, 263, 3), 3)
+                rt.warp(View(i1q.t, 0, 3), 3, View(fl4in, 2, 2), View(f_in, 269, 3))
         p = "amt_init_decoder.convblock"
         x = rt.act(B, h4, w4, 128)
         rt.conv(Ls[p + ".0.0"], f_in, x, act1=A.ACT_PRELU)
