@@ -1025,6 +1025,7 @@ static int launch_glds(const gvfi_conv_params& p, hipStream_t stream) {
     gvfi_magic_div((unsigned)p.Wo, a.wo_mul, a.wo_sh);
     a.dbg = (p.algo >> 8) & 0xff;   // profiling switches: algo bits 8.. (8 = no epilogue, 16 = no K loop)
     dim3 grid(a.per_xcd * 8, 1, groups);
+    GVFI_EMU_SERIAL(p.stats != nullptr);
     GVFI_LAUNCH_COOP((conv_igemm_glds_kernel<T, BM, BN, WAVES_M, WAVES_N, KB, NSTAGE, PIPE, PPS, BDIR>), grid, dim3(64 * WAVES_M * WAVES_N), stream, a);
     return (int)hipGetLastError();
 }

@@ -370,6 +370,7 @@ extern "C" int gvfi_conv2d_p3x3s(const gvfi_conv_params* pp, void* stream) {
     a.per_xcd = cdiv((long long)a.mtiles, 8);
     const dim3 grid(a.per_xcd * 8), block(256);
     hipStream_t st = (hipStream_t)stream;
+    GVFI_EMU_SERIAL(p.stats != nullptr);
     if (((p.algo >> 8) & 128) && p.aux1 != nullptr && p.c0 == 64 && p.Cout > 32) {
         GVFI_LAUNCH_COOP((conv_p3x3s_kernel<64, 64, true>), grid, block, st, a);
     } else if (p.c0 == 64) {

@@ -107,6 +107,7 @@ extern "C" int gvfi_instnorm_stats(const void* x, int ld, int C, int N, int HW, 
     const int ve = dtype == GVFI_F32 ? 4 : 8;
     if (C > GVFI_BLOCK || (C % ve) || (ld % ve) || ((uintptr_t)x & 15)) return -2;
     dim3 grid((unsigned)((HW + IN_CHUNK - 1) / IN_CHUNK), (unsigned)N);
+    GVFI_EMU_SERIAL(true);
     GVFI_DISPATCH_T(dtype, GVFI_LAUNCH_COOP((instnorm_stats_kernel<T>), grid, dim3(GVFI_BLOCK), (hipStream_t)stream,
                                             (const T*)x, ld, C, HW, stats));
     return (int)hipGetLastError();

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY.  A tiny thread-per-lane host emulator for the HIP kernels in
+// TEST INFRASTRUCTURE ONLY.  A tiny fiber-per-lane host emulator for the HIP kernels in
 // gimm-vfi_amd/csrc, used by the CPU test-suite (pytest -m "not gpu") to check index math,
 // LDS addressing, barrier placement and epilogues before spending GPU minutes.
 //
@@ -6,29 +6,36 @@
 // Python host code refuses to run without it.  This header is only seen when a source file is
 // compiled with -DGVFI_HOSTSIM by tests/hostsim/build.py.
 //
-// Model: every GPU thread of a workgroup is an OS thread; workgroups run one after another
-// ("coop" launches) so `__shared__` can be a plain static; `__syncthreads` / cross-lane ops are
-// std::barrier based.  "simple" launches (no LDS/barrier/cross-lane) run lanes sequentially and
-// workgroups in parallel.  MFMA builtins are emulated with the gfx950 register layouts of
-// /opt/skills/guides/cdna_hip_programming.md section 3.
+// Model (round 5: fibers instead of one OS thread per lane -- the thread-per-lane form spent most of its time in futex calls
+// of 64- / 256-party std::barriers): every GPU thread of a workgroup is a FIBER (a private stack, switched in user space);
+// the fibers of one workgroup run on ONE OS thread, round-robin, and change over only at `__syncthreads` / cross-lane
+// operations (wave_sync), so a workgroup's execution order is deterministic.  Workgroups of a "coop" launch are handed to a
+// small persistent pool of OS threads (the calling thread is one of them), `__shared__` is a thread_local static, i.e. one
+// copy per worker, dirty from the previous workgroup like real LDS.  A launch whose workgroups combine through FLOAT atomics
+// can ask for one worker (GVFI_EMU_SERIAL) so that its sums keep the block order; GVFI_EMU_THREADS=1 serialises everything.
+// "simple" launches (no LDS / barrier / cross-lane) run lanes sequentially and workgroups in parallel.  MFMA builtins are
+// emulated with the gfx950 register layouts of /opt/skills/guides/cdna_hip_programming.md section 3.
 #pragma once
 #include <atomic>
-#include <barrier>
+#include <condition_variable>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 
 struct dim3 {
     unsigned x, y, z;
@@ -54,32 +61,115 @@ struct f32x16 {
     const float& operator[](int i) const { return v[i]; }
 };
 
+// ---- fibers ---------------------------------------------------------------------------------
+// gvfi_emu_switch(save, load): push the callee-saved registers, store the stack pointer to *save, continue on `load`
+// (x86-64 System V; one weak, hidden copy per translation unit).
+#if !defined(__x86_64__)
+#error "tests/hostsim/hip_emu.h: the fiber switch is written for x86-64"
+#endif
+extern "C" __attribute__((visibility("hidden"))) void gvfi_emu_switch(void** save_sp, void* load_sp);
+asm(".pushsection .text\n"
+    ".weak gvfi_emu_switch\n"
+    ".hidden gvfi_emu_switch\n"
+    ".type gvfi_emu_switch,@function\n"
+    "gvfi_emu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size gvfi_emu_switch, .-gvfi_emu_switch\n"
+    ".popsection\n");
+
 namespace emu {
-struct BlockShared {
-    int nthreads;
-    std::barrier<> block_bar;
-    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
-    // per-wave exchange scratch: 64 lanes x 16 dwords
-    std::vector<uint32_t> xchg;
-    explicit BlockShared(int nt) : nthreads(nt), block_bar(nt) {
-        int nw = (nt + 63) / 64;
-        for (int w = 0; w < nw; ++w) {
-            int cnt = std::min(64, nt - 64 * w);
-            wave_bar.emplace_back(new std::barrier<>(cnt));
-        }
-        xchg.resize((size_t)nw * 64 * 16);
-    }
+constexpr size_t kStackBytes = 512u << 10;      // per lane; only touched pages are ever resident
+constexpr int kMaxWaves = 32;
+
+// one workgroup in flight on this OS thread
+struct WorkGroup {
+    int nt = 0, cur = -1, alive = 0;
+    void* main_sp = nullptr;
+    std::vector<void*> sp;                  // saved stack pointer per fiber
+    std::vector<unsigned char> done;
+    std::vector<unsigned char*> stacks;     // mmap'ed once per worker thread, reused by every launch
+    std::vector<unsigned> tid3;             // threadIdx (x, y, z) per fiber
+    unsigned long long progress = 0;        // arrivals + completions + exits: a full round without any = deadlock
+    int blk_arrived = 0;
+    unsigned blk_gen = 0;
+    int wv_arrived[kMaxWaves], wv_size[kMaxWaves];
+    unsigned wv_gen[kMaxWaves];
+    std::vector<uint32_t> xchg;             // per-wave exchange scratch: 64 lanes x 16 dwords
+    void (*call)(const void*) = nullptr;    // the kernel body of the running launch
+    const void* ctx = nullptr;
 };
-inline thread_local BlockShared* tl_bs = nullptr;
-inline unsigned char* dyn_smem = nullptr;   // dynamic LDS of the running (coop) launch
+inline thread_local WorkGroup* tl_wg = nullptr;
+inline thread_local unsigned char* dyn_smem = nullptr;   // dynamic LDS of the running (coop) launch: one buffer per worker
 inline thread_local int tl_lane = 0, tl_wave = 0;
-inline uint32_t* wave_scratch() { return tl_bs->xchg.data() + (size_t)tl_wave * 64 * 16; }
-inline void wave_sync() { tl_bs->wave_bar[tl_wave]->arrive_and_wait(); }
+inline thread_local bool serial_hint = false;            // GVFI_EMU_SERIAL: the next coop launch of this thread runs on one worker
+inline uint32_t* wave_scratch() { return tl_wg->xchg.data() + (size_t)tl_wave * 64 * 16; }
+inline void lane_vars(WorkGroup& g, int t);
+inline int next_alive(const WorkGroup& g, int t) {
+    do { t = t + 1 == g.nt ? 0 : t + 1; } while (g.done[t]);
+    return t;
+}
+// leave fiber `from` (-1: the worker's own context) for fiber `to` (-1: back to the worker)
+inline void switch_to(WorkGroup& g, int from, int to) {
+    g.cur = to;
+    if (to >= 0) lane_vars(g, to);
+    gvfi_emu_switch(from >= 0 ? &g.sp[from] : &g.main_sp, to >= 0 ? g.sp[to] : g.main_sp);
+}
+[[noreturn]] inline void deadlock(const char* what) {
+    std::fprintf(stderr, "hip_emu: deadlock in %s (a lane left the kernel, or took another path, while the others wait)\n", what);
+    std::abort();
+}
+// wait until *gen moves on from `seen`, running the other lanes meanwhile
+inline void wait_gen(WorkGroup& g, const unsigned* gen, unsigned seen, const char* what) {
+    unsigned long long last = g.progress;
+    int idle = 0;
+    while (*(volatile const unsigned*)gen == seen) {
+        const int me = g.cur, to = next_alive(g, me);
+        if (to == me) deadlock(what);
+        switch_to(g, me, to);
+        if (g.progress != last) { last = g.progress; idle = 0; }
+        else if (++idle > g.nt + 2) deadlock(what);
+    }
+}
+inline void wave_sync() {
+    WorkGroup& g = *tl_wg;
+    const int w = tl_wave;
+    const unsigned seen = g.wv_gen[w];
+    ++g.progress;
+    if (++g.wv_arrived[w] == g.wv_size[w]) { g.wv_arrived[w] = 0; ++g.wv_gen[w]; return; }
+    wait_gen(g, &g.wv_gen[w], seen, "a wave-level operation");
+}
+inline void block_sync() {
+    WorkGroup& g = *tl_wg;
+    const unsigned seen = g.blk_gen;
+    ++g.progress;
+    if (++g.blk_arrived == g.nt) { g.blk_arrived = 0; ++g.blk_gen; return; }
+    wait_gen(g, &g.blk_gen, seen, "__syncthreads");
+}
+// first frame of every fiber: run the kernel body for this lane, then hand over for good
+inline void fiber_entry() {
+    WorkGroup& g = *tl_wg;
+    g.call(g.ctx);
+    const int me = g.cur;
+    g.done[me] = 1;
+    ++g.progress;
+    if (--g.alive == 0) switch_to(g, me, -1);
+    else switch_to(g, me, next_alive(g, me));
+    std::abort();      // (a finished fiber is never resumed)
+}
 }  // namespace emu
 
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+inline void emu::lane_vars(WorkGroup& g, int t) {
+    tl_lane = t & 63;
+    tl_wave = t >> 6;
+    threadIdx = dim3(g.tid3[3 * t], g.tid3[3 * t + 1], g.tid3[3 * t + 2]);
+}
 
-static inline void __syncthreads() { emu::tl_bs->block_bar.arrive_and_wait(); }
+static inline void __syncthreads() { emu::block_sync(); }
 
 template <typename V> static inline V emu_shfl_from(V v, int src_lane) {
     static_assert(sizeof(V) == 4, "32-bit shuffles only");
@@ -249,62 +339,180 @@ static inline void emu_glds16(const void* gsrc, unsigned char* lds_wave_base) {
 }
 
 // ---- launches -----------------------------------------------------------------------------
-template <typename F> static void emu_launch_coop(dim3 grid, dim3 block, F f) {
-    const int nt = (int)(block.x * block.y * block.z);
-    emu::BlockShared bs(nt);
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    for (int t = 0; t < nt; ++t) {
-        th.emplace_back([&, t] {
-            emu::tl_bs = &bs;
-            emu::tl_lane = t & 63;
-            emu::tl_wave = t >> 6;
-            blockDim = block;
-            gridDim = grid;
-            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-            for (unsigned bz = 0; bz < grid.z; ++bz)
-                for (unsigned by = 0; by < grid.y; ++by)
-                    for (unsigned bx = 0; bx < grid.x; ++bx) {
-                        blockIdx = dim3(bx, by, bz);
-                        f();
-                        bs.block_bar.arrive_and_wait();
-                    }
-        });
+namespace emu {
+// persistent workers (leaked at exit on purpose: they sleep on a condition variable; rebuilt after a fork)
+struct Pool {
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    unsigned long long job = 0;
+    int want = 0, pending = 0, nthreads = 0;
+    void (*fn)(void*) = nullptr;
+    void* arg = nullptr;
+    pid_t pid = 0;
+};
+inline Pool*& pool_ptr() { static Pool* p = nullptr; return p; }
+inline int max_workers() {
+    static int n = 0;
+    if (n == 0) {
+        const char* e = std::getenv("GVFI_EMU_THREADS");
+        n = e ? std::atoi(e) : (int)std::min(16u, std::thread::hardware_concurrency());
+        if (n < 1) n = 1;
     }
-    for (auto& x : th) x.join();
+    return n;
+}
+inline void pool_worker(Pool* p, int id) {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(p->m);
+    for (;;) {
+        p->cv_job.wait(lk, [&] { return p->job != seen; });
+        seen = p->job;
+        if (id >= p->want) continue;
+        void (*fn)(void*) = p->fn;
+        void* arg = p->arg;
+        lk.unlock();
+        fn(arg);
+        lk.lock();
+        if (--p->pending == 0) p->cv_done.notify_all();
+    }
+}
+// run fn(arg) on `n` threads at once (the caller is one of them)
+inline void run_on(int n, void (*fn)(void*), void* arg) {
+    if (n <= 1) { fn(arg); return; }
+    Pool*& p = pool_ptr();
+    if (p == nullptr || p->pid != getpid()) {      // (after a fork the parent's workers do not exist here)
+        p = new Pool;
+        p->pid = getpid();
+        p->nthreads = max_workers() - 1;
+        for (int i = 0; i < p->nthreads; ++i) std::thread(pool_worker, p, i).detach();
+    }
+    const int helpers = std::min(n - 1, p->nthreads);
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        p->fn = fn;
+        p->arg = arg;
+        p->want = helpers;
+        p->pending = helpers;
+        ++p->job;
+    }
+    p->cv_job.notify_all();
+    fn(arg);
+    std::unique_lock<std::mutex> lk(p->m);
+    p->cv_done.wait(lk, [&] { return p->pending == 0; });
+}
+inline unsigned char* new_stack() {
+    const size_t page = 4096;
+    void* m = mmap(nullptr, kStackBytes + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) { std::perror("hip_emu: mmap of a lane stack"); std::abort(); }
+    mprotect(m, page, PROT_NONE);      // guard page under the stack
+    return (unsigned char*)m + page;
+}
+inline WorkGroup& my_wg() { static thread_local WorkGroup g; return g; }
+inline std::vector<uint32_t>& my_dyn() { static thread_local std::vector<uint32_t> d; return d; }
+template <typename F> struct CoopJob {
+    dim3 grid, block;
+    size_t shm;
+    const F* f;
+    std::atomic<long> next{0};
+};
+template <typename F> void coop_worker(void* jp) {
+    CoopJob<F>& job = *(CoopJob<F>*)jp;
+    WorkGroup& g = my_wg();                       // (per OS thread, NOT per kernel type: the lane stacks are reused by every launch)
+    std::vector<uint32_t>& dyn = my_dyn();
+    const dim3 grid = job.grid, block = job.block;
+    const int nt = (int)(block.x * block.y * block.z);
+    const int nw = (nt + 63) / 64;
+    if (nw > kMaxWaves) { std::fprintf(stderr, "hip_emu: workgroup of %d lanes\n", nt); std::abort(); }
+    g.nt = nt;
+    g.sp.resize(nt);
+    g.done.resize(nt);
+    g.tid3.resize(3 * (size_t)nt);
+    while ((int)g.stacks.size() < nt) g.stacks.push_back(new_stack());
+    g.xchg.resize((size_t)nw * 64 * 16);
+    for (int t = 0; t < nt; ++t) {
+        g.tid3[3 * t] = t % block.x;
+        g.tid3[3 * t + 1] = (t / block.x) % block.y;
+        g.tid3[3 * t + 2] = t / (block.x * block.y);
+    }
+    for (int w = 0; w < nw; ++w) g.wv_size[w] = std::min(64, nt - 64 * w);
+    g.call = [](const void* c) { (*(const F*)c)(); };
+    g.ctx = job.f;
+    if (job.shm) {
+        dyn.assign(job.shm / 4 + 64, 0xdeadbeefu);
+        dyn_smem = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(dyn.data()) + 63) & ~(uintptr_t)63);
+    }
+    WorkGroup* outer = tl_wg;
+    tl_wg = &g;
+    blockDim = block;
+    gridDim = grid;
+    const long nb = (long)grid.x * grid.y * grid.z;
+    for (;;) {
+        const long b = job.next.fetch_add(1);
+        if (b >= nb) break;
+        blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
+        g.alive = nt;
+        g.blk_arrived = 0;
+        for (int w = 0; w < nw; ++w) g.wv_arrived[w] = 0;
+        for (int t = 0; t < nt; ++t) {
+            g.done[t] = 0;
+            // initial frame: six callee-saved registers, the entry as return address, a null return address above it
+            // (after the switch's `ret` the stack pointer is 8 below a 16-byte boundary, as after a call)
+            void** top = (void**)(g.stacks[t] + kStackBytes - 64);
+            for (int i = 0; i < 6; ++i) top[i] = nullptr;
+            top[6] = (void*)&fiber_entry;
+            top[7] = nullptr;
+            g.sp[t] = top;
+        }
+        switch_to(g, -1, 0);        // returns when every lane of the workgroup has finished
+    }
+    tl_wg = outer;
+    dyn_smem = nullptr;
+}
+}  // namespace emu
+template <typename F> static void emu_launch_coop(dim3 grid, dim3 block, size_t shm, F f) {
+    emu::CoopJob<F> job;
+    job.grid = grid;
+    job.block = block;
+    job.shm = shm;
+    job.f = &f;
+    const long nb = (long)grid.x * grid.y * grid.z;
+    const bool serial = emu::serial_hint;
+    emu::serial_hint = false;
+    emu::run_on(serial ? 1 : (int)std::min<long>(nb, emu::max_workers()), &emu::coop_worker<F>, &job);
+}
+template <typename F> struct SimpleJob {
+    dim3 grid, block;
+    const F* f;
+    std::atomic<long> next{0};
+};
+template <typename F> static void emu_simple_worker(void* jp) {
+    SimpleJob<F>& job = *(SimpleJob<F>*)jp;
+    const dim3 grid = job.grid, block = job.block;
+    const long nb = (long)grid.x * grid.y * grid.z;
+    blockDim = block;
+    gridDim = grid;
+    for (;;) {
+        const long b = job.next.fetch_add(1);
+        if (b >= nb) break;
+        blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
+        for (unsigned tz = 0; tz < block.z; ++tz)
+            for (unsigned ty = 0; ty < block.y; ++ty)
+                for (unsigned tx = 0; tx < block.x; ++tx) {
+                    threadIdx = dim3(tx, ty, tz);
+                    (*job.f)();
+                }
+    }
 }
 template <typename F> static void emu_launch_simple(dim3 grid, dim3 block, F f) {
+    SimpleJob<F> job;
+    job.grid = grid;
+    job.block = block;
+    job.f = &f;
     const long nb = (long)grid.x * grid.y * grid.z;
-    const int nw = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::atomic<long> next{0};
-    std::vector<std::thread> th;
-    for (int w = 0; w < nw; ++w) {
-        th.emplace_back([&] {
-            blockDim = block;
-            gridDim = grid;
-            for (;;) {
-                long b = next.fetch_add(1);
-                if (b >= nb) break;
-                blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
-                for (unsigned tz = 0; tz < block.z; ++tz)
-                    for (unsigned ty = 0; ty < block.y; ++ty)
-                        for (unsigned tx = 0; tx < block.x; ++tx) {
-                            threadIdx = dim3(tx, ty, tz);
-                            f();
-                        }
-            }
-        });
-    }
-    for (auto& x : th) x.join();
+    emu::run_on((int)std::min<long>(nb, emu::max_workers()), &emu_simple_worker<F>, &job);
 }
-#define GVFI_LAUNCH_COOP(kernel, grid, block, stream, ...) emu_launch_coop(grid, block, [=] { kernel(__VA_ARGS__); })
+#define GVFI_LAUNCH_COOP(kernel, grid, block, stream, ...) emu_launch_coop(grid, block, 0, [=] { kernel(__VA_ARGS__); })
 #define GVFI_DYN_SMEM(name) unsigned char* name = emu::dyn_smem
-#define GVFI_LAUNCH_COOP_SHM(kernel, grid, block, shm, stream, ...)                       \
-    do {                                                                                  \
-        std::vector<uint32_t> gvfi_dyn_((size_t)(shm) / 4 + 64, 0xdeadbeefu);             \
-        emu::dyn_smem = reinterpret_cast<unsigned char*>(                                 \
-            (reinterpret_cast<uintptr_t>(gvfi_dyn_.data()) + 63) & ~(uintptr_t)63);       \
-        emu_launch_coop(grid, block, [=] { kernel(__VA_ARGS__); });                       \
-        emu::dyn_smem = nullptr;                                                          \
-    } while (0)
+#define GVFI_LAUNCH_COOP_SHM(kernel, grid, block, shm, stream, ...) emu_launch_coop(grid, block, (size_t)(shm), [=] { kernel(__VA_ARGS__); })
+// the next coop launch combines its workgroups through float atomics: keep the block order (one worker)
+#define GVFI_EMU_SERIAL(cond) (emu::serial_hint = (cond))
 #define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) emu_launch_simple(grid, block, [=] { kernel(__VA_ARGS__); })
