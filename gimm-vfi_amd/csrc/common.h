@@ -1,6 +1,6 @@
 // Shared device/host helpers for the GIMM-VFI HIP kernels (gfx950 / CDNA4 only).
 //
-// The same sources are also compiled for the host by tests/hostsim (a thread-per-lane
+// The same sources are also compiled for the host by tests/hostsim (a lane-level
 // emulator used ONLY by the CPU test-suite to check index math before a GPU run);
 // GVFI_HOSTSIM selects that build.  The product library is always the hipcc build.
 #pragma once

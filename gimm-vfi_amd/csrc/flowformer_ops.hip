@@ -106,7 +106,7 @@ extern "C" int gvfi_layernorm(const void* x, int ldx, int x_f32, const float* ga
     const bool vec = (C % ve) == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && (ldy % ve) == 0 &&
                      (((uintptr_t)y) & 15) == 0 && (((uintptr_t)x) & 15) == 0 && ((ldx * xbytes) & 15) == 0;
 #ifdef GVFI_HOSTSIM
-    // the emulator runs cooperative launches with one OS thread per lane: keep the CPU suite fast, the vector kernel
+    // the emulator runs cooperative launches lane by lane: keep the CPU suite fast, the vector kernel
     // is exercised by the unit tests at small row counts
     const bool vec_ok_rows = rows <= 256;
     const long long r4_min = 65;       // ... and let those unit tests reach the four-row variant too
@@ -339,7 +339,7 @@ extern "C" int gvfi_cost_lookup(const float* maps, const float* coords, void* ou
 // A/B switch of the MFMA attention kernels (attn_mfma.hip): GVFI_ATTN_MFMA=0 keeps the scalar kernels below
 static bool attn_mfma_enabled() {
 #ifdef GVFI_HOSTSIM
-    // emulator: only on request (a thread per lane makes whole-model emulations with MFMA attention take minutes); read at
+    // emulator: only on request (the engine-level emulations with a torch statement of the convolutions stay at seconds); read at
     // every call so that a kernel test can switch it on inside a long-lived test process
     const char* eh = getenv("GVFI_ATTN_MFMA");
     return eh != nullptr && eh[0] == '1';

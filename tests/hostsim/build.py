@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY: compiles gimm-vfi_amd/csrc/*.hip for the HOST with the
-thread-per-lane emulator header (hip_emu.h) so CPU tests can exercise kernel index math.
+lane-level emulator header (hip_emu.h: lanes as fibers) so CPU tests can exercise kernel index math.
 The result (tests/hostsim/_build/libgimmvfi_hostsim.so) is never loaded by the product."""
 import os
 import subprocess
@@ -13,13 +13,22 @@ LIB = os.path.join(OUT, "libgimmvfi_hostsim.so")
 CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
+def _fma_flag():
+    """std::fmaf (the emulated fp32 MFMA) as one instruction where the host has it -- exactly rounded either way."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            return ["-mfma"] if " fma " in f.read().replace("\n", " ") else []
+    except OSError:
+        return []
+
+
 def _compile(src):
     obj = os.path.join(OUT, os.path.basename(src) + ".o")
     deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_mma.h"), os.path.join(HERE, "hip_emu.h"),
             os.path.join(ROOT, "include", "gimmvfi_hip.h")]
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in deps):
         return obj
-    cmd = [CXX, "-std=c++20", "-O2", "-DGVFI_HOSTSIM", "-ffp-contract=off", "-I", HERE, "-x", "c++", "-fPIC", "-pthread",
+    cmd = [CXX, "-std=c++20", "-O2", "-DGVFI_HOSTSIM", "-ffp-contract=off", "-I", HERE, "-x", "c++", "-fPIC", "-pthread"] + _fma_flag() + [
            "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -98,7 +98,8 @@ struct WorkGroup {
     unsigned blk_gen = 0;
     int wv_arrived[kMaxWaves], wv_size[kMaxWaves];
     unsigned wv_gen[kMaxWaves];
-    std::vector<uint32_t> xchg;             // per-wave exchange scratch: 64 lanes x 16 dwords
+    unsigned char wv_par[kMaxWaves];        // flips with every completed wave barrier: which MFMA operand buffer is free
+    std::vector<uint32_t> xchg;             // per wave: 64 lanes x 16 dwords of exchange scratch + two MFMA operand buffers of the same size
     void (*call)(const void*) = nullptr;    // the kernel body of the running launch
     const void* ctx = nullptr;
 };
@@ -106,7 +107,12 @@ inline thread_local WorkGroup* tl_wg = nullptr;
 inline thread_local unsigned char* dyn_smem = nullptr;   // dynamic LDS of the running (coop) launch: one buffer per worker
 inline thread_local int tl_lane = 0, tl_wave = 0;
 inline thread_local bool serial_hint = false;            // GVFI_EMU_SERIAL: the next coop launch of this thread runs on one worker
-inline uint32_t* wave_scratch() { return tl_wg->xchg.data() + (size_t)tl_wave * 64 * 16; }
+inline uint32_t* wave_scratch() { return tl_wg->xchg.data() + (size_t)tl_wave * 64 * 48; }
+// operand buffer of the next MFMA.  An MFMA publishes its operands, meets the wave ONCE and reads; it needs no second
+// barrier because the next MFMA publishes into the OTHER buffer, and the one after that cannot publish before every lane
+// has arrived at the barrier in between, i.e. has finished reading.  Other cross-lane operations use the first 1024 dwords
+// with barriers of their own on both sides.
+inline uint32_t* mfma_scratch() { return wave_scratch() + 1024 * (1 + tl_wg->wv_par[tl_wave]); }
 inline void lane_vars(WorkGroup& g, int t);
 inline int next_alive(const WorkGroup& g, int t) {
     do { t = t + 1 == g.nt ? 0 : t + 1; } while (g.done[t]);
@@ -139,7 +145,7 @@ inline void wave_sync() {
     const int w = tl_wave;
     const unsigned seen = g.wv_gen[w];
     ++g.progress;
-    if (++g.wv_arrived[w] == g.wv_size[w]) { g.wv_arrived[w] = 0; ++g.wv_gen[w]; return; }
+    if (++g.wv_arrived[w] == g.wv_size[w]) { g.wv_arrived[w] = 0; g.wv_par[w] ^= 1; ++g.wv_gen[w]; return; }
     wait_gen(g, &g.wv_gen[w], seen, "a wave-level operation");
 }
 inline void block_sync() {
@@ -218,26 +224,35 @@ static inline float emu_bf2f(uint16_t v) {
     std::memcpy(&f, &u, 4);
     return f;
 }
-static inline f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
-    uint32_t* s = emu::wave_scratch();
-    const int l = emu::tl_lane;
-    std::memcpy(&s[l * 16], &a, 16);
-    std::memcpy(&s[l * 16 + 4], &b, 16);
+// (every lane converts ITS eight A and eight B values to float once and publishes them -- 16 dwords, the lane's scratch row;
+// the products of two bf16 / half values are exact in float, the sums run in ascending k like before)
+template <float (*CVT)(uint16_t)> static inline const float* emu_publish_ab(const uint4& a, const uint4& b) {
+    float* base = reinterpret_cast<float*>(emu::mfma_scratch());
+    float* s = base + emu::tl_lane * 16;
+    uint16_t h[16];
+    std::memcpy(h, &a, 16);
+    std::memcpy(h + 8, &b, 16);
+    for (int i = 0; i < 16; ++i) s[i] = CVT(h[i]);
+    return base;
+}
+template <float (*CVT)(uint16_t)> static inline f32x16 emu_mfma_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
+    const float* s = emu_publish_ab<CVT>(a, b);
     emu::wave_sync();
-    const int j = l & 31, hi = l >> 5;
+    const int l = emu::tl_lane, j = l & 31, hi = l >> 5;
+    const float* pb0 = s + j * 16 + 8;
+    const float* pb1 = s + (j + 32) * 16 + 8;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float* pa0 = s + i * 16;
+        const float* pa1 = s + (i + 32) * 16;
         float acc = c[r];
-        for (int k = 0; k < 16; ++k) {
-            const uint16_t* pa = reinterpret_cast<const uint16_t*>(&s[(i + 32 * (k >> 3)) * 16]);
-            const uint16_t* pb = reinterpret_cast<const uint16_t*>(&s[(j + 32 * (k >> 3)) * 16 + 4]);
-            acc += emu_bf2f(pa[k & 7]) * emu_bf2f(pb[k & 7]);
-        }
+        for (int k = 0; k < 8; ++k) acc += pa0[k] * pb0[k];
+        for (int k = 0; k < 8; ++k) acc += pa1[k] * pb1[k];
         c[r] = acc;
     }
-    emu::wave_sync();
     return c;
 }
+static inline f32x16 mfma_bf16_32x32x16(const uint4& a, const uint4& b, f32x16 c) { return emu_mfma_32x32x16<emu_bf2f>(a, b, c); }
 // v_mfma_f32_16x16x32_bf16: A lane l holds A[m=l&15][k=8*(l>>4)+0..7]; B lane l holds B[k=8*(l>>4)+0..7][n=l&15];
 // C/D: col n = l&15, row m = 4*(l>>4) + r.
 struct f32x4 {
@@ -246,23 +261,19 @@ struct f32x4 {
     const float& operator[](int i) const { return v[i]; }
 };
 static inline f32x4 mfma_bf16_16x16x32(const uint4& a, const uint4& b, f32x4 c) {
-    uint32_t* s = emu::wave_scratch();
-    const int l = emu::tl_lane;
-    std::memcpy(&s[l * 16], &a, 16);
-    std::memcpy(&s[l * 16 + 4], &b, 16);
+    const float* s = emu_publish_ab<emu_bf2f>(a, b);
     emu::wave_sync();
-    const int n = l & 15;
+    const int l = emu::tl_lane, n = l & 15;
     for (int r = 0; r < 4; ++r) {
         const int m = 4 * (l >> 4) + r;
         float acc = c[r];
-        for (int k = 0; k < 32; ++k) {
-            const uint16_t* pa = reinterpret_cast<const uint16_t*>(&s[(m + 16 * (k >> 3)) * 16]);
-            const uint16_t* pb = reinterpret_cast<const uint16_t*>(&s[(n + 16 * (k >> 3)) * 16 + 4]);
-            acc += emu_bf2f(pa[k & 7]) * emu_bf2f(pb[k & 7]);
+        for (int kq = 0; kq < 4; ++kq) {
+            const float* pa = s + (m + 16 * kq) * 16;
+            const float* pb = s + (n + 16 * kq) * 16 + 8;
+            for (int k = 0; k < 8; ++k) acc += pa[k] * pb[k];
         }
         c[r] = acc;
     }
-    emu::wave_sync();
     return c;
 }
 // v_mfma_f32_32x32x16_f16: the same layouts with IEEE half operands
@@ -280,46 +291,20 @@ static inline float emu_h2f(uint16_t v) {
     std::memcpy(&f, &u, 4);
     return f;
 }
-static inline f32x16 mfma_f16_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
-    uint32_t* s = emu::wave_scratch();
-    const int l = emu::tl_lane;
-    std::memcpy(&s[l * 16], &a, 16);
-    std::memcpy(&s[l * 16 + 4], &b, 16);
-    emu::wave_sync();
-    const int j = l & 31, hi = l >> 5;
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float acc = c[r];
-        for (int k = 0; k < 16; ++k) {
-            const uint16_t* pa = reinterpret_cast<const uint16_t*>(&s[(i + 32 * (k >> 3)) * 16]);
-            const uint16_t* pb = reinterpret_cast<const uint16_t*>(&s[(j + 32 * (k >> 3)) * 16 + 4]);
-            acc += emu_h2f(pa[k & 7]) * emu_h2f(pb[k & 7]);
-        }
-        c[r] = acc;
-    }
-    emu::wave_sync();
-    return c;
-}
+static inline f32x16 mfma_f16_32x32x16(const uint4& a, const uint4& b, f32x16 c) { return emu_mfma_32x32x16<emu_h2f>(a, b, c); }
 // v_mfma_f32_32x32x2_f32: A lane l holds A[i=l&31][k=l>>5]; B lane l holds B[k=l>>5][j=l&31].
 static inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
-    uint32_t* s = emu::wave_scratch();
+    float* s = reinterpret_cast<float*>(emu::mfma_scratch());
     const int l = emu::tl_lane;
-    std::memcpy(&s[l * 16], &a, 4);
-    std::memcpy(&s[l * 16 + 1], &b, 4);
+    s[l * 2] = a;
+    s[l * 2 + 1] = b;
     emu::wave_sync();
     const int j = l & 31, hi = l >> 5;
+    const float b0 = s[j * 2 + 1], b1 = s[(j + 32) * 2 + 1];
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float acc = c[r];
-        for (int k = 0; k < 2; ++k) {
-            float fa, fb;
-            std::memcpy(&fa, &s[(i + 32 * k) * 16], 4);
-            std::memcpy(&fb, &s[(j + 32 * k) * 16 + 1], 4);
-            acc = std::fmaf(fa, fb, acc);
-        }
-        c[r] = acc;
+        c[r] = std::fmaf(s[(i + 32) * 2], b1, std::fmaf(s[i * 2], b0, c[r]));
     }
-    emu::wave_sync();
     return c;
 }
 
@@ -427,7 +412,7 @@ template <typename F> void coop_worker(void* jp) {
     g.done.resize(nt);
     g.tid3.resize(3 * (size_t)nt);
     while ((int)g.stacks.size() < nt) g.stacks.push_back(new_stack());
-    g.xchg.resize((size_t)nw * 64 * 16);
+    g.xchg.resize((size_t)nw * 64 * 48);
     for (int t = 0; t < nt; ++t) {
         g.tid3[3 * t] = t % block.x;
         g.tid3[3 * t + 1] = (t / block.x) % block.y;
@@ -451,7 +436,7 @@ template <typename F> void coop_worker(void* jp) {
         blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
         g.alive = nt;
         g.blk_arrived = 0;
-        for (int w = 0; w < nw; ++w) g.wv_arrived[w] = 0;
+        for (int w = 0; w < nw; ++w) g.wv_arrived[w] = 0, g.wv_par[w] = 0;
         for (int t = 0; t < nt; ++t) {
             g.done[t] = 0;
             // initial frame: six callee-saved registers, the entry as return address, a null return address above it

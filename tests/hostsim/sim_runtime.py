@@ -6,10 +6,10 @@ arguments) and every glue kernel can be checked against the oracle without a GPU
 
 * all non-convolution entry points run in the host emulator build of the real kernels
   (tests/hostsim/_build/libgimmvfi_hostsim.so);
-* convolutions run either in the emulator too (``emulate_conv=True`` - slow, used for
-  small unit shapes) or through an independent torch statement of the launch arguments
-  (``_torch_conv``), because a thread-per-lane emulation of 256-channel convolutions at
-  full resolution would take hours.
+* convolutions run either in the emulator too (``emulate_conv=True``: the kernel unit cases and the
+  whole-model emulation tests -- half a minute to two minutes per forward at 128 x 192) or through an
+  independent torch statement of the launch arguments (``_torch_conv``): a second, independent check
+  of the launch lists, and seconds per forward.
 
 Nothing here is importable from the product package.
 """
@@ -69,7 +69,7 @@ class SimRuntime(Runtime):
 
     def gru_half(self, *a, **kw):
         if not self.emulate_conv:
-            return False     # (the torch statement of the two gate convolutions runs instead: emulating the fused kernel at engine sizes takes hours)
+            return False     # (the torch statement of the two gate convolutions runs instead)
         return super().gru_half(*a, **kw)
 
     def conv_pair(self, a, b):

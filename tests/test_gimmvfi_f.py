@@ -100,7 +100,7 @@ def test_engine_f_sim_token_chains_equal_the_separate_launches(sd_f, monkeypatch
 def test_engine_f_sim_token_path_equals_the_four_launches(sd_f, monkeypatch):
     """One launch per decoder iteration for the whole flow-token path (gvfi_token_path, GVFI_F_TOKPATH=1 -- OFF by default: measured
     slower, profiles/r4_tokpath_ab_v2.txt) against the four launches it replaces (the default, GVFI_F_TOKPATH=0: look-up | chain |
-    attention | chain), same emulated engine, two iterations: bit-identical
+    attention | chain), same emulated engine, three iterations: bit-identical
     flows and frames."""
     import torch
 
@@ -115,11 +115,11 @@ def test_engine_f_sim_token_path_equals_the_four_launches(sd_f, monkeypatch):
         eng = EngineF(SimRuntime("bf16"), sd_f)
         assert eng.fuse_token_path == (sw == "1") and eng.chain_a is not None
         n0 = eng.rt.n_launch
-        outs[sw] = eng.forward(x, coords, ts, iters=2)
+        outs[sw] = eng.forward(x, coords, ts, iters=3)
         outs[sw + "n"] = eng.rt.n_launch - n0
     assert torch.equal(outs["1"]["raft_flow"], outs["0"]["raft_flow"])
     assert torch.equal(outs["1"]["imgt_pred"][0], outs["0"]["imgt_pred"][0])
-    assert outs["0n"] - outs["1n"] == 3 * 2 * 2      # three launches fewer per iteration and launch sequence (two sub-batches)
+    assert outs["0n"] - outs["1n"] == 3 * 3 * 2      # three launches fewer per iteration and launch sequence (two sub-batches)
 
 
 def test_engine_f_sim_flow_precision_policy(sd_f):
@@ -143,9 +143,8 @@ def test_engine_f_sim_flow_precision_policy(sd_f):
     p_mixed = psnr(mixed["imgt_pred"][0], gold["imgt_pred_0"])
     assert p_mixed > 50.0, p_mixed                                       # bf16 synthesis on exact flows
     # every stage-boundary conversion of the launch list: float encoder, the default (half decoder), a float token path feeding a
-    # half update block (the single-stage policies "tok" / "upd" exercise the same conversions; they ran here until the CPU
-    # suite needed trimming)
-    for pol in ("dec:f16", "upd:f16,tok", "f16"):        # ("f16": the model default since round 5; a float encoder is part of "fp32" above)
+    # half update block
+    for pol in ("enc", "dec:f16", "upd:f16,tok", "f16"):        # ("f16": the model default since round 5)
         part = EngineF(SimRuntime("bf16"), sd_f, flow_precision=pol).forward(x, coords, ts, iters=None)
         assert psnr(part["imgt_pred"][0], gold["imgt_pred_0"]) > 40.0, pol
     # an fp32 engine ignores the policy (everything is float already)
@@ -276,3 +275,21 @@ def test_gpu_f_benchmark_size_bf16_vs_fp32(sd_f):
     o32 = _run(_model(sd_f, "fp32"), x, coords, ts)
     p = psnr(o16["imgt_pred"][0], o32["imgt_pred"][0])
     assert p >= 35.0, p
+
+
+def test_whole_f_model_on_the_emulated_kernels(sd_f, monkeypatch):
+    """GIMM-VFI-F in its default precision policy (bf16 synthesis, half-precision flow estimator) with every launch on the host
+    build of the real kernels -- convolutions, the MFMA attentions, token chains: the GPU suite's golden test without a GPU."""
+    from gimmvfi_hip.engine_f import EngineF
+    from sim_runtime import SimRuntime
+
+    monkeypatch.setenv("GVFI_ATTN_MFMA", "1")        # (the emulator build keeps the scalar attention kernels unless asked)
+    meta, gold = load_golden("f_128x192_t050")
+    x, coords, ts = golden_inputs(meta)
+    rt = SimRuntime("bf16", emulate_conv=True)
+    out = EngineF(rt, sd_f, flow_precision="f16").forward(x, coords, ts, iters=None)
+    p = psnr(out["imgt_pred"][0], gold["imgt_pred_0"])
+    print(f"WHOLE-MODEL EMULATION gimmvfi_f bf16 / f16: PSNR(imgt_pred vs reference golden) = {p:.2f} dB, "
+          f"max|raft_flow err| = {maxabs(out['raft_flow'], gold['raft_flow']):.3e}")
+    assert p >= 50.0, p
+    assert maxabs(out["raft_flow"], gold["raft_flow"]) < 0.1

@@ -99,8 +99,8 @@ CONV_SHAPES = [
     (2, 37, 45, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=3)),
     (1, 33, 34, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=4)),
     (1, 12, 40, 3, 16, 7, 7, dict(algo=7, act1=L.ACT_LRELU, out_scale=0.5, pad16=True, bf16_only=True)),
-    (1, 72, 70, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=5)),         # an interior tile: tile-independent patch offsets
-    (1, 70, 71, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=6)),
+    (1, 100, 104, 9, 18, 7, 7, dict(algo=7, act1=L.ACT_PRELU, pad16=True, bf16_only=True, seed=5)),       # interior tiles: tile-independent patch offsets
+    (2, 97, 70, 18, 3, 7, 7, dict(algo=7, out_f32=True, with_res=True, res_f32=True, pad16=True, bf16_only=True, seed=6)),
     (1, 8, 33, 8, 32, 7, 7, dict(algo=7, act1=L.ACT_RELU, pad16=True, bf16_only=True)),
     (1, 6, 36, 24, 12, 7, 7, dict(algo=7, pad16=True, bf16_only=True)),
     # row-linear kernel (conv_lin.hip, algo 8): weights resident in registers, rows streamed; every (K, N) instantiation, ragged
@@ -198,8 +198,8 @@ def test_conv_pair_launch_equals_two_launches(rt):
         kc.conv_pair_case(rt, shapes=((32, 40, 1, 1), (32, 24, 3, 3)), expect_pair=False)     # float: never a pair -> two launches
         return
     kc.conv_pair_case(rt)                                                                # 1x1 || 1x1: convc1 || convf1
-    kc.conv_pair_case(rt, N=1, H=7, W=10, shapes=((128, 192, 3, 3), (64, 64, 3, 3)), seed=1)   # 3x3 || 3x3, ragged tiles: convc2 || convf2
-    kc.conv_pair_case(rt, N=1, H=3, W=200, shapes=((64, 126, 1, 1), (64, 130, 1, 1)), seed=2)  # 10 + 20 workgroups: XCD order of both grids
+    kc.conv_pair_case(rt, N=2, H=7, W=10, shapes=((128, 192, 3, 3), (64, 64, 3, 3)), seed=1)   # 3x3 || 3x3, ragged tiles: convc2 || convf2
+    kc.conv_pair_case(rt, N=1, H=5, W=200, shapes=((64, 126, 1, 1), (64, 130, 3, 3)), seed=2)  # 16 + 32 workgroups: XCD order of both grids
     kc.conv_pair_case(rt, shapes=((32, 40, 1, 1), (64, 24, 3, 3)), seed=3, expect_pair=False)  # 32 channels: not the weights-direct variant
 
 
@@ -251,7 +251,7 @@ def test_flow_step_equals_tap_sum_flow_pack_im2col(rt):
 
 
 def test_space_to_depth_form_of_the_filter_equals_stride_convolutions(rt):
-    kc.s2d_case(rt, 1, 8, 12, 3, 64, 4)          # Twins patch embedding (twins.py:720-745): 4 taps of 4 x 8 values
+    kc.s2d_case(rt, 2, 8, 12, 3, 64, 4)          # Twins patch embedding (twins.py:720-745): 4 taps of 4 x 8 values
     kc.s2d_case(rt, 1, 8, 16, 32, 32, 8, 1)      # sub-sampling convolution (twins.py:870-925; there 8 taps of 1024): 8 taps of 256
 
 
@@ -272,7 +272,7 @@ def test_col7_folded_finalisation_equals_finalize_image(rt):
     if rt.precision != "bf16":
         pytest.skip("the column kernel is bf16 only")
     kc.col7_planar_case(rt)
-    kc.col7_planar_case(rt, N=1, H=40, W=65, seed=9)      # (the GPU suite runs 70 x 71: an interior tile)
+    kc.col7_planar_case(rt, N=1, H=70, W=71, seed=9)      # (an interior tile)
 
 
 def test_softsplat_gather_is_deterministic_and_matches_the_oracle(rt):

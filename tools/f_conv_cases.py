@@ -1,6 +1,6 @@
 """Unit shapes of the convolutions the FlowFormer path adds (patch / sub-sampling convolutions with stride == kernel,
 6x6 stride-2 cost-map convolutions, token-matrix linears, grouped 'weights are activations' contractions, GELU) against
-a torch statement.  Runs on the GPU (default) or in the host emulator (--sim: real kernel sources, thread-per-lane)."""
+a torch statement.  Runs on the GPU (default) or in the host emulator (--sim: real kernel sources, lanes as fibers)."""
 import os
 import sys
 
