@@ -86,12 +86,11 @@ struct gvfi_i32x4 { const unsigned char* base; };
 static inline gvfi_i32x4 make_srd(const void* base) { return gvfi_i32x4{(const unsigned char*)base}; }
 #define GVFI_DMA_OOB 0xffffff00u
 // host emulation: an "LDS address" is an offset from a per-thread-block base pointer registered by lds_address()
-inline thread_local unsigned char* gvfi_emu_lds_base = nullptr;
-static inline unsigned lds_address(const void* p) { gvfi_emu_lds_base = (unsigned char*)p; return 0u; }
+static inline unsigned lds_address(const void* p) { emu::tl.lds_base = (unsigned char*)p; return 0u; }
 static inline void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned soff, unsigned lds_addr) {
     static const unsigned char zeros[16] = {0};
     emu_glds16(voff >= 0x7fffff00u - soff ? (const void*)zeros : (const void*)(srd.base + soff + voff),
-               gvfi_emu_lds_base + lds_addr);
+               emu::tl.lds_base + lds_addr);
 }
 static inline void glds_wait() {}
 template <int N> static inline void glds_wait_n() {}

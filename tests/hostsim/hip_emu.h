@@ -39,7 +39,7 @@
 
 struct dim3 {
     unsigned x, y, z;
-    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint4 { uint32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
@@ -103,16 +103,24 @@ struct WorkGroup {
     void (*call)(const void*) = nullptr;    // the kernel body of the running launch
     const void* ctx = nullptr;
 };
-inline thread_local WorkGroup* tl_wg = nullptr;
-inline thread_local unsigned char* dyn_smem = nullptr;   // dynamic LDS of the running (coop) launch: one buffer per worker
-inline thread_local int tl_lane = 0, tl_wave = 0;
-inline thread_local bool serial_hint = false;            // GVFI_EMU_SERIAL: the next coop launch of this thread runs on one worker
-inline uint32_t* wave_scratch() { return tl_wg->xchg.data() + (size_t)tl_wave * 64 * 48; }
+// Everything a lane reads often lives in ONE thread_local object: in a dlopen'ed library every thread_local VARIABLE costs a
+// __tls_get_addr call per use site, and the cross-lane operations sit in the kernels' inner loops.  (The address of a
+// thread_local is fixed for an OS thread; fibers never migrate.)
+struct LaneState {
+    WorkGroup* wg = nullptr;
+    int lane = 0, wave = 0;                  // of the running fiber
+    dim3 tid, bid, bdim, gdim;               // threadIdx, blockIdx, blockDim, gridDim
+    unsigned char* dyn_smem = nullptr;          // dynamic LDS of the running (coop) launch: one buffer per worker
+    unsigned char* lds_base = nullptr;       // conv_mma.h: base of the object lds_address() was last asked about
+    bool serial_hint = false;                // GVFI_EMU_SERIAL: the next coop launch of this thread runs on one worker
+};
+inline constinit thread_local LaneState tl;      // (constant-initialised: no guard / wrapper call on access)
+inline uint32_t* wave_scratch() { return tl.wg->xchg.data() + (size_t)tl.wave * 64 * 48; }
 // operand buffer of the next MFMA.  An MFMA publishes its operands, meets the wave ONCE and reads; it needs no second
 // barrier because the next MFMA publishes into the OTHER buffer, and the one after that cannot publish before every lane
 // has arrived at the barrier in between, i.e. has finished reading.  Other cross-lane operations use the first 1024 dwords
 // with barriers of their own on both sides.
-inline uint32_t* mfma_scratch() { return wave_scratch() + 1024 * (1 + tl_wg->wv_par[tl_wave]); }
+inline uint32_t* mfma_scratch() { return wave_scratch() + 1024 * (1 + tl.wg->wv_par[tl.wave]); }
 inline void lane_vars(WorkGroup& g, int t);
 inline int next_alive(const WorkGroup& g, int t) {
     do { t = t + 1 == g.nt ? 0 : t + 1; } while (g.done[t]);
@@ -141,15 +149,15 @@ inline void wait_gen(WorkGroup& g, const unsigned* gen, unsigned seen, const cha
     }
 }
 inline void wave_sync() {
-    WorkGroup& g = *tl_wg;
-    const int w = tl_wave;
+    WorkGroup& g = *tl.wg;
+    const int w = tl.wave;
     const unsigned seen = g.wv_gen[w];
     ++g.progress;
     if (++g.wv_arrived[w] == g.wv_size[w]) { g.wv_arrived[w] = 0; g.wv_par[w] ^= 1; ++g.wv_gen[w]; return; }
     wait_gen(g, &g.wv_gen[w], seen, "a wave-level operation");
 }
 inline void block_sync() {
-    WorkGroup& g = *tl_wg;
+    WorkGroup& g = *tl.wg;
     const unsigned seen = g.blk_gen;
     ++g.progress;
     if (++g.blk_arrived == g.nt) { g.blk_arrived = 0; ++g.blk_gen; return; }
@@ -157,7 +165,7 @@ inline void block_sync() {
 }
 // first frame of every fiber: run the kernel body for this lane, then hand over for good
 inline void fiber_entry() {
-    WorkGroup& g = *tl_wg;
+    WorkGroup& g = *tl.wg;
     g.call(g.ctx);
     const int me = g.cur;
     g.done[me] = 1;
@@ -168,10 +176,13 @@ inline void fiber_entry() {
 }
 }  // namespace emu
 
-inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define threadIdx (emu::tl.tid)
+#define blockIdx (emu::tl.bid)
+#define blockDim (emu::tl.bdim)
+#define gridDim (emu::tl.gdim)
 inline void emu::lane_vars(WorkGroup& g, int t) {
-    tl_lane = t & 63;
-    tl_wave = t >> 6;
+    tl.lane = t & 63;
+    tl.wave = t >> 6;
     threadIdx = dim3(g.tid3[3 * t], g.tid3[3 * t + 1], g.tid3[3 * t + 2]);
 }
 
@@ -182,7 +193,7 @@ template <typename V> static inline V emu_shfl_from(V v, int src_lane) {
     uint32_t* s = emu::wave_scratch();
     uint32_t bits;
     std::memcpy(&bits, &v, 4);
-    s[emu::tl_lane * 16] = bits;
+    s[emu::tl.lane * 16] = bits;
     emu::wave_sync();
     uint32_t o = s[(src_lane & 63) * 16];
     emu::wave_sync();
@@ -190,10 +201,10 @@ template <typename V> static inline V emu_shfl_from(V v, int src_lane) {
     std::memcpy(&r, &o, 4);
     return r;
 }
-template <typename V> static inline V __shfl_xor(V v, int mask) { return emu_shfl_from(v, emu::tl_lane ^ mask); }
+template <typename V> static inline V __shfl_xor(V v, int mask) { return emu_shfl_from(v, emu::tl.lane ^ mask); }
 template <typename V> static inline V __shfl_down(V v, int d) {
-    int src = emu::tl_lane + d;
-    return emu_shfl_from(v, src > 63 ? emu::tl_lane : src);
+    int src = emu::tl.lane + d;
+    return emu_shfl_from(v, src > 63 ? emu::tl.lane : src);
 }
 
 static inline float atomicAdd(float* p, float v) {
@@ -228,7 +239,7 @@ static inline float emu_bf2f(uint16_t v) {
 // the products of two bf16 / half values are exact in float, the sums run in ascending k like before)
 template <float (*CVT)(uint16_t)> static inline const float* emu_publish_ab(const uint4& a, const uint4& b) {
     float* base = reinterpret_cast<float*>(emu::mfma_scratch());
-    float* s = base + emu::tl_lane * 16;
+    float* s = base + emu::tl.lane * 16;
     uint16_t h[16];
     std::memcpy(h, &a, 16);
     std::memcpy(h + 8, &b, 16);
@@ -238,7 +249,7 @@ template <float (*CVT)(uint16_t)> static inline const float* emu_publish_ab(cons
 template <float (*CVT)(uint16_t)> static inline f32x16 emu_mfma_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
     const float* s = emu_publish_ab<CVT>(a, b);
     emu::wave_sync();
-    const int l = emu::tl_lane, j = l & 31, hi = l >> 5;
+    const int l = emu::tl.lane, j = l & 31, hi = l >> 5;
     const float* pb0 = s + j * 16 + 8;
     const float* pb1 = s + (j + 32) * 16 + 8;
     for (int r = 0; r < 16; ++r) {
@@ -263,7 +274,7 @@ struct f32x4 {
 static inline f32x4 mfma_bf16_16x16x32(const uint4& a, const uint4& b, f32x4 c) {
     const float* s = emu_publish_ab<emu_bf2f>(a, b);
     emu::wave_sync();
-    const int l = emu::tl_lane, n = l & 15;
+    const int l = emu::tl.lane, n = l & 15;
     for (int r = 0; r < 4; ++r) {
         const int m = 4 * (l >> 4) + r;
         float acc = c[r];
@@ -295,7 +306,7 @@ static inline f32x16 mfma_f16_32x32x16(const uint4& a, const uint4& b, f32x16 c)
 // v_mfma_f32_32x32x2_f32: A lane l holds A[i=l&31][k=l>>5]; B lane l holds B[k=l>>5][j=l&31].
 static inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     float* s = reinterpret_cast<float*>(emu::mfma_scratch());
-    const int l = emu::tl_lane;
+    const int l = emu::tl.lane;
     s[l * 2] = a;
     s[l * 2 + 1] = b;
     emu::wave_sync();
@@ -312,7 +323,7 @@ static inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
 #include <cassert>
 static inline void emu_glds16(const void* gsrc, unsigned char* lds_wave_base) {
     uint32_t* s = emu::wave_scratch();
-    const int l = emu::tl_lane;
+    const int l = emu::tl.lane;
     uint64_t b = reinterpret_cast<uint64_t>(lds_wave_base);
     std::memcpy(&s[l * 16], &b, 8);
     emu::wave_sync();
@@ -423,10 +434,10 @@ template <typename F> void coop_worker(void* jp) {
     g.ctx = job.f;
     if (job.shm) {
         dyn.assign(job.shm / 4 + 64, 0xdeadbeefu);
-        dyn_smem = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(dyn.data()) + 63) & ~(uintptr_t)63);
+        tl.dyn_smem = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(dyn.data()) + 63) & ~(uintptr_t)63);
     }
-    WorkGroup* outer = tl_wg;
-    tl_wg = &g;
+    WorkGroup* outer = tl.wg;
+    tl.wg = &g;
     blockDim = block;
     gridDim = grid;
     const long nb = (long)grid.x * grid.y * grid.z;
@@ -449,8 +460,8 @@ template <typename F> void coop_worker(void* jp) {
         }
         switch_to(g, -1, 0);        // returns when every lane of the workgroup has finished
     }
-    tl_wg = outer;
-    dyn_smem = nullptr;
+    tl.wg = outer;
+    tl.dyn_smem = nullptr;
 }
 }  // namespace emu
 template <typename F> static void emu_launch_coop(dim3 grid, dim3 block, size_t shm, F f) {
@@ -460,8 +471,8 @@ template <typename F> static void emu_launch_coop(dim3 grid, dim3 block, size_t 
     job.shm = shm;
     job.f = &f;
     const long nb = (long)grid.x * grid.y * grid.z;
-    const bool serial = emu::serial_hint;
-    emu::serial_hint = false;
+    const bool serial = emu::tl.serial_hint;
+    emu::tl.serial_hint = false;
     emu::run_on(serial ? 1 : (int)std::min<long>(nb, emu::max_workers()), &emu::coop_worker<F>, &job);
 }
 template <typename F> struct SimpleJob {
@@ -496,8 +507,8 @@ template <typename F> static void emu_launch_simple(dim3 grid, dim3 block, F f) 
     emu::run_on((int)std::min<long>(nb, emu::max_workers()), &emu_simple_worker<F>, &job);
 }
 #define GVFI_LAUNCH_COOP(kernel, grid, block, stream, ...) emu_launch_coop(grid, block, 0, [=] { kernel(__VA_ARGS__); })
-#define GVFI_DYN_SMEM(name) unsigned char* name = emu::dyn_smem
+#define GVFI_DYN_SMEM(name) unsigned char* name = emu::tl.dyn_smem
 #define GVFI_LAUNCH_COOP_SHM(kernel, grid, block, shm, stream, ...) emu_launch_coop(grid, block, (size_t)(shm), [=] { kernel(__VA_ARGS__); })
 // the next coop launch combines its workgroups through float atomics: keep the block order (one worker)
-#define GVFI_EMU_SERIAL(cond) (emu::serial_hint = (cond))
+#define GVFI_EMU_SERIAL(cond) (emu::tl.serial_hint = (cond))
 #define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) emu_launch_simple(grid, block, [=] { kernel(__VA_ARGS__); })
