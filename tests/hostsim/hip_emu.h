@@ -374,6 +374,8 @@ inline void pool_worker(Pool* p, int id) {
 // run fn(arg) on `n` threads at once (the caller is one of them)
 inline void run_on(int n, void (*fn)(void*), void* arg) {
     if (n <= 1) { fn(arg); return; }
+    static std::mutex one_job;                   // (launches from two host threads at once take turns: the pool holds one job)
+    std::lock_guard<std::mutex> turn(one_job);
     Pool*& p = pool_ptr();
     if (p == nullptr || p->pid != getpid()) {      // (after a fork the parent's workers do not exist here)
         p = new Pool;
