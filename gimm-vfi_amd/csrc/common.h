@@ -18,6 +18,8 @@
 #ifndef GVFI_HOSTSIM
 // (emulator only: a launch whose workgroups meet in float atomics keeps its block order; nothing on the device)
 #define GVFI_EMU_SERIAL(cond) ((void)0)
+// (emulator only: a plain vector load that a kernel's counted s_waitcnt includes -- tests/hostsim's adversarial LDS-DMA timing)
+#define GVFI_EMU_VMEM_OP() ((void)0)
 // simple = no LDS / barriers / cross-lane ops;  coop = anything else.  Identical on device.
 #define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

@@ -315,7 +315,10 @@ __device__ __forceinline__ void conv_igemm_glds_body(const ConvArgs2& a, const i
         for (int j = 0; j < NI; ++j) {
             const unsigned char* src = wfrag[j] + (size_t)kt_ * wf_chunk;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) bq[slot][j][kk] = *(const uint4*)(src + kk * 1024);
+            for (int kk = 0; kk < KK; ++kk) {
+                bq[slot][j][kk] = *(const uint4*)(src + kk * 1024);
+                GVFI_EMU_VMEM_OP();
+            }
         }
     };
     // ---- prologue: fill the ring with chunks 0 .. AHEAD-1

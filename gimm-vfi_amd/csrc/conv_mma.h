@@ -92,8 +92,8 @@ static inline void bufdma16(unsigned voff, gvfi_i32x4 srd, unsigned soff, unsign
     emu_glds16(voff >= 0x7fffff00u - soff ? (const void*)zeros : (const void*)(srd.base + soff + voff),
                emu::tl.lds_base + lds_addr);
 }
-static inline void glds_wait() {}
-template <int N> static inline void glds_wait_n() {}
+static inline void glds_wait() { emu::dma_retire(0); }
+template <int N> static inline void glds_wait_n() { emu::dma_retire(N); }
 #endif
 
 // instruction-scheduling fence: nothing is moved across it (keeps hand-written software pipelining in place)

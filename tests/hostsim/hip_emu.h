@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -85,6 +86,23 @@ namespace emu {
 constexpr size_t kStackBytes = 512u << 10;      // per lane; only touched pages are ever resident
 constexpr int kMaxWaves = 32;
 
+// ---- adversarial LDS-DMA timing (GVFI_EMU_DMA=1, or gvfi_emu_set_dma_mode(1) on the test library) ----------------------------
+// On the GPU an LDS-DMA lands some time between its issue and the `s_waitcnt vmcnt(N)` that covers it; a kernel is correct only
+// if it is correct for EVERY such time.  Mode 0 lands it at issue.  Mode 1 plays both extremes at once: the destination is
+// poisoned (NaN patterns) at issue -- the old contents are gone as early as possible: a slot re-filled while a slower wave still
+// reads it is caught -- and the data arrive only at the wait that covers them, as late as possible: a missing or too lenient
+// counted wait, or a read in front of the barrier that publishes a chunk, reads NaNs.  Every lane keeps the FIFO of its
+// outstanding operations (vmcnt retires in order); plain vector loads that a kernel includes in its counts are entered with
+// GVFI_EMU_VMEM_OP().  Loads the model does not see only make it stricter than the hardware, never more lenient.
+// Mode 2 (negative control of the tests): counted waits (N > 0) retire nothing.
+struct PendingDma {
+    const void* src;          // nullptr: a plain vector-memory operation (occupies a place in the count, moves nothing)
+    unsigned char* dst;
+};
+inline int& dma_mode() {
+    static int m = [] { const char* e = std::getenv("GVFI_EMU_DMA"); return e ? std::atoi(e) : 0; }();
+    return m;
+}
 // one workgroup in flight on this OS thread
 struct WorkGroup {
     int nt = 0, cur = -1, alive = 0;
@@ -100,6 +118,7 @@ struct WorkGroup {
     unsigned wv_gen[kMaxWaves];
     unsigned char wv_par[kMaxWaves];        // flips with every completed wave barrier: which MFMA operand buffer is free
     std::vector<uint32_t> xchg;             // per wave: 64 lanes x 16 dwords of exchange scratch + two MFMA operand buffers of the same size
+    std::vector<std::deque<PendingDma>> pend;   // (GVFI_EMU_DMA) per lane: vector-memory operations issued and not yet awaited
     void (*call)(const void*) = nullptr;    // the kernel body of the running launch
     const void* ctx = nullptr;
 };
@@ -163,10 +182,30 @@ inline void block_sync() {
     if (++g.blk_arrived == g.nt) { g.blk_arrived = 0; ++g.blk_gen; return; }
     wait_gen(g, &g.blk_gen, seen, "__syncthreads");
 }
+inline void dma_retire(int keep) {
+    if (tl.wg == nullptr || tl.wg->pend.empty()) return;
+    std::deque<PendingDma>& q = tl.wg->pend[tl.wg->cur];
+    if (keep > 0 && dma_mode() == 2) return;
+    while ((int)q.size() > keep) {
+        const PendingDma e = q.front();
+        q.pop_front();
+        if (e.src != nullptr) std::memcpy(e.dst, e.src, 16);
+    }
+}
+inline void dma_issue(const void* src, unsigned char* dst) {
+    if (dma_mode() == 0) { std::memcpy(dst, src, 16); return; }
+    static const uint32_t poison[4] = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};     // NaN as bf16, half and float
+    std::memcpy(dst, poison, 16);
+    tl.wg->pend[tl.wg->cur].push_back(PendingDma{src, dst});
+}
+inline void vmem_op() {
+    if (dma_mode() != 0 && tl.wg != nullptr && !tl.wg->pend.empty()) tl.wg->pend[tl.wg->cur].push_back(PendingDma{nullptr, nullptr});
+}
 // first frame of every fiber: run the kernel body for this lane, then hand over for good
 inline void fiber_entry() {
     WorkGroup& g = *tl.wg;
     g.call(g.ctx);
+    dma_retire(0);     // (the end of the kernel: whatever is still in flight lands)
     const int me = g.cur;
     g.done[me] = 1;
     ++g.progress;
@@ -331,7 +370,7 @@ static inline void emu_glds16(const void* gsrc, unsigned char* lds_wave_base) {
     std::memcpy(&b0, &s[0], 8);
     if (b0 != b) { std::fprintf(stderr, "emu_glds16: LDS base is not wave-uniform\n"); std::abort(); }
     emu::wave_sync();
-    std::memcpy(lds_wave_base + l * 16, gsrc, 16);
+    emu::dma_issue(gsrc, lds_wave_base + l * 16);
 }
 
 // ---- launches -----------------------------------------------------------------------------
@@ -449,6 +488,10 @@ template <typename F> void coop_worker(void* jp) {
         blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
         g.alive = nt;
         g.blk_arrived = 0;
+        if (dma_mode() != 0) {
+            g.pend.resize(nt);
+            for (auto& q : g.pend) q.clear();
+        } else g.pend.clear();
         for (int w = 0; w < nw; ++w) g.wv_arrived[w] = 0, g.wv_par[w] = 0;
         for (int t = 0; t < nt; ++t) {
             g.done[t] = 0;
@@ -513,4 +556,7 @@ template <typename F> static void emu_launch_simple(dim3 grid, dim3 block, F f) 
 #define GVFI_LAUNCH_COOP_SHM(kernel, grid, block, shm, stream, ...) emu_launch_coop(grid, block, (size_t)(shm), [=] { kernel(__VA_ARGS__); })
 // the next coop launch combines its workgroups through float atomics: keep the block order (one worker)
 #define GVFI_EMU_SERIAL(cond) (emu::tl.serial_hint = (cond))
+// a plain vector-memory operation that the kernel's counted waits include (see the adversarial LDS-DMA timing above)
+#define GVFI_EMU_VMEM_OP() emu::vmem_op()
+extern "C" __attribute__((weak)) void gvfi_emu_set_dma_mode(int m) { emu::dma_mode() = m; }
 #define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) emu_launch_simple(grid, block, [=] { kernel(__VA_ARGS__); })

@@ -1,6 +1,8 @@
 """CPU checks of the HIP kernel sources through the host emulator build (tests/hostsim): index math,
 LDS addressing, barriers, epilogues and edge cases, before any GPU minute is spent.  The same cases
 run against the real library in tests/test_gpu_kernels.py."""
+import os
+
 import pytest
 
 import kernel_cases as kc
@@ -332,3 +334,25 @@ def test_fp16_convolutions_and_gru():
     kc.tap_split_conv_case(rt16)
     kc.patch_conv_case(rt16)
     kc.corr_volume_case(rt16)
+
+
+@pytest.mark.skipif(bool(os.environ.get("GVFI_EMU_DMA")), reason="already inside the adversarial run")
+def test_kernel_cases_under_adversarial_lds_dma_timing():
+    """Every emulated kernel case again with GVFI_EMU_DMA=1 (tests/hostsim/hip_emu.h): an LDS-DMA poisons its destination at
+    issue and delivers the data only at the `s_waitcnt vmcnt(N)` that covers it -- the latest and the earliest the hardware may
+    land it, at once.  A missing or too lenient counted wait, a read in front of the barrier that publishes a chunk, a ring slot
+    re-filled while a slower wave still reads it, a DMA landing in the epilogue's staging area: all read NaNs here, on every run,
+    where the GPU would fail now and then.  Negative control: with the counted waits disabled (mode 2) the same cases must FAIL."""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    files = [os.path.join(root, "tests", f) for f in ("test_hostsim_kernels.py", "test_kernels_f.py")]
+    base = [sys.executable, "-m", "pytest", "-q", "-m", "not gpu", "-p", "no:cacheprovider"]
+    r = subprocess.run(base + files, capture_output=True, text=True, env=dict(os.environ, GVFI_EMU_DMA="1"), cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:]
+    print("adversarial LDS-DMA timing:", r.stdout.strip().splitlines()[-1])
+    r2 = subprocess.run(base + files[:1] + ["-k", "p3x3s_conv_is_bit_identical or conv_pair_launch or gru_half_as_one_launch"],
+                        capture_output=True, text=True, env=dict(os.environ, GVFI_EMU_DMA="2"), cwd=root)
+    assert r2.returncode != 0 and " failed" in r2.stdout, r2.stdout[-2000:]
+    print("negative control (counted waits retire nothing):", r2.stdout.strip().splitlines()[-1])
