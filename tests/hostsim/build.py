@@ -39,6 +39,7 @@ def _compile(src):
 def build():
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    srcs += sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))     # (the emulator's own self-test kernels)
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(_compile, srcs))
     # objects of sources that no longer exist (a deleted kernel file) are pruned: the library is linked from `objs` only, but a

@@ -106,6 +106,7 @@ inline int& dma_mode() {
 // one workgroup in flight on this OS thread
 struct WorkGroup {
     int nt = 0, cur = -1, alive = 0;
+    bool reverse = false, depth_first = false;      // the schedule of this launch (sched_mode())
     void* main_sp = nullptr;
     std::vector<void*> sp;                  // saved stack pointer per fiber
     std::vector<unsigned char> done;
@@ -141,8 +142,37 @@ inline uint32_t* wave_scratch() { return tl.wg->xchg.data() + (size_t)tl.wave * 
 // with barriers of their own on both sides.
 inline uint32_t* mfma_scratch() { return wave_scratch() + 1024 * (1 + tl.wg->wv_par[tl.wave]); }
 inline void lane_vars(WorkGroup& g, int t);
+// ---- schedules (GVFI_EMU_SCHED, or gvfi_emu_set_sched() on the test library) -------------------------------------------------
+// A kernel with all its barriers computes the same thing under EVERY interleaving of its waves; one that lacks a barrier does
+// not.  The default runs the lanes round-robin in thread order, which keeps the waves within one synchronisation step of
+// each other and so hides such races.  bit 0: the waves take their turns in REVERSE order (lanes of a wave stay in order: the
+// kernels mark intra-wave exchanges with wave-level syncs only where lock-step execution does not already order them for the
+// round-robin).  bit 1: DEPTH first -- a lane waiting for its wave hands over to lanes of the SAME wave only, so a wave runs
+// ahead alone until a workgroup barrier (or its end) stops it: the largest skew between waves the barriers allow.
+inline int& sched_mode() {
+    static int m = [] { const char* e = std::getenv("GVFI_EMU_SCHED"); return e ? std::atoi(e) : 0; }();
+    return m;
+}
 inline int next_alive(const WorkGroup& g, int t) {
+    if (g.reverse) {          // thread order with the waves reversed: wave w, lane l -> next lane of w, then wave w - 1
+        do {
+            const int w = t >> 6, l = t & 63;
+            if (l + 1 < g.wv_size[w]) t = t + 1;
+            else t = (w == 0 ? (g.nt - 1) >> 6 : w - 1) << 6;
+        } while (g.done[t]);
+        return t;
+    }
     do { t = t + 1 == g.nt ? 0 : t + 1; } while (g.done[t]);
+    return t;
+}
+// the next unfinished lane of t's own wave (t itself when there is no other)
+inline int next_in_wave(const WorkGroup& g, int t) {
+    const int w = t >> 6, n = g.wv_size[w];
+    int l = t & 63;
+    for (int i = 0; i < n; ++i) {
+        l = l + 1 == n ? 0 : l + 1;
+        if (!g.done[(w << 6) + l]) return (w << 6) + l;
+    }
     return t;
 }
 // leave fiber `from` (-1: the worker's own context) for fiber `to` (-1: back to the worker)
@@ -156,15 +186,18 @@ inline void switch_to(WorkGroup& g, int from, int to) {
     std::abort();
 }
 // wait until *gen moves on from `seen`, running the other lanes meanwhile
-inline void wait_gen(WorkGroup& g, const unsigned* gen, unsigned seen, const char* what) {
+inline void wait_gen(WorkGroup& g, const unsigned* gen, unsigned seen, const char* what, bool wave_level) {
     unsigned long long last = g.progress;
     int idle = 0;
     while (*(volatile const unsigned*)gen == seen) {
-        const int me = g.cur, to = next_alive(g, me);
+        const int me = g.cur;
+        int to = me;
+        if (wave_level && g.depth_first && idle <= 64) to = next_in_wave(g, me);      // (idle: the rest of the wave waits elsewhere)
+        if (to == me) to = next_alive(g, me);
         if (to == me) deadlock(what);
         switch_to(g, me, to);
         if (g.progress != last) { last = g.progress; idle = 0; }
-        else if (++idle > g.nt + 2) deadlock(what);
+        else if (++idle > g.nt + 66) deadlock(what);
     }
 }
 inline void wave_sync() {
@@ -173,14 +206,14 @@ inline void wave_sync() {
     const unsigned seen = g.wv_gen[w];
     ++g.progress;
     if (++g.wv_arrived[w] == g.wv_size[w]) { g.wv_arrived[w] = 0; g.wv_par[w] ^= 1; ++g.wv_gen[w]; return; }
-    wait_gen(g, &g.wv_gen[w], seen, "a wave-level operation");
+    wait_gen(g, &g.wv_gen[w], seen, "a wave-level operation", true);
 }
 inline void block_sync() {
     WorkGroup& g = *tl.wg;
     const unsigned seen = g.blk_gen;
     ++g.progress;
     if (++g.blk_arrived == g.nt) { g.blk_arrived = 0; ++g.blk_gen; return; }
-    wait_gen(g, &g.blk_gen, seen, "__syncthreads");
+    wait_gen(g, &g.blk_gen, seen, "__syncthreads", false);
 }
 inline void dma_retire(int keep) {
     if (tl.wg == nullptr || tl.wg->pend.empty()) return;
@@ -472,6 +505,8 @@ template <typename F> void coop_worker(void* jp) {
     }
     for (int w = 0; w < nw; ++w) g.wv_size[w] = std::min(64, nt - 64 * w);
     g.call = [](const void* c) { (*(const F*)c)(); };
+    g.reverse = (sched_mode() & 1) != 0;
+    g.depth_first = (sched_mode() & 2) != 0;
     g.ctx = job.f;
     if (job.shm) {
         dyn.assign(job.shm / 4 + 64, 0xdeadbeefu);
@@ -503,7 +538,7 @@ template <typename F> void coop_worker(void* jp) {
             top[7] = nullptr;
             g.sp[t] = top;
         }
-        switch_to(g, -1, 0);        // returns when every lane of the workgroup has finished
+        switch_to(g, -1, g.reverse ? ((nt - 1) >> 6) << 6 : 0);        // returns when every lane of the workgroup has finished
     }
     tl.wg = outer;
     tl.dyn_smem = nullptr;
@@ -559,4 +594,5 @@ template <typename F> static void emu_launch_simple(dim3 grid, dim3 block, F f) 
 // a plain vector-memory operation that the kernel's counted waits include (see the adversarial LDS-DMA timing above)
 #define GVFI_EMU_VMEM_OP() emu::vmem_op()
 extern "C" __attribute__((weak)) void gvfi_emu_set_dma_mode(int m) { emu::dma_mode() = m; }
+extern "C" __attribute__((weak)) void gvfi_emu_set_sched(int m) { emu::sched_mode() = m; }
 #define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) emu_launch_simple(grid, block, [=] { kernel(__VA_ARGS__); })

@@ -116,10 +116,12 @@ def test_whole_model_on_the_emulated_kernels(precision, name, sd):
     x, coords, ts = golden_inputs(meta)
     rt = SimRuntime(precision, emulate_conv=True)
     rt.lib.dll.gvfi_emu_set_dma_mode(1)       # (adversarial LDS-DMA timing, tests/hostsim/hip_emu.h: same results, or NaNs)
+    rt.lib.dll.gvfi_emu_set_sched(3)          # (... and the waves in reverse order, depth first)
     try:
         out = Engine(rt, sd).forward(x, coords, ts, ds_factor=meta["ds"])
     finally:
         rt.lib.dll.gvfi_emu_set_dma_mode(0)
+        rt.lib.dll.gvfi_emu_set_sched(0)
     assert maxabs(out["raft_flow"], gold["raft_flow"]) < (1e-4 if precision == "fp32" else 0.1)
     for i in range(len(meta["t"])):
         p = psnr(out["imgt_pred"][i], gold[f"imgt_pred_{i}"])

@@ -288,10 +288,12 @@ def test_whole_f_model_on_the_emulated_kernels(sd_f, monkeypatch):
     x, coords, ts = golden_inputs(meta)
     rt = SimRuntime("bf16", emulate_conv=True)
     rt.lib.dll.gvfi_emu_set_dma_mode(1)       # (adversarial LDS-DMA timing, tests/hostsim/hip_emu.h)
+    rt.lib.dll.gvfi_emu_set_sched(3)          # (... and the waves in reverse order, depth first)
     try:
         out = EngineF(rt, sd_f, flow_precision="f16").forward(x, coords, ts, iters=None)
     finally:
         rt.lib.dll.gvfi_emu_set_dma_mode(0)
+        rt.lib.dll.gvfi_emu_set_sched(0)
     p = psnr(out["imgt_pred"][0], gold["imgt_pred_0"])
     print(f"WHOLE-MODEL EMULATION gimmvfi_f bf16 / f16: PSNR(imgt_pred vs reference golden) = {p:.2f} dB, "
           f"max|raft_flow err| = {maxabs(out['raft_flow'], gold['raft_flow']):.3e}")

@@ -342,16 +342,19 @@ def test_kernel_cases_under_adversarial_lds_dma_timing():
     issue and delivers the data only at the `s_waitcnt vmcnt(N)` that covers it -- the latest and the earliest the hardware may
     land it, at once.  A missing or too lenient counted wait, a read in front of the barrier that publishes a chunk, a ring slot
     re-filled while a slower wave still reads it, a DMA landing in the epilogue's staging area: all read NaNs here, on every run,
-    where the GPU would fail now and then.  Negative control: with the counted waits disabled (mode 2) the same cases must FAIL."""
+    where the GPU would fail now and then.  Together with it the emulator's other wave schedules (GVFI_EMU_SCHED: reversed wave
+    order, depth first, both): a kernel with all its barriers computes the same under every interleaving of its waves.
+    Negative controls: with the counted waits disabled (DMA mode 2) the same cases must FAIL; tests/test_emulator_selftest.py."""
     import subprocess
     import sys
 
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    files = [os.path.join(root, "tests", f) for f in ("test_hostsim_kernels.py", "test_kernels_f.py")]
+    files = [os.path.join(root, "tests", f) for f in ("test_hostsim_kernels.py", "test_kernels_f.py", "test_alt_corr.py")]
     base = [sys.executable, "-m", "pytest", "-q", "-m", "not gpu", "-p", "no:cacheprovider"]
-    r = subprocess.run(base + files, capture_output=True, text=True, env=dict(os.environ, GVFI_EMU_DMA="1"), cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:]
-    print("adversarial LDS-DMA timing:", r.stdout.strip().splitlines()[-1])
+    for sched in ("3", "1", "2"):
+        r = subprocess.run(base + files, capture_output=True, text=True, env=dict(os.environ, GVFI_EMU_DMA="1", GVFI_EMU_SCHED=sched), cwd=root)
+        assert r.returncode == 0, (sched, r.stdout[-3000:])
+        print(f"adversarial LDS-DMA timing, schedule {sched}:", r.stdout.strip().splitlines()[-1])
     r2 = subprocess.run(base + files[:1] + ["-k", "p3x3s_conv_is_bit_identical or conv_pair_launch or gru_half_as_one_launch"],
                         capture_output=True, text=True, env=dict(os.environ, GVFI_EMU_DMA="2"), cwd=root)
     assert r2.returncode != 0 and " failed" in r2.stdout, r2.stdout[-2000:]
