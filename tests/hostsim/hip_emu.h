@@ -541,6 +541,14 @@ template <typename F> void coop_worker(void* jp) {
         switch_to(g, -1, g.reverse ? ((nt - 1) >> 6) << 6 : 0);        // returns when every lane of the workgroup has finished
     }
     tl.wg = outer;
+    if (job.shm) {      // the words behind the dynamic LDS must still hold the fill pattern: a write past the end of the allocation
+        const uint32_t* w = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(tl.dyn_smem) + job.shm + 3) & ~(uintptr_t)3);
+        for (const uint32_t* e = dyn.data() + dyn.size(); w < e; ++w)
+            if (*w != 0xdeadbeefu) {
+                std::fprintf(stderr, "hip_emu: a kernel wrote behind its %zu bytes of dynamic LDS\n", job.shm);
+                std::abort();
+            }
+    }
     tl.dyn_smem = nullptr;
 }
 }  // namespace emu
