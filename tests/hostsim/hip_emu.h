@@ -106,13 +106,15 @@ inline int& dma_mode() {
 // one workgroup in flight on this OS thread
 struct WorkGroup {
     int nt = 0, cur = -1, alive = 0;
-    bool reverse = false, depth_first = false;      // the schedule of this launch (sched_mode())
+    bool reverse = false, depth_first = false, random = false;      // the schedule of this launch (sched_mode())
+    uint32_t rng = 1;
     void* main_sp = nullptr;
     std::vector<void*> sp;                  // saved stack pointer per fiber
     std::vector<unsigned char> done;
     std::vector<unsigned char*> stacks;     // mmap'ed once per worker thread, reused by every launch
     std::vector<unsigned> tid3;             // threadIdx (x, y, z) per fiber
-    unsigned long long progress = 0;        // arrivals + completions + exits: a full round without any = deadlock
+    std::vector<const unsigned*> wait_on;   // per lane: the barrier generation it waits to move on from (nullptr: not waiting)
+    std::vector<unsigned> wait_seen;
     int blk_arrived = 0;
     unsigned blk_gen = 0;
     int wv_arrived[kMaxWaves], wv_size[kMaxWaves];
@@ -149,31 +151,17 @@ inline void lane_vars(WorkGroup& g, int t);
 // kernels mark intra-wave exchanges with wave-level syncs only where lock-step execution does not already order them for the
 // round-robin).  bit 1: DEPTH first -- a lane waiting for its wave hands over to lanes of the SAME wave only, so a wave runs
 // ahead alone until a workgroup barrier (or its end) stops it: the largest skew between waves the barriers allow.
+// bit 2: RANDOM -- a waiting lane hands over to the first unfinished lane of a wave drawn at random (xorshift, seeded per
+// workgroup from GVFI_EMU_SEED and the block index: reproducible): interleavings of three and more waves that the fixed
+// orders never produce.  Every mode explores ONE interleaving per workgroup (3 is not a superset of 1 and 2): the suite runs its
+// kernel cases under 1, 2, 3 and a random one.
+inline uint32_t& sched_seed() {
+    static uint32_t v = [] { const char* e = std::getenv("GVFI_EMU_SEED"); return e ? (uint32_t)std::atoi(e) : 1u; }();
+    return v;
+}
 inline int& sched_mode() {
     static int m = [] { const char* e = std::getenv("GVFI_EMU_SCHED"); return e ? std::atoi(e) : 0; }();
     return m;
-}
-inline int next_alive(const WorkGroup& g, int t) {
-    if (g.reverse) {          // thread order with the waves reversed: wave w, lane l -> next lane of w, then wave w - 1
-        do {
-            const int w = t >> 6, l = t & 63;
-            if (l + 1 < g.wv_size[w]) t = t + 1;
-            else t = (w == 0 ? (g.nt - 1) >> 6 : w - 1) << 6;
-        } while (g.done[t]);
-        return t;
-    }
-    do { t = t + 1 == g.nt ? 0 : t + 1; } while (g.done[t]);
-    return t;
-}
-// the next unfinished lane of t's own wave (t itself when there is no other)
-inline int next_in_wave(const WorkGroup& g, int t) {
-    const int w = t >> 6, n = g.wv_size[w];
-    int l = t & 63;
-    for (int i = 0; i < n; ++i) {
-        l = l + 1 == n ? 0 : l + 1;
-        if (!g.done[(w << 6) + l]) return (w << 6) + l;
-    }
-    return t;
 }
 // leave fiber `from` (-1: the worker's own context) for fiber `to` (-1: back to the worker)
 inline void switch_to(WorkGroup& g, int from, int to) {
@@ -185,33 +173,59 @@ inline void switch_to(WorkGroup& g, int from, int to) {
     std::fprintf(stderr, "hip_emu: deadlock in %s (a lane left the kernel, or took another path, while the others wait)\n", what);
     std::abort();
 }
+// a lane is runnable when it has not finished and is not waiting, or the barrier it waits for has completed meanwhile
+inline bool runnable(const WorkGroup& g, int t) {
+    return !g.done[t] && (g.wait_on[t] == nullptr || *(volatile const unsigned*)g.wait_on[t] != g.wait_seen[t]);
+}
+// the lane that runs next when lane `me` cannot go on: the first RUNNABLE one in the order of the launch's schedule
+// (-1: nobody -- every unfinished lane waits for a barrier that cannot complete)
+inline int pick_next(WorkGroup& g, int me, bool wave_level) {
+    if (wave_level && g.depth_first) {          // own wave first
+        const int w = me >> 6, n = g.wv_size[w];
+        for (int i = 1, l = me & 63; i < n; ++i) {
+            l = l + 1 == n ? 0 : l + 1;
+            if (runnable(g, (w << 6) + l)) return (w << 6) + l;
+        }
+    }
+    int t = me;
+    if (g.random) {                              // start the search at the head of a wave drawn at random
+        g.rng ^= g.rng << 13; g.rng ^= g.rng >> 17; g.rng ^= g.rng << 5;
+        const int nw = (g.nt + 63) >> 6;
+        t = ((int)(g.rng % (uint32_t)nw) << 6);
+        if (t != me && runnable(g, t)) return t;
+    }
+    for (int i = 0; i < g.nt; ++i) {
+        if (g.reverse) {                         // thread order with the waves reversed: next lane of the wave, then wave w - 1
+            const int w = t >> 6, l = t & 63;
+            if (l + 1 < g.wv_size[w]) t = t + 1;
+            else t = (w == 0 ? (g.nt - 1) >> 6 : w - 1) << 6;
+        } else t = t + 1 == g.nt ? 0 : t + 1;
+        if (t != me && runnable(g, t)) return t;
+    }
+    return -1;
+}
 // wait until *gen moves on from `seen`, running the other lanes meanwhile
 inline void wait_gen(WorkGroup& g, const unsigned* gen, unsigned seen, const char* what, bool wave_level) {
-    unsigned long long last = g.progress;
-    int idle = 0;
+    const int me = g.cur;
+    g.wait_on[me] = gen;
+    g.wait_seen[me] = seen;
     while (*(volatile const unsigned*)gen == seen) {
-        const int me = g.cur;
-        int to = me;
-        if (wave_level && g.depth_first && idle <= 64) to = next_in_wave(g, me);      // (idle: the rest of the wave waits elsewhere)
-        if (to == me) to = next_alive(g, me);
-        if (to == me) deadlock(what);
+        const int to = pick_next(g, me, wave_level);
+        if (to < 0) deadlock(what);
         switch_to(g, me, to);
-        if (g.progress != last) { last = g.progress; idle = 0; }
-        else if (++idle > g.nt + 66) deadlock(what);
     }
+    g.wait_on[me] = nullptr;
 }
 inline void wave_sync() {
     WorkGroup& g = *tl.wg;
     const int w = tl.wave;
     const unsigned seen = g.wv_gen[w];
-    ++g.progress;
     if (++g.wv_arrived[w] == g.wv_size[w]) { g.wv_arrived[w] = 0; g.wv_par[w] ^= 1; ++g.wv_gen[w]; return; }
     wait_gen(g, &g.wv_gen[w], seen, "a wave-level operation", true);
 }
 inline void block_sync() {
     WorkGroup& g = *tl.wg;
     const unsigned seen = g.blk_gen;
-    ++g.progress;
     if (++g.blk_arrived == g.nt) { g.blk_arrived = 0; ++g.blk_gen; return; }
     wait_gen(g, &g.blk_gen, seen, "__syncthreads", false);
 }
@@ -241,9 +255,12 @@ inline void fiber_entry() {
     dma_retire(0);     // (the end of the kernel: whatever is still in flight lands)
     const int me = g.cur;
     g.done[me] = 1;
-    ++g.progress;
     if (--g.alive == 0) switch_to(g, me, -1);
-    else switch_to(g, me, next_alive(g, me));
+    else {
+        const int to = pick_next(g, me, true);
+        if (to < 0) deadlock("the end of a lane");
+        switch_to(g, me, to);
+    }
     std::abort();      // (a finished fiber is never resumed)
 }
 }  // namespace emu
@@ -495,6 +512,8 @@ template <typename F> void coop_worker(void* jp) {
     g.nt = nt;
     g.sp.resize(nt);
     g.done.resize(nt);
+    g.wait_on.assign(nt, nullptr);
+    g.wait_seen.assign(nt, 0u);
     g.tid3.resize(3 * (size_t)nt);
     while ((int)g.stacks.size() < nt) g.stacks.push_back(new_stack());
     g.xchg.resize((size_t)nw * 64 * 48);
@@ -507,6 +526,7 @@ template <typename F> void coop_worker(void* jp) {
     g.call = [](const void* c) { (*(const F*)c)(); };
     g.reverse = (sched_mode() & 1) != 0;
     g.depth_first = (sched_mode() & 2) != 0;
+    g.random = (sched_mode() & 4) != 0;
     g.ctx = job.f;
     if (job.shm) {
         dyn.assign(job.shm / 4 + 64, 0xdeadbeefu);
@@ -523,6 +543,8 @@ template <typename F> void coop_worker(void* jp) {
         blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
         g.alive = nt;
         g.blk_arrived = 0;
+        g.rng = (sched_seed() * 2654435761u) ^ ((uint32_t)b * 40503u + 0x9e3779b9u);
+        if (g.rng == 0) g.rng = 1;
         if (dma_mode() != 0) {
             g.pend.resize(nt);
             for (auto& q : g.pend) q.clear();
@@ -530,6 +552,7 @@ template <typename F> void coop_worker(void* jp) {
         for (int w = 0; w < nw; ++w) g.wv_arrived[w] = 0, g.wv_par[w] = 0;
         for (int t = 0; t < nt; ++t) {
             g.done[t] = 0;
+            g.wait_on[t] = nullptr;
             // initial frame: six callee-saved registers, the entry as return address, a null return address above it
             // (after the switch's `ret` the stack pointer is 8 below a 16-byte boundary, as after a call)
             void** top = (void**)(g.stacks[t] + kStackBytes - 64);
@@ -603,4 +626,5 @@ template <typename F> static void emu_launch_simple(dim3 grid, dim3 block, F f) 
 #define GVFI_EMU_VMEM_OP() emu::vmem_op()
 extern "C" __attribute__((weak)) void gvfi_emu_set_dma_mode(int m) { emu::dma_mode() = m; }
 extern "C" __attribute__((weak)) void gvfi_emu_set_sched(int m) { emu::sched_mode() = m; }
+extern "C" __attribute__((weak)) void gvfi_emu_set_seed(int v) { emu::sched_seed() = (uint32_t)v; }
 #define GVFI_LAUNCH_SIMPLE(kernel, grid, block, stream, ...) emu_launch_simple(grid, block, [=] { kernel(__VA_ARGS__); })

@@ -32,5 +32,23 @@ def test_deliberate_hazards_are_caught_by_the_mode_made_for_them(sched, dma):
         dll.gvfi_emu_set_dma_mode(0)
     # (hazard version passes?, fixed version passes?)
     assert got["race"] == (not (sched & 1), True), got       # no barrier between producer and consumer wave: reversed wave order
-    assert got["skew"] == (not (sched & 2), True), got       # waves that must not drift apart: depth first
+    assert got["skew"] == (sched != 2, True), got            # waves that must not drift apart: depth first (in thread order: in the
+    #                                                          reversed order the PRODUCER is the wave that runs ahead -- every mode is ONE
+    #                                                          interleaving, which is why the suite runs its kernel cases under several)
     assert got["dma"] == (dma == 0, True), got               # LDS read without the vmcnt wait: adversarial DMA timing
+
+
+def test_random_schedules_find_the_missing_barrier_for_some_seed_and_never_fault_the_fixed_kernel():
+    dll = hostsim_lib().dll
+    src = (C.c_ubyte * 1024)(*[(i * 7 + 3) & 255 for i in range(1024)])
+    caught = 0
+    try:
+        dll.gvfi_emu_set_sched(4)
+        for seed in range(1, 9):
+            dll.gvfi_emu_set_seed(seed)
+            caught += not _run(dll, 0, 0, src)
+            assert _run(dll, 0, 1, src) and _run(dll, 2, 1, src), seed
+    finally:
+        dll.gvfi_emu_set_sched(0)
+        dll.gvfi_emu_set_seed(1)
+    assert caught >= 2, caught

@@ -351,7 +351,7 @@ def test_kernel_cases_under_adversarial_lds_dma_timing():
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     files = [os.path.join(root, "tests", f) for f in ("test_hostsim_kernels.py", "test_kernels_f.py", "test_alt_corr.py")]
     base = [sys.executable, "-m", "pytest", "-q", "-m", "not gpu", "-p", "no:cacheprovider"]
-    for sched in ("3", "1", "2"):
+    for sched in ("3", "1", "2", "4"):          # reverse + depth first, reverse, depth first, random (seed 1)
         r = subprocess.run(base + files, capture_output=True, text=True, env=dict(os.environ, GVFI_EMU_DMA="1", GVFI_EMU_SCHED=sched), cwd=root)
         assert r.returncode == 0, (sched, r.stdout[-3000:])
         print(f"adversarial LDS-DMA timing, schedule {sched}:", r.stdout.strip().splitlines()[-1])
