@@ -86,7 +86,7 @@ namespace emu {
 constexpr size_t kStackBytes = 512u << 10;      // per lane; only touched pages are ever resident
 constexpr int kMaxWaves = 32;
 
-// ---- adversarial LDS-DMA timing (GVFI_EMU_DMA=1, or gvfi_emu_set_dma_mode(1) on the test library) ----------------------------
+// ---- adversarial LDS-DMA timing (GVFI_EMU_DMA=1, the default; gvfi_emu_set_dma_mode() on the test library) -------------------
 // On the GPU an LDS-DMA lands some time between its issue and the `s_waitcnt vmcnt(N)` that covers it; a kernel is correct only
 // if it is correct for EVERY such time.  Mode 0 lands it at issue.  Mode 1 plays both extremes at once: the destination is
 // poisoned (NaN patterns) at issue -- the old contents are gone as early as possible: a slot re-filled while a slower wave still
@@ -100,7 +100,7 @@ struct PendingDma {
     unsigned char* dst;
 };
 inline int& dma_mode() {
-    static int m = [] { const char* e = std::getenv("GVFI_EMU_DMA"); return e ? std::atoi(e) : 0; }();
+    static int m = [] { const char* e = std::getenv("GVFI_EMU_DMA"); return e ? std::atoi(e) : 1; }();      // (the strict mode is the default)
     return m;
 }
 // one workgroup in flight on this OS thread

@@ -29,7 +29,7 @@ def test_deliberate_hazards_are_caught_by_the_mode_made_for_them(sched, dma):
         got = {name: (_run(dll, which, 0, src), _run(dll, which, 1, src)) for name, which in (("race", 0), ("dma", 1), ("skew", 2))}
     finally:
         dll.gvfi_emu_set_sched(0)
-        dll.gvfi_emu_set_dma_mode(0)
+        dll.gvfi_emu_set_dma_mode(1)      # (the emulator's default)
     # (hazard version passes?, fixed version passes?)
     assert got["race"] == (not (sched & 1), True), got       # no barrier between producer and consumer wave: reversed wave order
     assert got["skew"] == (sched != 2, True), got            # waves that must not drift apart: depth first (in thread order: in the

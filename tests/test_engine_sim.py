@@ -120,7 +120,6 @@ def test_whole_model_on_the_emulated_kernels(precision, name, sd):
     try:
         out = Engine(rt, sd).forward(x, coords, ts, ds_factor=meta["ds"])
     finally:
-        rt.lib.dll.gvfi_emu_set_dma_mode(0)
         rt.lib.dll.gvfi_emu_set_sched(0)
     assert maxabs(out["raft_flow"], gold["raft_flow"]) < (1e-4 if precision == "fp32" else 0.1)
     for i in range(len(meta["t"])):

@@ -292,7 +292,6 @@ def test_whole_f_model_on_the_emulated_kernels(sd_f, monkeypatch):
     try:
         out = EngineF(rt, sd_f, flow_precision="f16").forward(x, coords, ts, iters=None)
     finally:
-        rt.lib.dll.gvfi_emu_set_dma_mode(0)
         rt.lib.dll.gvfi_emu_set_sched(0)
     p = psnr(out["imgt_pred"][0], gold["imgt_pred_0"])
     print(f"WHOLE-MODEL EMULATION gimmvfi_f bf16 / f16: PSNR(imgt_pred vs reference golden) = {p:.2f} dB, "

@@ -336,7 +336,7 @@ def test_fp16_convolutions_and_gru():
     kc.corr_volume_case(rt16)
 
 
-@pytest.mark.skipif(bool(os.environ.get("GVFI_EMU_DMA")), reason="already inside the adversarial run")
+@pytest.mark.skipif(bool(os.environ.get("GVFI_EMU_SCHED")), reason="already inside the adversarial run")
 def test_kernel_cases_under_adversarial_lds_dma_timing():
     """Every emulated kernel case again with GVFI_EMU_DMA=1 (tests/hostsim/hip_emu.h): an LDS-DMA poisons its destination at
     issue and delivers the data only at the `s_waitcnt vmcnt(N)` that covers it -- the latest and the earliest the hardware may
