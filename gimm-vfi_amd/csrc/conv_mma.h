@@ -96,13 +96,39 @@ static inline void glds_wait() { emu::dma_retire(0); }
 template <int N> static inline void glds_wait_n() { emu::dma_retire(N); }
 #endif
 
+// 16-byte buffer store with a per-lane byte offset relative to a wave-uniform base (offsets >= num_records are dropped: a
+// masked lane uses GVFI_DMA_OOB and the INSTRUCTION is still issued, so counted s_waitcnt stay exact).  The scalar-offset
+// operand stays 0 ON PURPOSE: hipcc (ROCm 7.2) assumes that a buffer store of more than 8 bytes WITH a register soffset may
+// have its data registers overwritten by the next VALU instruction, and gfx950 says otherwise -- measured: the first dword of
+// one store in ~500 replaced by the address the compiler computed into that register right behind it.  Without a register
+// soffset the compiler pads the hazard itself.
+#ifndef GVFI_HOSTSIM
+typedef __amdgpu_buffer_rsrc_t gvfi_rsrc_t;
+__device__ __forceinline__ gvfi_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffff00, 0x00020000);
+}
+__device__ __forceinline__ void bufst16(const uint4& v, gvfi_rsrc_t r, unsigned voff) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, 0, 0);
+}
+#else
+struct gvfi_rsrc_t { unsigned char* base; };
+static inline gvfi_rsrc_t make_rsrc(const void* base) { return gvfi_rsrc_t{(unsigned char*)base}; }
+static inline void bufst16(const uint4& v, gvfi_rsrc_t r, unsigned voff) {
+    GVFI_EMU_VMEM_OP();      // (takes its place in the lane's in-order queue of vector-memory operations)
+    if (voff < 0x7fffff00u) memcpy(r.base + voff, &v, 16);
+}
+#endif
+
 // instruction-scheduling fence: nothing is moved across it (keeps hand-written software pipelining in place)
 #ifndef GVFI_HOSTSIM
 #define GVFI_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define GVFI_OPAQUE_V(x) asm volatile("" : "+v"(x))      /* the compiler may not derive anything about x across this point */
+#define GVFI_OPAQUE_S(x) asm volatile("" : "+s"(x))      /* ... a wave-uniform x */
 #else
 #define GVFI_SCHED_BARRIER() ((void)0)
 #define GVFI_OPAQUE_V(x) ((void)0)
+#define GVFI_OPAQUE_S(x) ((void)0)
 #endif
 
 template <typename T> struct Mma2;

@@ -23,6 +23,8 @@
 #else
 #define P3_WAVE_SYNC() emu::wave_sync()
 #endif
+// (a wave-uniform value the compiler keeps in a VGPR -- e.g. derived from an integer division -- for an SGPR asm operand)
+#define P3_UNIFORM(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
 #define P3_TH 16
 #define P3_TW 16
 #define P3_PW (P3_TW + 2)
@@ -37,13 +39,147 @@ struct P3Args {
     gvfi_conv_params p;
     int chunks0, chunks;        // 64-channel chunks of source 0 / of both sources
     int tiles_x, tiles_y, mtiles, ntiles_n, per_xcd;
+    int slots;                  // (stream kernel) workgroups per XCD: the grid is 8 x slots
 };
+
+// ---- wave-private epilogue ----------------------------------------------------------------------------------------------
+// y = act2(act1(acc + bias) + res) * out_scale for ONE wave's 128 pixels x 64 channels, in four passes of 32 pixels (one
+// accumulator row block i each) through two 4 KB staging regions of LDS that belong to this wave alone -- no workgroup barrier
+// anywhere: a pass writes its 8-byte pieces (lane = pixel, 4 consecutive channels), reads them back as 16-byte units
+// (8 lanes = the 128 bytes one pixel has in this wave's channel range) and stores four times 8 pixels x 128 bytes, whole
+// cache lines.  Row `px` of a region keeps its 16-byte unit u at slot u ^ ((px >> 1) & 7): the 64 lanes of a ds_write_b64 cover
+// the 64 banks twice, the 16 lanes of a ds_read_b128 group (two pixels) once.  The residual of a pass arrives by LDS-DMA in
+// the same layout (pre-swizzled on the source side), two passes ahead, and the result overwrites it in place.
+// Vector-memory order of a wave (they retire in order; the counted waits below rely on it):
+//   DMA0 DMA1 | st0 DMA2 | st1 DMA3 | st2 | st3      (4 instructions each; without a residual only the stores)
+// Same arithmetic and order as the workgroup-wide form below: bit-identical.
+// reg0: byte offset of the wave's 2 x 4 KB inside smem; pix0: pixel index of the tile's first pixel; the tile's row r is pixel
+// (y0 + r / 16, x0 + r % 16).
+template <bool RES, bool SC>
+__device__ __forceinline__ void p3_wave_epilogue(const gvfi_conv_params& p, f32x16 (&acc)[4][2], unsigned char* smem, unsigned smem_lds,
+                                                 unsigned reg0, const float* ptab, int lane, int wm, int wn, long long pix0, int y0,
+                                                 int x0, int n0) {
+    const int px = lane & 31, fhalf = lane >> 5, fsw = (px >> 1) & 7;
+    const int q0 = lane >> 3, un = lane & 7;
+    const float inf = __builtin_inff();
+    const gvfi_rsrc_t rs_y = make_rsrc((const bf16_t*)p.y + pix0 * p.ldy + n0 + wn * 64);
+    const gvfi_i32x4 srd_r = make_srd(RES ? (const bf16_t*)p.res + pix0 * p.ldr + n0 + wn * 64 : (const bf16_t*)p.y);
+    // per-lane byte offsets of its pixel column x = q0 / q0 + 8 (k even / odd); the pixel row enters as a scalar offset
+    unsigned yv[2], rv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int xx = q0 + 8 * h;
+        const bool ok = x0 + xx < p.W;
+        yv[h] = ok ? (unsigned)((xx * p.ldy + un * 8) * 2) : GVFI_DMA_OOB;
+        rv[h] = ok ? (unsigned)((xx * p.ldr + ((un ^ (q0 >> 1) ^ (4 * h)) * 8)) * 2) : GVFI_DMA_OOB;
+    }
+    auto res_dma = [&](int i) {      // residual of pass i -> its staging region
+        if (!RES) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yy = wm * 8 + i * 2 + (k >> 1);
+            const bool oky = y0 + yy < p.H;
+            bufdma16(oky ? rv[k & 1] : GVFI_DMA_OOB, srd_r, (unsigned)(yy * p.W * p.ldr * 2), smem_lds + reg0 + (unsigned)((i & 1) * 4096 + k * 1024));
+        }
+    };
+    res_dma(0);
+    res_dma(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned reg = reg0 + (unsigned)((i & 1) * 4096);
+        if (RES) {
+            // in flight behind pass i's residual: i = 0: DMA1; i = 1: st0 DMA2; i = 2: st1 DMA3; i = 3: st2
+            if (i == 1 || i == 2) glds_wait_n<8>(); else glds_wait_n<4>();
+            P3_WAVE_SYNC();
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = wn * 64 + j * 32 + 8 * g + 4 * fhalf;          // first of this lane's 4 channels (within the tile)
+                const float4 b4 = *(const float4*)(ptab + c0), s4 = *(const float4*)(ptab + 256 + c0);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, s1[4] = {s4.x, s4.y, s4.z, s4.w};
+                float s2[4] = {1.f, 1.f, 1.f, 1.f};
+                if (RES) {
+                    const float4 z4 = *(const float4*)(ptab + 512 + c0);
+                    s2[0] = z4.x; s2[1] = z4.y; s2[2] = z4.z; s2[3] = z4.w;
+                }
+                unsigned char* sp = smem + reg + px * 128 + (((j * 4 + g) ^ fsw) << 4) + fhalf * 8;
+                float vv[4];
+#ifndef GVFI_HOSTSIM
+                {   // packed pairs: v_pk_add_f32 / v_pk_mul_f32
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f2 a2 = {acc[i][j][4 * g + 2 * h], acc[i][j][4 * g + 2 * h + 1]};
+                        const f2 t2 = a2 + f2{bb[2 * h], bb[2 * h + 1]};
+                        const f2 st = t2 * f2{s1[2 * h], s1[2 * h + 1]};
+                        vv[2 * h] = med3f(t2.x, st.x, s1[2 * h] <= 1.f ? inf : -inf);
+                        vv[2 * h + 1] = med3f(t2.y, st.y, s1[2 * h + 1] <= 1.f ? inf : -inf);
+                    }
+                }
+#else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[i][j][4 * g + e] + bb[e];
+                    vv[e] = med3f(t, s1[e] * t, s1[e] <= 1.f ? inf : -inf);
+                }
+#endif
+                if (RES) {
+                    const uint2 ru = *(const uint2*)sp;
+                    vv[0] += __builtin_bit_cast(float, ru.x << 16);
+                    vv[1] += __builtin_bit_cast(float, ru.x & 0xffff0000u);
+                    vv[2] += __builtin_bit_cast(float, ru.y << 16);
+                    vv[3] += __builtin_bit_cast(float, ru.y & 0xffff0000u);
+#ifndef GVFI_HOSTSIM
+                    {
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f2 t2 = {vv[2 * h], vv[2 * h + 1]};
+                            const f2 st = t2 * f2{s2[2 * h], s2[2 * h + 1]};
+                            vv[2 * h] = med3f(t2.x, st.x, s2[2 * h] <= 1.f ? inf : -inf);
+                            vv[2 * h + 1] = med3f(t2.y, st.y, s2[2 * h + 1] <= 1.f ? inf : -inf);
+                        }
+                    }
+#else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] = med3f(vv[e], s2[e] * vv[e], s2[e] <= 1.f ? inf : -inf);
+#endif
+                }
+                if (SC) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] *= p.out_scale;
+                }
+                uint2 u;
+                u.x = pack_bf16x2(vv[0], vv[1]);
+                u.y = pack_bf16x2(vv[2], vv[3]);
+                *(uint2*)sp = u;
+            }
+        }
+        P3_WAVE_SYNC();
+        uint4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = k * 8 + q0;
+            t[k] = *(const uint4*)(smem + reg + q * 128 + ((un ^ ((q >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yy = wm * 8 + i * 2 + (k >> 1);
+            const bool oky = y0 + yy < p.H;
+            bufst16(t[k], rs_y, oky && yv[k & 1] != GVFI_DMA_OOB ? yv[k & 1] + (unsigned)(yy * p.W * p.ldy * 2) : GVFI_DMA_OOB);
+        }
+        if (i < 2) res_dma(i + 2);
+    }
+}
 
 // 8 waves of 128 x 64, 2 per SIMD.  (Measured and dropped: 4 waves of 128 x 128 with 256 accumulator registers -- a third
 // fewer LDS fragment reads per MFMA, but one wave per SIMD: 0.965 vs 0.861 ms on the 8 x 256 x 448 256->256 layer.)
 // PROF (algo bit 15): wave 0 adds up shader-clock cycles per phase into aux1[block * 4 + {prologue, K loop, of which waiting
 // for the DMA + barrier, epilogue}] (tools/p3x3_timeline.py)
-template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3Args a) {
+// VAR bit 0: wave-private epilogue (p3_wave_epilogue) instead of the workgroup-wide staging tile
+template <bool PROF, int VAR> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3Args a) {
     typedef bf16_t T;
     constexpr int WAVES_N = 4;
     constexpr int NW = 2 * WAVES_N, NT = NW * 64, WM = 128, WN = 256 / WAVES_N, MI = 4, NI = WN / 32, BN = 256, BM = 256, RB = 128, KK = 4;
@@ -271,6 +407,22 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
     };
     const bool has_sc = p.out_scale != 1.0f, has_res = p.res != nullptr;
     const float* ptab = (const float*)(smem + PTAB);
+    if constexpr ((VAR & 1) != 0) {
+        // wave-private epilogue (p3_wave_epilogue): one barrier (every wave has read its last fragments), then each wave stages,
+        // reads back and stores its own 128 x 64 part of the tile with no further workgroup synchronisation
+        __syncthreads();
+        const long long pix0 = img_pix + (long long)y0 * p.W + x0;
+        const unsigned reg0 = (unsigned)wave * 8192u;
+        if (has_res) {
+            if (has_sc) p3_wave_epilogue<true, true>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+            else p3_wave_epilogue<true, false>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+        } else {
+            if (has_sc) p3_wave_epilogue<false, true>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+            else p3_wave_epilogue<false, false>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+        }
+        prof_out();
+        return;
+    }
     __syncthreads();   // every wave is done reading the last staged step
     if (has_res) {
         // residual tile -> staging area (same layout: the result overwrites it in place), 128 DMA instructions of 2 rows
@@ -399,6 +551,316 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_kernel(P3A
     prof_out();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same convolution as ONE STREAM of channel chunks per compute unit (algo bit 14; Cout == 256).  The kernel above pays, per
+// 256 x 256 tile, a prologue (2-3 k cycles: the first patch + weight stage arrive before any MFMA), an epilogue behind two
+// workgroup barriers (9.5 k, 21 k with a residual) and a workgroup turn-over (the LDS admits one workgroup per CU: the next one
+// starts when the last store of this one has retired) -- 12-25 % of a tile's time with the matrix pipe idle.  Here a workgroup
+// is PERSISTENT (one per CU, tiles t_begin + k * slots of its XCD's contiguous range) and the LDS-DMA ring never drains: during the
+// last channel chunk of tile k the patch of chunk 0 of tile k + 1 streams into the other patch buffer (taps 0-5) and its first
+// weight stage behind tap 8, exactly like any other next chunk.  The epilogue is wave-private (p3_wave_epilogue): after the
+// barrier of the tile's last step the patch buffer and the weight stage that step read are dead -- waves 0-3 stage in the former,
+// waves 4-7 in the latter (8 KB each) --, the stores are fire-and-forget (they retire under the next tile's K loop), one barrier
+// ends the epilogue (the staging areas are the next step's DMA targets) and the accumulators are re-initialised by the first MFMA
+// of the next tile taking a zero C operand.  K order, roundings and epilogue arithmetic are those of the kernel above: bit-identical.
+template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_kernel(P3Args a) {
+    typedef bf16_t T;
+    constexpr int NW = 8, WM = 128, WN = 64, MI = 4, NI = 2, RB = 128, KK = 4;
+    constexpr int QP = (P3_PIECES + NW - 1) / NW;      // patch pieces per wave (6): one per tap during taps 0..5
+    constexpr int B_INSTR = 32 / NW;
+    constexpr int PTAB = 2 * P3_PATCH + 2 * P3_BSTAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PTAB + 3 * 256 * 4];
+    const gvfi_conv_params& p = a.p;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int t_last = (xcd + 1) * a.per_xcd < a.mtiles ? (xcd + 1) * a.per_xcd : a.mtiles;      // end of this XCD's range of tiles
+    int tile = xcd * a.per_xcd + slot;
+    if (tile >= t_last) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const T* __restrict__ xs0 = (const T*)p.x0;
+    const T* __restrict__ xs1 = (const T*)p.x1;
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    auto decode = [&](int v, int& img, int& y0, int& x0) {
+        img = v / tiles_img;
+        const int trem = v - img * tiles_img;
+        const int tyi = trem / a.tiles_x;
+        y0 = tyi * P3_TH;
+        x0 = (trem - tyi * a.tiles_x) * P3_TW;
+    };
+    // ---- patch DMA: the lane's slot of each of its pieces as (patch row, patch column, 16-byte group); the byte offset and the
+    // border mask of a tile are derived at issue time (a dozen VALU operations per piece and tap, nothing tile-dependent is kept)
+    unsigned geo[QP / 2];      // two 16-bit entries per register: row | column << 5 | group << 10, 0xffff = no slot
+    static_assert(QP % 2 == 0, "pieces per wave");
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        const int piece = q * NW + wave;
+        const int s = piece * 64 + lane;
+        const int pp = s / 9, col = s - pp * 9;
+        const int py = pp / P3_PW, px = pp - py * P3_PW;
+        const unsigned e = (piece < P3_PIECES && pp < P3_PIX && col < 8) ? (unsigned)(py | (px << 5) | (col << 10)) : 0xffffu;
+        if (q & 1) geo[q >> 1] |= e << 16; else geo[q >> 1] = e;
+    }
+    const unsigned smem_lds = lds_address(smem);
+    const gvfi_i32x4 srd_b = make_srd(p.w);
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const unsigned b_off = (unsigned)(((wave * 8 + lrow) * 8 + lslot) * 16);      // + i * 8 KB (scalar): instruction i of a stage
+    auto swz = [](int row) { return (row >> 1) & 7; };
+    // fragment read addresses: pa = patch buffer of the chunk being read, pbe / pbo = the weight stages of its even / odd taps
+    // ((gc + tap) & 1); they change only at a chunk boundary: pa moves to the other buffer, pbe and pbo swap (9 taps per chunk)
+    unsigned pa[MI], pbe[KK], pbo[KK];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * WM + i * 32 + (lane & 31);
+        pa[i] = (unsigned)(((row >> 4) * P3_PW + (row & 15)) * P3_PITCH + (lane >> 5) * 16);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int rb = wn * WN + (lane & 31);
+        const int slot16 = 2 * kk + (lane >> 5);
+        pbe[kk] = 2 * P3_PATCH + rb * RB + ((slot16 ^ swz(rb)) << 4);
+        pbo[kk] = pbe[kk] + P3_BSTAGE;
+    }
+    // piece q of the patch of a chunk: descriptor at the patch origin of its tile (y0p - 1, x0p - 1), channel chunk offset soff.
+    // The per-lane offset (a dozen VALU operations) is computed one step ahead, in front of the step barrier where the wave is
+    // about to wait anyway: VALU work inside the MFMA stream costs far more than its issue slots.
+    auto patch_off = [&](int q, int ld, int y0p, int x0p) -> unsigned {
+        const unsigned g = (geo[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+        const int py = g & 31, px = (g >> 5) & 31, col = (g >> 10) & 15;
+        const bool ok = g != 0xffffu && (unsigned)(y0p - 1 + py) < (unsigned)p.H && (unsigned)(x0p - 1 + px) < (unsigned)p.W;
+        return ok ? (unsigned)(((py * p.W + px) * ld + col * 8) * 2) : GVFI_DMA_OOB;
+    };
+    auto issue_patch = [&](int q, unsigned off, unsigned par, gvfi_i32x4 srd, unsigned soff) {
+        const int piece = q * NW + wave;
+        if (piece >= P3_PIECES) return;
+        bufdma16(off, srd, P3_UNIFORM(soff), P3_UNIFORM(smem_lds + par * P3_PATCH + piece * 1024));
+    };
+    auto issue_b = [&](unsigned soff, unsigned par, int i) {
+        bufdma16(b_off, srd_b, P3_UNIFORM(soff + (unsigned)(i * NW * 1024)), P3_UNIFORM(smem_lds + 2 * P3_PATCH + par * P3_BSTAGE + (i * NW + wave) * 1024));
+    };
+    auto patch_srd = [&](int cn, int img, int y0, int x0, gvfi_i32x4& srd, unsigned& soff, int& ld) {
+        const bool from0 = cn < a.chunks0;
+        const long long pix_org = ((long long)img * p.H + (y0 - 1)) * p.W + (x0 - 1);
+        ld = from0 ? p.ld0 : p.ld1;
+        srd = make_srd((from0 ? xs0 : xs1) + pix_org * ld);
+        soff = (unsigned)((from0 ? cn : cn - a.chunks0) * 128);
+    };
+    // ---- per-channel epilogue parameters -> LDS (published by the prologue barrier; Cout == 256: one table per launch)
+    if (tid < 256) {
+        float* pt = (float*)(smem + PTAB);
+        pt[tid] = p.bias ? p.bias[tid] : 0.f;
+        pt[256 + tid] = p.act1 == GVFI_ACT_PRELU ? p.slope1[tid] : (p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f));
+        pt[512 + tid] = p.act2 == GVFI_ACT_PRELU ? p.slope2[tid] : (p.act2 == GVFI_ACT_NONE ? 1.f : (p.act2 == GVFI_ACT_LRELU ? 0.1f : 0.f));
+    }
+    const float* ptab = (const float*)(smem + PTAB);
+    const bool has_sc = p.out_scale != 1.0f, has_res = p.res != nullptr;
+    const unsigned wstride = (unsigned)(p.Cout * 128);        // bytes of one (chunk, tap) stage of the weight image
+
+    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
+    auto now = [&]() -> unsigned long long {
+#ifndef GVFI_HOSTSIM
+        return __builtin_readcyclecounter();
+#else
+        return 0;
+#endif
+    };
+    if (PROF) tprev = now();
+    int img, y0, x0;
+    decode(tile, img, y0, x0);
+    {   // prologue of the stream: patch of (first tile, chunk 0) + weights of its (chunk 0, tap 0)
+        gvfi_i32x4 srd;
+        unsigned soff;
+        int ld;
+        patch_srd(0, img, y0, x0, srd, soff, ld);
+#pragma unroll
+        for (int q = 0; q < QP; ++q) issue_patch(q, patch_off(q, ld, y0, x0), 0u, srd, soff);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) issue_b(0u, 0u, i);
+    }
+    f32x16 acc[MI][NI];
+    uint4 fa[2][MI], fb[2][NI];
+    auto load_frags = [&](int toff, int kk, int buf, const unsigned (&pb)[KK]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[buf][i] = *(const uint4*)(smem + pa[i] + toff + kk * 32);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[buf][j] = *(const uint4*)(smem + pb[kk] + j * 32 * RB);
+    };
+    // chunk boundary: the other patch buffer, the weight stages of even and odd taps change places
+    auto next_chunk_bases = [&](unsigned gc_new) {
+        const unsigned da = (gc_new & 1) ? (unsigned)P3_PATCH : 0u - (unsigned)P3_PATCH;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) pa[i] += da;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const unsigned t = pbe[kk];
+            pbe[kk] = pbo[kk];
+            pbo[kk] = t;
+        }
+    };
+    glds_wait_n<0>();
+    __syncthreads();
+    if (PROF) { const unsigned long long t = now(); ph[0] = t - tprev; tprev = t; }
+    load_frags(0, 0, 0, pbe);
+    unsigned gc = 0;      // chunks this workgroup has been through: patch buffer gc & 1, weight stage of tap t (gc + t) & 1
+    unsigned ntiles_done = 0;
+    for (;;) {
+        const int tnext = tile + a.slots;
+        const bool has_next = tnext < t_last;
+        int imgn = img, y0n = y0, x0n = x0;
+        if (has_next) decode(tnext, imgn, y0n, x0n);
+        for (int c = 0; c < a.chunks; ++c, ++gc) {
+            const bool last = c + 1 == a.chunks;
+            // what streams in during this chunk: the patch of this tile's next chunk, or of the next tile's chunk 0
+            const bool do_next = !last || has_next;
+            gvfi_i32x4 srd_n;
+            unsigned soff_n;
+            int ld_n;
+            patch_srd(last ? 0 : c + 1, last ? imgn : img, last ? y0n : y0, last ? x0n : x0, srd_n, soff_n, ld_n);
+            const int y0p = last ? y0n : y0, x0p = last ? x0n : x0;
+            // first chunk of a tile (its first MFMAs take C = 0).  Read through an opaque copy of the chunk index: tied to the
+            // induction variable hipcc peels the first chunk into a second copy of the whole K loop (and spills in it)
+            int c_o = c;
+            GVFI_OPAQUE_S(c_o);
+            const bool first = c_o == 0;
+            unsigned noff = patch_off(0, ld_n, y0p, x0p);      // (tap 0's piece: the one offset computed inside the MFMA stream)
+            auto step = [&](auto tap_tag) {
+                constexpr int tap = decltype(tap_tag)::value;
+                constexpr int toff = ((tap / 3) * P3_PW + (tap % 3)) * P3_PITCH;
+                constexpr int ntap = tap == 8 ? 0 : tap + 1;
+                constexpr int ntoff = ((ntap / 3) * P3_PW + (ntap % 3)) * P3_PITCH;
+                const unsigned (&pb)[KK] = (tap & 1) ? pbo : pbe;
+                const unsigned wsoff_n = tap < 8 ? (unsigned)(c * 9 + tap + 1) * wstride : (last ? 0u : (unsigned)((c + 1) * 9) * wstride);
+                const bool tile_end = tap == 8 && last;
+#pragma unroll
+                for (int kk = 0; kk + 1 < KK; ++kk) {
+                    load_frags(toff, kk + 1, (kk + 1) & 1, pb);
+                    GVFI_SCHED_BARRIER();
+                    if (tap == 0 && kk == 0 && first) {
+                        // first MFMA of a tile into every accumulator block: C = 0
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                                Mma2<T>::run(acc[i][j], fb[0][j], fa[0][i]);
+                            }
+                            if (i == 0) {
+#pragma unroll
+                                for (int q = 0; q < B_INSTR; ++q) issue_b(wsoff_n, (gc + tap + 1) & 1, q);
+                                issue_patch(tap, noff, (gc + 1) & 1, srd_n, soff_n);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                            for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fb[kk & 1][j], fa[kk & 1][i]);
+                            if (kk == 0 && i == 0 && (tap < 8 || do_next)) {
+#pragma unroll
+                                for (int q = 0; q < B_INSTR; ++q) issue_b(wsoff_n, (gc + tap + 1) & 1, q);
+                                if (tap < 6 && tap < QP && do_next) issue_patch(tap, noff, (gc + 1) & 1, srd_n, soff_n);
+                            }
+                        }
+                    }
+                    GVFI_SCHED_BARRIER();
+                }
+                if (tap + 1 < 6 && tap + 1 < QP) noff = patch_off(tap + 1, ld_n, y0p, x0p);      // next step's piece
+                {
+                    unsigned long long tw = 0;
+                    if (PROF) tw = now();
+                    glds_wait_n<0>();
+                    __syncthreads();
+                    if (PROF) ph[2] += now() - tw;
+                }
+                if (!tile_end) {
+                    if (tap == 8) {
+                        next_chunk_bases(gc + 1);
+                        load_frags(ntoff, 0, KK & 1, pbe);
+                    } else {
+                        load_frags(ntoff, 0, KK & 1, (tap & 1) ? pbe : pbo);
+                    }
+                    GVFI_SCHED_BARRIER();
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma2<T>::run(acc[i][j], fb[(KK - 1) & 1][j], fa[(KK - 1) & 1][i]);
+                }
+                GVFI_SCHED_BARRIER();
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{});
+            step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{});
+            step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{});
+        }
+        // ---- the tile's epilogue: staging in what its last step read (patch buffer / weight stage (gc - 1) & 1)
+        if (PROF) { const unsigned long long t = now(); ph[1] += t - tprev; tprev = t; }
+        {
+            const unsigned par = (gc - 1) & 1;
+            const unsigned reg0 = wave < 4 ? par * P3_PATCH + (unsigned)wave * 8192u : 2 * P3_PATCH + par * P3_BSTAGE + (unsigned)(wave - 4) * 8192u;
+            const long long pix0 = ((long long)img * p.H + y0) * p.W + x0;
+            // (the epilogue's per-lane addresses are tile-independent: behind an opaque copy of the lane index hipcc re-derives
+            // them here -- ~30 VALU operations per tile -- instead of keeping two dozen registers alive across the K loop)
+            int lane_e = lane;
+            GVFI_OPAQUE_V(lane_e);
+            if (has_res) {
+                if (has_sc) p3_wave_epilogue<true, true>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+                else p3_wave_epilogue<true, false>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+            } else {
+                if (has_sc) p3_wave_epilogue<false, true>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+                else p3_wave_epilogue<false, false>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+            }
+        }
+        ++ntiles_done;
+        if (!has_next) {
+            if (PROF) { const unsigned long long t = now(); ph[3] += t - tprev; tprev = t; }
+            break;
+        }
+        __syncthreads();      // the staging areas are the DMA targets of the next tile's first step
+        if (PROF) { const unsigned long long t = now(); ph[3] += t - tprev; tprev = t; }
+        tile = tnext;
+        img = imgn;
+        y0 = y0n;
+        x0 = x0n;
+        next_chunk_bases(gc);
+        load_frags(0, 0, 0, pbe);
+    }
+    if (PROF && tid == 0) {
+        // per workgroup: cycles summed over its tiles; word 0 carries the tile count in its upper half
+        unsigned long long* o = (unsigned long long*)p.aux1 + (size_t)bid * 4;
+        o[0] = ph[0] | ((unsigned long long)ntiles_done << 32);
+        o[1] = ph[1];
+        o[2] = ph[2];
+        o[3] = ph[3];
+    }
+}
+
+// workgroups of the stream kernel per XCD: one per compute unit (the LDS admits one)
+static int p3_slots_per_xcd() {
+#ifndef GVFI_HOSTSIM
+    static int cached[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        cached[dev] = cus / 8;
+    }
+    return cached[dev];
+#else
+    return 1;        // (emulator: 8 persistent workgroups -- small test images still give every workgroup several tiles)
+#endif
+}
+
 // 1 = gvfi_conv2d routes this problem here ahead of the LDS-DMA kernel; 2 = runnable on request (algo 4) but too few
 // output pixels for the 16 x 16 tiles to pay; 0 = not this kernel's problem
 extern "C" int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* pp) {
@@ -413,6 +875,7 @@ extern "C" int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* pp) {
     // per-lane DMA offsets are 32-bit and stay below the descriptor's range: 18 image rows of the widest source
     if ((long long)18 * p.W * (p.ld0 > p.ld1 ? p.ld0 : p.ld1) * 2 >= 0x7fffff00ll) return 0;
     if (p.res && (long long)18 * p.W * p.ldr * 2 >= 0x7fffff00ll) return 0;               // ... and the residual tile's rows
+    if ((long long)18 * p.W * p.ldy * 2 >= 0x7fffff00ll) return 0;                        // ... and the output tile's (register-side epilogue)
     return (long long)p.N * p.H * p.W >= 65536 ? 1 : 2;
 }
 
@@ -428,10 +891,21 @@ extern "C" int gvfi_conv2d_p3x3(const gvfi_conv_params* pp, void* stream) {
     a.mtiles = a.tiles_x * a.tiles_y * p.N;
     a.ntiles_n = p.Cout / 256;
     a.per_xcd = cdiv((long long)a.mtiles * a.ntiles_n, 8);
-    if (((p.algo >> 8) & 128) && p.aux1 != nullptr) {
-        GVFI_LAUNCH_COOP(conv_p3x3_kernel<true>, dim3(a.per_xcd * 8), dim3(512), (hipStream_t)stream, a);
-    } else {
-        GVFI_LAUNCH_COOP(conv_p3x3_kernel<false>, dim3(a.per_xcd * 8), dim3(512), (hipStream_t)stream, a);
+    const bool prof = ((p.algo >> 8) & 128) && p.aux1 != nullptr;
+    const int var = (p.algo >> 13) & 3;      // algo bits 13, 14: A/B switches (1: wave-private epilogue, 2: persistent stream)
+    if ((var & 2) && a.ntiles_n == 1) {
+        a.slots = p3_slots_per_xcd();
+        if (a.slots > a.per_xcd) a.slots = a.per_xcd;
+        if (prof) GVFI_LAUNCH_COOP(conv_p3x3_stream_kernel<true>, dim3(a.slots * 8), dim3(512), (hipStream_t)stream, a);
+        else GVFI_LAUNCH_COOP(conv_p3x3_stream_kernel<false>, dim3(a.slots * 8), dim3(512), (hipStream_t)stream, a);
+        return (int)hipGetLastError();
     }
+#define P3_LAUNCH(PR, V) GVFI_LAUNCH_COOP((conv_p3x3_kernel<PR, V>), dim3(a.per_xcd * 8), dim3(512), (hipStream_t)stream, a)
+    if (prof) {
+        if (var & 1) P3_LAUNCH(true, 1); else P3_LAUNCH(true, 0);
+    } else {
+        if (var & 1) P3_LAUNCH(false, 1); else P3_LAUNCH(false, 0);
+    }
+#undef P3_LAUNCH
     return (int)hipGetLastError();
 }
