@@ -1176,7 +1176,10 @@ extern "C" int gvfi_conv2d_glds(const gvfi_conv_params* pp, void* stream) {
         // IEEE-half operands: the tiles of the flow estimators' recurrence (small M); everything else of that size takes the
         // 128-wide 4-wave tiles
         if (k != 128) return -7;
-        if (tile == 256) return launch_glds<f16_t, 256, 256, 2, 4, 128, 2, true, 4>(p, st);
+        if (tile == 256) {
+            if (p.algo & 32) return -7;      // (the one-piece-per-MFMA-group A/B variant exists for bf16 / float only)
+            return launch_glds<f16_t, 256, 256, 2, 4, 128, 2, true, 4>(p, st);
+        }
         if (tile == 128) {
             if (bm == 64) return launch_glds<f16_t, 64, 128, 2, 2, 128, 2>(p, st);
             return launch_glds<f16_t, 128, 128, 2, 2, 128, 2>(p, st);

@@ -111,12 +111,37 @@ __device__ __forceinline__ void bufst16(const uint4& v, gvfi_rsrc_t r, unsigned 
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, 0, 0);
 }
+// ... and the matching load (out-of-range offsets read zeros)
+__device__ __forceinline__ uint4 bufld16(gvfi_rsrc_t r, unsigned voff) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    uint4 o;
+    o.x = t.x; o.y = t.y; o.z = t.z; o.w = t.w;
+    return o;
+}
+// true in every lane iff x is true in every lane of the wave
+__device__ __forceinline__ bool wave_all(bool x) { return __builtin_amdgcn_ballot_w64(x) == __builtin_amdgcn_ballot_w64(true); }
 #else
 struct gvfi_rsrc_t { unsigned char* base; };
 static inline gvfi_rsrc_t make_rsrc(const void* base) { return gvfi_rsrc_t{(unsigned char*)base}; }
 static inline void bufst16(const uint4& v, gvfi_rsrc_t r, unsigned voff) {
     GVFI_EMU_VMEM_OP();      // (takes its place in the lane's in-order queue of vector-memory operations)
     if (voff < 0x7fffff00u) memcpy(r.base + voff, &v, 16);
+}
+static inline uint4 bufld16(gvfi_rsrc_t r, unsigned voff) {
+    GVFI_EMU_VMEM_OP();
+    uint4 o = {0u, 0u, 0u, 0u};
+    if (voff < 0x7fffff00u) memcpy(&o, r.base + voff, 16);
+    return o;
+}
+static inline bool wave_all(bool x) {
+    uint32_t* s = emu::wave_scratch();
+    s[emu::tl.lane * 16] = x ? 1u : 0u;
+    emu::wave_sync();
+    bool r = true;
+    for (int l = 0, n = emu::tl.wg->wv_size[emu::tl.wave]; l < n; ++l) r = r && s[l * 16] != 0u;
+    emu::wave_sync();
+    return r;
 }
 #endif
 

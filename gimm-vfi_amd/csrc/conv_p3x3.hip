@@ -40,6 +40,7 @@ struct P3Args {
     int chunks0, chunks;        // 64-channel chunks of source 0 / of both sources
     int tiles_x, tiles_y, mtiles, ntiles_n, per_xcd;
     int slots;                  // (stream kernel) workgroups per XCD: the grid is 8 x slots
+    int dbg;                    // (stream kernel, profiling build only: tile_hint bits 10, 11) 1: no patch offsets, 2: no stores
 };
 
 // ---- wave-private epilogue ----------------------------------------------------------------------------------------------
@@ -48,22 +49,36 @@ struct P3Args {
 // anywhere: a pass writes its 8-byte pieces (lane = pixel, 4 consecutive channels), reads them back as 16-byte units
 // (8 lanes = the 128 bytes one pixel has in this wave's channel range) and stores four times 8 pixels x 128 bytes, whole
 // cache lines.  Row `px` of a region keeps its 16-byte unit u at slot u ^ ((px >> 1) & 7): the 64 lanes of a ds_write_b64 cover
-// the 64 banks twice, the 16 lanes of a ds_read_b128 group (two pixels) once.  The residual of a pass arrives by LDS-DMA in
-// the same layout (pre-swizzled on the source side), two passes ahead, and the result overwrites it in place.
-// Vector-memory order of a wave (they retire in order; the counted waits below rely on it):
-//   DMA0 DMA1 | st0 DMA2 | st1 DMA3 | st2 | st3      (4 instructions each; without a residual only the stores)
+// the 64 banks twice, the 16 lanes of a ds_read_b128 group (two pixels) once.  The residual arrives in the same layout
+// (pre-swizzled on the source side) and the result overwrites it in place: passes 0 and 1 by LDS-DMA into the two regions,
+// passes 2 and 3 into REGISTERS first and from there into the region its predecessor has just left.  A wave's vector-memory
+// operations retire in order, so every residual load has to be in the queue before the first store: a load behind a store would
+// wait for that store to reach memory -- microseconds when every CU of the chip stores its tile at the same time.
+//   queue: DMA0 DMA1 | ld2 ld3 st0 st1 | st2 st3      (4 instructions each; without a residual only the stores)
+// FAST: every slope of the launch is <= 1 (none = 1, ReLU = 0, leaky = 0.1, the usual PReLU): act(t) = max(t, s t) -- one
+// operation instead of the select of +-inf and the median (v_med3(t, s t, s <= 1 ? +inf : -inf), same value for finite t).
 // Same arithmetic and order as the workgroup-wide form below: bit-identical.
 // reg0: byte offset of the wave's 2 x 4 KB inside smem; pix0: pixel index of the tile's first pixel; the tile's row r is pixel
 // (y0 + r / 16, x0 + r % 16).
-template <bool RES, bool SC>
-__device__ __forceinline__ void p3_wave_epilogue(const gvfi_conv_params& p, f32x16 (&acc)[4][2], unsigned char* smem, unsigned smem_lds,
+// what the epilogue needs of the launch (the stream kernel keeps it in LDS between tiles instead of in 12 scalar registers)
+struct P3Epi {
+    const void* y;
+    const void* res;
+    int ldy, ldr, H, W;
+    float out_scale;
+    int nostore;      // (profiling experiments)
+};
+template <bool RES, bool SC, bool FAST>
+__device__ __forceinline__ void p3_wave_epilogue(const P3Epi& p, f32x16 (&acc)[4][2], unsigned char* smem, unsigned smem_lds,
                                                  unsigned reg0, const float* ptab, int lane, int wm, int wn, long long pix0, int y0,
                                                  int x0, int n0) {
     const int px = lane & 31, fhalf = lane >> 5, fsw = (px >> 1) & 7;
     const int q0 = lane >> 3, un = lane & 7;
     const float inf = __builtin_inff();
     const gvfi_rsrc_t rs_y = make_rsrc((const bf16_t*)p.y + pix0 * p.ldy + n0 + wn * 64);
-    const gvfi_i32x4 srd_r = make_srd(RES ? (const bf16_t*)p.res + pix0 * p.ldr + n0 + wn * 64 : (const bf16_t*)p.y);
+    const bf16_t* rbase = RES ? (const bf16_t*)p.res + pix0 * p.ldr + n0 + wn * 64 : (const bf16_t*)p.y;
+    const gvfi_i32x4 srd_r = make_srd(rbase);
+    const gvfi_rsrc_t rs_r = make_rsrc(rbase);
     // per-lane byte offsets of its pixel column x = q0 / q0 + 8 (k even / odd); the pixel row enters as a scalar offset
     unsigned yv[2], rv[2];
 #pragma unroll
@@ -74,7 +89,6 @@ __device__ __forceinline__ void p3_wave_epilogue(const gvfi_conv_params& p, f32x
         rv[h] = ok ? (unsigned)((xx * p.ldr + ((un ^ (q0 >> 1) ^ (4 * h)) * 8)) * 2) : GVFI_DMA_OOB;
     }
     auto res_dma = [&](int i) {      // residual of pass i -> its staging region
-        if (!RES) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int yy = wm * 8 + i * 2 + (k >> 1);
@@ -82,95 +96,147 @@ __device__ __forceinline__ void p3_wave_epilogue(const gvfi_conv_params& p, f32x
             bufdma16(oky ? rv[k & 1] : GVFI_DMA_OOB, srd_r, (unsigned)(yy * p.W * p.ldr * 2), smem_lds + reg0 + (unsigned)((i & 1) * 4096 + k * 1024));
         }
     };
-    res_dma(0);
-    res_dma(1);
+    constexpr int GF = RES ? 2 : 4;
+    uint4 rreg[2][4];
+    if (RES) {
+        res_dma(0);
+        res_dma(1);
+    }
+    // two passes at a time (i = 2 pr, 2 pr + 1: the two staging regions): the per-channel parameters of four channel groups are
+    // fetched once and serve both -- a parameter fetch in front of every 4 x 4 values made the epilogue a chain of 32 LDS
+    // round trips per wave (6.9 of the stream kernel's 8.3 kcycles per tile)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned reg = reg0 + (unsigned)((i & 1) * 4096);
+    for (int pr = 0; pr < 2; ++pr) {
         if (RES) {
-            // in flight behind pass i's residual: i = 0: DMA1; i = 1: st0 DMA2; i = 2: st1 DMA3; i = 3: st2
-            if (i == 1 || i == 2) glds_wait_n<8>(); else glds_wait_n<4>();
+            if (pr == 0) {
+                glds_wait_n<0>();      // DMA0, DMA1
+            } else {
+#pragma unroll
+                for (int i = 2; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *(uint4*)(smem + reg0 + (i & 1) * 4096 + k * 1024 + lane * 16) = rreg[i - 2][k];
+            }
             P3_WAVE_SYNC();
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int jg = 0; jg < 8; jg += GF) {      // GF channel groups per parameter fetch (their registers: 8 / 12 per group)
+            const int j = jg >> 2;
+            float4 b4[GF], s4[GF], z4[GF];
+            int cj = wn * 64 + jg * 8 + 4 * fhalf;
+            GVFI_OPAQUE_V(cj);      // (fetched per pass pair: kept across the pairs the parameters would cost 96 registers)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = wn * 64 + j * 32 + 8 * g + 4 * fhalf;          // first of this lane's 4 channels (within the tile)
-                const float4 b4 = *(const float4*)(ptab + c0), s4 = *(const float4*)(ptab + 256 + c0);
-                const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, s1[4] = {s4.x, s4.y, s4.z, s4.w};
-                float s2[4] = {1.f, 1.f, 1.f, 1.f};
-                if (RES) {
-                    const float4 z4 = *(const float4*)(ptab + 512 + c0);
-                    s2[0] = z4.x; s2[1] = z4.y; s2[2] = z4.z; s2[3] = z4.w;
-                }
-                unsigned char* sp = smem + reg + px * 128 + (((j * 4 + g) ^ fsw) << 4) + fhalf * 8;
-                float vv[4];
+            for (int gg = 0; gg < GF; ++gg) {
+                const int c0 = cj + 8 * gg;          // first of this lane's 4 channels (within the tile)
+                b4[gg] = *(const float4*)(ptab + c0);
+                s4[gg] = *(const float4*)(ptab + 256 + c0);
+                if (RES) z4[gg] = *(const float4*)(ptab + 512 + c0);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * pr + ii;
+                const unsigned reg = reg0 + (unsigned)(ii * 4096);
+#pragma unroll
+                for (int gg = 0; gg < GF; ++gg) {
+                    const int g = (jg & 3) + gg;
+                    const float bb[4] = {b4[gg].x, b4[gg].y, b4[gg].z, b4[gg].w}, s1[4] = {s4[gg].x, s4[gg].y, s4[gg].z, s4[gg].w};
+                    float s2[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (RES) { s2[0] = z4[gg].x; s2[1] = z4[gg].y; s2[2] = z4[gg].z; s2[3] = z4[gg].w; }
+                    unsigned char* sp = smem + reg + px * 128 + (((j * 4 + g) ^ fsw) << 4) + fhalf * 8;
+                    float vv[4];
 #ifndef GVFI_HOSTSIM
-                {   // packed pairs: v_pk_add_f32 / v_pk_mul_f32
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f2 a2 = {acc[i][j][4 * g + 2 * h], acc[i][j][4 * g + 2 * h + 1]};
-                        const f2 t2 = a2 + f2{bb[2 * h], bb[2 * h + 1]};
-                        const f2 st = t2 * f2{s1[2 * h], s1[2 * h + 1]};
-                        vv[2 * h] = med3f(t2.x, st.x, s1[2 * h] <= 1.f ? inf : -inf);
-                        vv[2 * h + 1] = med3f(t2.y, st.y, s1[2 * h + 1] <= 1.f ? inf : -inf);
-                    }
-                }
-#else
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[i][j][4 * g + e] + bb[e];
-                    vv[e] = med3f(t, s1[e] * t, s1[e] <= 1.f ? inf : -inf);
-                }
-#endif
-                if (RES) {
-                    const uint2 ru = *(const uint2*)sp;
-                    vv[0] += __builtin_bit_cast(float, ru.x << 16);
-                    vv[1] += __builtin_bit_cast(float, ru.x & 0xffff0000u);
-                    vv[2] += __builtin_bit_cast(float, ru.y << 16);
-                    vv[3] += __builtin_bit_cast(float, ru.y & 0xffff0000u);
-#ifndef GVFI_HOSTSIM
-                    {
+                    {   // packed pairs: v_pk_add_f32 / v_pk_mul_f32
                         typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const f2 t2 = {vv[2 * h], vv[2 * h + 1]};
-                            const f2 st = t2 * f2{s2[2 * h], s2[2 * h + 1]};
-                            vv[2 * h] = med3f(t2.x, st.x, s2[2 * h] <= 1.f ? inf : -inf);
-                            vv[2 * h + 1] = med3f(t2.y, st.y, s2[2 * h + 1] <= 1.f ? inf : -inf);
+                            const f2 a2 = {acc[i][j][4 * g + 2 * h], acc[i][j][4 * g + 2 * h + 1]};
+                            const f2 t2 = a2 + f2{bb[2 * h], bb[2 * h + 1]};
+                            const f2 st = t2 * f2{s1[2 * h], s1[2 * h + 1]};
+                            if (FAST) {
+                                vv[2 * h] = __builtin_fmaxf(t2.x, st.x);
+                                vv[2 * h + 1] = __builtin_fmaxf(t2.y, st.y);
+                            } else {
+                                vv[2 * h] = med3f(t2.x, st.x, s1[2 * h] <= 1.f ? inf : -inf);
+                                vv[2 * h + 1] = med3f(t2.y, st.y, s1[2 * h + 1] <= 1.f ? inf : -inf);
+                            }
                         }
                     }
 #else
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) vv[e] = med3f(vv[e], s2[e] * vv[e], s2[e] <= 1.f ? inf : -inf);
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = acc[i][j][4 * g + e] + bb[e];
+                        vv[e] = FAST ? fmaxf(t, s1[e] * t) : med3f(t, s1[e] * t, s1[e] <= 1.f ? inf : -inf);
+                    }
 #endif
-                }
-                if (SC) {
+                    if (RES) {
+                        const uint2 ru = *(const uint2*)sp;
+                        vv[0] += __builtin_bit_cast(float, ru.x << 16);
+                        vv[1] += __builtin_bit_cast(float, ru.x & 0xffff0000u);
+                        vv[2] += __builtin_bit_cast(float, ru.y << 16);
+                        vv[3] += __builtin_bit_cast(float, ru.y & 0xffff0000u);
+#ifndef GVFI_HOSTSIM
+                        {
+                            typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) vv[e] *= p.out_scale;
+                            for (int h = 0; h < 2; ++h) {
+                                const f2 t2 = {vv[2 * h], vv[2 * h + 1]};
+                                const f2 st = t2 * f2{s2[2 * h], s2[2 * h + 1]};
+                                if (FAST) {
+                                    vv[2 * h] = __builtin_fmaxf(t2.x, st.x);
+                                    vv[2 * h + 1] = __builtin_fmaxf(t2.y, st.y);
+                                } else {
+                                    vv[2 * h] = med3f(t2.x, st.x, s2[2 * h] <= 1.f ? inf : -inf);
+                                    vv[2 * h + 1] = med3f(t2.y, st.y, s2[2 * h + 1] <= 1.f ? inf : -inf);
+                                }
+                            }
+                        }
+#else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] = FAST ? fmaxf(vv[e], s2[e] * vv[e]) : med3f(vv[e], s2[e] * vv[e], s2[e] <= 1.f ? inf : -inf);
+#endif
+                    }
+                    if (SC) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] *= p.out_scale;
+                    }
+                    uint2 u;
+                    u.x = pack_bf16x2(vv[0], vv[1]);
+                    u.y = pack_bf16x2(vv[2], vv[3]);
+                    *(uint2*)sp = u;
                 }
-                uint2 u;
-                u.x = pack_bf16x2(vv[0], vv[1]);
-                u.y = pack_bf16x2(vv[2], vv[3]);
-                *(uint2*)sp = u;
+            }
+        }
+        if (RES && pr == 0) {
+            // passes 2 and 3: requested here -- behind the first pair's arithmetic (their 32 registers do not fit beside it), in
+            // front of its stores
+#pragma unroll
+            for (int i = 2; i < 4; ++i) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int yy = wm * 8 + i * 2 + (k >> 1);
+                    const bool oky = y0 + yy < p.H && rv[k & 1] != GVFI_DMA_OOB;
+                    rreg[i - 2][k] = bufld16(rs_r, oky ? rv[k & 1] + (unsigned)(yy * p.W * p.ldr * 2) : GVFI_DMA_OOB);
+                }
             }
         }
         P3_WAVE_SYNC();
-        uint4 t[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = k * 8 + q0;
-            t[k] = *(const uint4*)(smem + reg + q * 128 + ((un ^ ((q >> 1) & 7)) << 4));
-        }
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * pr + ii;
+            const unsigned reg = reg0 + (unsigned)(ii * 4096);
+            uint4 t[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int yy = wm * 8 + i * 2 + (k >> 1);
-            const bool oky = y0 + yy < p.H;
-            bufst16(t[k], rs_y, oky && yv[k & 1] != GVFI_DMA_OOB ? yv[k & 1] + (unsigned)(yy * p.W * p.ldy * 2) : GVFI_DMA_OOB);
+            for (int k = 0; k < 4; ++k) {
+                const int q = k * 8 + q0;
+                t[k] = *(const uint4*)(smem + reg + q * 128 + ((un ^ ((q >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = wm * 8 + i * 2 + (k >> 1);
+                const bool oky = y0 + yy < p.H;
+                if (!p.nostore) bufst16(t[k], rs_y, oky && yv[k & 1] != GVFI_DMA_OOB ? yv[k & 1] + (unsigned)(yy * p.W * p.ldy * 2) : GVFI_DMA_OOB);
+            }
         }
-        if (i < 2) res_dma(i + 2);
+        P3_WAVE_SYNC();
     }
 }
 
@@ -413,12 +479,13 @@ template <bool PROF, int VAR> __global__ void __launch_bounds__(512) conv_p3x3_k
         __syncthreads();
         const long long pix0 = img_pix + (long long)y0 * p.W + x0;
         const unsigned reg0 = (unsigned)wave * 8192u;
+        const P3Epi ep = {p.y, p.res, p.ldy, p.ldr, p.H, p.W, p.out_scale, 0};
         if (has_res) {
-            if (has_sc) p3_wave_epilogue<true, true>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
-            else p3_wave_epilogue<true, false>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+            if (has_sc) p3_wave_epilogue<true, true, false>(ep, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+            else p3_wave_epilogue<true, false, false>(ep, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
         } else {
-            if (has_sc) p3_wave_epilogue<false, true>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
-            else p3_wave_epilogue<false, false>(p, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+            if (has_sc) p3_wave_epilogue<false, true, false>(ep, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
+            else p3_wave_epilogue<false, false, false>(ep, acc, smem, smem_lds, reg0, ptab, lane, wm, wn, pix0, y0, x0, n0);
         }
         prof_out();
         return;
@@ -569,7 +636,7 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_ker
     constexpr int QP = (P3_PIECES + NW - 1) / NW;      // patch pieces per wave (6): one per tap during taps 0..5
     constexpr int B_INSTR = 32 / NW;
     constexpr int PTAB = 2 * P3_PATCH + 2 * P3_BSTAGE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[PTAB + 3 * 256 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PTAB + 3 * 256 * 4 + 32];
     const gvfi_conv_params& p = a.p;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
@@ -590,18 +657,17 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_ker
         y0 = tyi * P3_TH;
         x0 = (trem - tyi * a.tiles_x) * P3_TW;
     };
-    // ---- patch DMA: the lane's slot of each of its pieces as (patch row, patch column, 16-byte group); the byte offset and the
-    // border mask of a tile are derived at issue time (a dozen VALU operations per piece and tap, nothing tile-dependent is kept)
-    unsigned geo[QP / 2];      // two 16-bit entries per register: row | column << 5 | group << 10, 0xffff = no slot
-    static_assert(QP % 2 == 0, "pieces per wave");
+    // ---- patch DMA: the lane's slot of each of its pieces in one register: pixel offset py * W + px (17 bits), 16-byte group
+    // (4 bits), py, px (5 bits each), "no slot" in the sign bit.  The byte offset of a chunk is two operations away (pitch and
+    // group), the border mask of a tile four more; nothing tile-dependent is kept in registers.
+    unsigned geo[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
         const int piece = q * NW + wave;
         const int s = piece * 64 + lane;
         const int pp = s / 9, col = s - pp * 9;
         const int py = pp / P3_PW, px = pp - py * P3_PW;
-        const unsigned e = (piece < P3_PIECES && pp < P3_PIX && col < 8) ? (unsigned)(py | (px << 5) | (col << 10)) : 0xffffu;
-        if (q & 1) geo[q >> 1] |= e << 16; else geo[q >> 1] = e;
+        geo[q] = (piece < P3_PIECES && pp < P3_PIX && col < 8) ? (unsigned)((py * p.W + px) | (col << 17) | (py << 21) | (px << 26)) : 0x80000000u;
     }
     const unsigned smem_lds = lds_address(smem);
     const gvfi_i32x4 srd_b = make_srd(p.w);
@@ -611,26 +677,40 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_ker
     // fragment read addresses: pa = patch buffer of the chunk being read, pbe / pbo = the weight stages of its even / odd taps
     // ((gc + tap) & 1); they change only at a chunk boundary: pa moves to the other buffer, pbe and pbo swap (9 taps per chunk)
     unsigned pa[MI], pbe[KK], pbo[KK];
+    // (re-derived from the lane index at the start of every tile: kept across the epilogue they are 12 registers it cannot spare)
+    auto init_bases = [&](unsigned gcpar) {
+        int l = lane;
+        GVFI_OPAQUE_V(l);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int row = wm * WM + i * 32 + (lane & 31);
-        pa[i] = (unsigned)(((row >> 4) * P3_PW + (row & 15)) * P3_PITCH + (lane >> 5) * 16);
-    }
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * WM + i * 32 + (l & 31);
+            pa[i] = (unsigned)(((row >> 4) * P3_PW + (row & 15)) * P3_PITCH + (l >> 5) * 16) + gcpar * (unsigned)P3_PATCH;
+        }
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        const int rb = wn * WN + (lane & 31);
-        const int slot16 = 2 * kk + (lane >> 5);
-        pbe[kk] = 2 * P3_PATCH + rb * RB + ((slot16 ^ swz(rb)) << 4);
-        pbo[kk] = pbe[kk] + P3_BSTAGE;
-    }
+        for (int kk = 0; kk < KK; ++kk) {
+            const int rb = wn * WN + (l & 31);
+            const int slot16 = 2 * kk + (l >> 5);
+            const unsigned b = 2 * P3_PATCH + rb * RB + ((slot16 ^ swz(rb)) << 4);
+            pbe[kk] = b + gcpar * (unsigned)P3_BSTAGE;
+            pbo[kk] = b + (gcpar ^ 1u) * (unsigned)P3_BSTAGE;
+        }
+    };
+    init_bases(0u);
     // piece q of the patch of a chunk: descriptor at the patch origin of its tile (y0p - 1, x0p - 1), channel chunk offset soff.
     // The per-lane offset (a dozen VALU operations) is computed one step ahead, in front of the step barrier where the wave is
     // about to wait anyway: VALU work inside the MFMA stream costs far more than its issue slots.
     auto patch_off = [&](int q, int ld, int y0p, int x0p) -> unsigned {
-        const unsigned g = (geo[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
-        const int py = g & 31, px = (g >> 5) & 31, col = (g >> 10) & 15;
-        const bool ok = g != 0xffffu && (unsigned)(y0p - 1 + py) < (unsigned)p.H && (unsigned)(x0p - 1 + px) < (unsigned)p.W;
-        return ok ? (unsigned)(((py * p.W + px) * ld + col * 8) * 2) : GVFI_DMA_OOB;
+        if (PROF && (a.dbg & 1)) return GVFI_DMA_OOB;
+        unsigned g = geo[q];
+        GVFI_OPAQUE_V(g);      // (decoded here, every time: hoisted out of the K loop the decoded fields cost 18 registers)
+        const unsigned off = (g & 0x1ffffu) * (unsigned)(ld * 2) + ((g >> 17) & 15u) * 16u;
+        bool ok = (int)g >= 0;
+        // a tile whose halo lies inside the image (most of them) needs no border test
+        if (!(y0p >= 1 && y0p + P3_TH < p.H && x0p >= 1 && x0p + P3_TW < p.W)) {
+            const int py = (g >> 21) & 31, px = (g >> 26) & 31;
+            ok = ok && (unsigned)(y0p - 1 + py) < (unsigned)p.H && (unsigned)(x0p - 1 + px) < (unsigned)p.W;
+        }
+        return ok ? off : GVFI_DMA_OOB;
     };
     auto issue_patch = [&](int q, unsigned off, unsigned par, gvfi_i32x4 srd, unsigned soff) {
         const int piece = q * NW + wave;
@@ -654,11 +734,16 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_ker
         pt[256 + tid] = p.act1 == GVFI_ACT_PRELU ? p.slope1[tid] : (p.act1 == GVFI_ACT_NONE ? 1.f : (p.act1 == GVFI_ACT_LRELU ? 0.1f : 0.f));
         pt[512 + tid] = p.act2 == GVFI_ACT_PRELU ? p.slope2[tid] : (p.act2 == GVFI_ACT_NONE ? 1.f : (p.act2 == GVFI_ACT_LRELU ? 0.1f : 0.f));
     }
+    if (tid == 0) {      // the epilogue's launch parameters, read back per tile (see P3Epi)
+        unsigned* e = (unsigned*)(smem + PTAB + 3072);
+        const unsigned long long yp = (unsigned long long)p.y, rp = (unsigned long long)p.res;
+        e[0] = (unsigned)yp; e[1] = (unsigned)(yp >> 32); e[2] = (unsigned)rp; e[3] = (unsigned)(rp >> 32);
+        e[4] = (unsigned)p.ldy; e[5] = (unsigned)p.ldr; e[6] = (unsigned)p.H; e[7] = (unsigned)p.W;
+    }
     const float* ptab = (const float*)(smem + PTAB);
-    const bool has_sc = p.out_scale != 1.0f, has_res = p.res != nullptr;
     const unsigned wstride = (unsigned)(p.Cout * 128);        // bytes of one (chunk, tap) stage of the weight image
 
-    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto now = [&]() -> unsigned long long {
 #ifndef GVFI_HOSTSIM
         return __builtin_readcyclecounter();
@@ -702,6 +787,12 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_ker
     glds_wait_n<0>();
     __syncthreads();
     if (PROF) { const unsigned long long t = now(); ph[0] = t - tprev; tprev = t; }
+    // every slope of both activations <= 1?  (each wave looks at all 2 x 256 table entries: 4 per lane and table)
+    bool fast_act;
+    {
+        const float4 sa = *(const float4*)(ptab + 256 + lane * 4), sb = *(const float4*)(ptab + 512 + lane * 4);
+        fast_act = wave_all(sa.x <= 1.f && sa.y <= 1.f && sa.z <= 1.f && sa.w <= 1.f && sb.x <= 1.f && sb.y <= 1.f && sb.z <= 1.f && sb.w <= 1.f);
+    }
     load_frags(0, 0, 0, pbe);
     unsigned gc = 0;      // chunks this workgroup has been through: patch buffer gc & 1, weight stage of tap t (gc + t) & 1
     unsigned ntiles_done = 0;
@@ -767,7 +858,8 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_ker
                     }
                     GVFI_SCHED_BARRIER();
                 }
-                if (tap + 1 < 6 && tap + 1 < QP) noff = patch_off(tap + 1, ld_n, y0p, x0p);      // next step's piece
+                // next step's piece: in front of the barrier (same-binary A/B against a place behind the step's last MFMAs: equal)
+                if (tap + 1 < 6 && tap + 1 < QP) noff = patch_off(tap + 1, ld_n, y0p, x0p);
                 {
                     unsigned long long tw = 0;
                     if (PROF) tw = now();
@@ -806,40 +898,57 @@ template <bool PROF> __global__ void __launch_bounds__(512) conv_p3x3_stream_ker
         {
             const unsigned par = (gc - 1) & 1;
             const unsigned reg0 = wave < 4 ? par * P3_PATCH + (unsigned)wave * 8192u : 2 * P3_PATCH + par * P3_BSTAGE + (unsigned)(wave - 4) * 8192u;
-            const long long pix0 = ((long long)img * p.H + y0) * p.W + x0;
             // (the epilogue's per-lane addresses are tile-independent: behind an opaque copy of the lane index hipcc re-derives
             // them here -- ~30 VALU operations per tile -- instead of keeping two dozen registers alive across the K loop)
             int lane_e = lane;
             GVFI_OPAQUE_V(lane_e);
+            P3Epi ep;
+            {
+                const uint4 e0 = *(const uint4*)(smem + PTAB + 3072), e1 = *(const uint4*)(smem + PTAB + 3072 + 16);
+                ep.y = (const void*)((unsigned long long)P3_UNIFORM(e0.x) | ((unsigned long long)P3_UNIFORM(e0.y) << 32));
+                ep.res = (const void*)((unsigned long long)P3_UNIFORM(e0.z) | ((unsigned long long)P3_UNIFORM(e0.w) << 32));
+                ep.ldy = (int)P3_UNIFORM(e1.x);
+                ep.ldr = (int)P3_UNIFORM(e1.y);
+                ep.H = (int)P3_UNIFORM(e1.z);
+                ep.W = (int)P3_UNIFORM(e1.w);
+                ep.out_scale = 1.0f;
+                ep.nostore = PROF ? (a.dbg & 2) : 0;
+            }
+            const long long pix0 = ((long long)img * ep.H + y0) * ep.W + x0;
+            const bool has_res = ep.res != nullptr;
             if (has_res) {
-                if (has_sc) p3_wave_epilogue<true, true>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
-                else p3_wave_epilogue<true, false>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+                if (fast_act) p3_wave_epilogue<true, false, true>(ep, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+                else p3_wave_epilogue<true, false, false>(ep, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
             } else {
-                if (has_sc) p3_wave_epilogue<false, true>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
-                else p3_wave_epilogue<false, false>(p, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+                if (fast_act) p3_wave_epilogue<false, false, true>(ep, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
+                else p3_wave_epilogue<false, false, false>(ep, acc, smem, smem_lds, reg0, ptab, lane_e, wm, wn, pix0, y0, x0, 0);
             }
         }
+        if (PROF) ph[4] += now() - tprev;      // (the wave's own epilogue, without the barrier behind it)
         ++ntiles_done;
         if (!has_next) {
             if (PROF) { const unsigned long long t = now(); ph[3] += t - tprev; tprev = t; }
             break;
         }
+        // the next tile's first fragments: published since the last step's barrier, read while the other waves finish
+        init_bases(gc & 1);
+        load_frags(0, 0, 0, pbe);
         __syncthreads();      // the staging areas are the DMA targets of the next tile's first step
         if (PROF) { const unsigned long long t = now(); ph[3] += t - tprev; tprev = t; }
         tile = tnext;
         img = imgn;
         y0 = y0n;
         x0 = x0n;
-        next_chunk_bases(gc);
-        load_frags(0, 0, 0, pbe);
     }
     if (PROF && tid == 0) {
-        // per workgroup: cycles summed over its tiles; word 0 carries the tile count in its upper half
-        unsigned long long* o = (unsigned long long*)p.aux1 + (size_t)bid * 4;
+        // per workgroup (8 words): cycles summed over its tiles; word 0 carries the tile count in its upper half
+        unsigned long long* o = (unsigned long long*)p.aux1 + (size_t)bid * 8;
         o[0] = ph[0] | ((unsigned long long)ntiles_done << 32);
         o[1] = ph[1];
         o[2] = ph[2];
         o[3] = ph[3];
+        o[4] = ph[4];
+        o[5] = o[6] = o[7] = 0;
     }
 }
 
@@ -879,10 +988,8 @@ extern "C" int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* pp) {
     return (long long)p.N * p.H * p.W >= 65536 ? 1 : 2;
 }
 
-extern "C" int gvfi_conv2d_p3x3(const gvfi_conv_params* pp, void* stream) {
-    if (!gvfi_conv2d_p3x3_eligible(pp)) return -2;
-    const gvfi_conv_params& p = *pp;
-    P3Args a;
+// the launch geometry and form of a problem (shared by the launcher and gvfi_conv2d_p3x3_form)
+static int p3_plan(const gvfi_conv_params& p, P3Args& a) {
     a.p = p;
     a.chunks0 = p.c0 / 64;
     a.chunks = (p.c0 + p.c1) / 64;
@@ -891,20 +998,41 @@ extern "C" int gvfi_conv2d_p3x3(const gvfi_conv_params* pp, void* stream) {
     a.mtiles = a.tiles_x * a.tiles_y * p.N;
     a.ntiles_n = p.Cout / 256;
     a.per_xcd = cdiv((long long)a.mtiles * a.ntiles_n, 8);
+    // algo bits 13, 14: 0 = auto (the stream kernel where it applies and every CU gets at least two tiles, else the tile-per-
+    // workgroup kernel with the wave-private epilogue); A/B switches: 1 = tile per workgroup, workgroup-wide epilogue (the
+    // round-2 kernel), 2 = tile per workgroup, wave-private epilogue, 3 = stream kernel whenever it applies
+    const int var = (p.algo >> 13) & 3;
+    const bool stream_ok = a.ntiles_n == 1 && p.out_scale == 1.0f && 18 * p.W + 18 < (1 << 17);
+    a.slots = p3_slots_per_xcd();
+    if (a.slots > a.per_xcd) a.slots = a.per_xcd;
+    a.dbg = 0;
+    if (stream_ok && (var == 3 || (var == 0 && a.per_xcd >= 2 * a.slots))) return 3;
+    return var == 1 ? 1 : 2;
+}
+
+extern "C" int gvfi_conv2d_p3x3_form(const gvfi_conv_params* pp) {
+    if (!gvfi_conv2d_p3x3_eligible(pp)) return 0;
+    P3Args a;
+    return p3_plan(*pp, a);
+}
+
+extern "C" int gvfi_conv2d_p3x3(const gvfi_conv_params* pp, void* stream) {
+    if (!gvfi_conv2d_p3x3_eligible(pp)) return -2;
+    const gvfi_conv_params& p = *pp;
+    P3Args a;
+    const int form = p3_plan(p, a);
     const bool prof = ((p.algo >> 8) & 128) && p.aux1 != nullptr;
-    const int var = (p.algo >> 13) & 3;      // algo bits 13, 14: A/B switches (1: wave-private epilogue, 2: persistent stream)
-    if ((var & 2) && a.ntiles_n == 1) {
-        a.slots = p3_slots_per_xcd();
-        if (a.slots > a.per_xcd) a.slots = a.per_xcd;
+    if (form == 3) {
+        a.dbg = prof ? (p.tile_hint >> 10) & 3 : 0;
         if (prof) GVFI_LAUNCH_COOP(conv_p3x3_stream_kernel<true>, dim3(a.slots * 8), dim3(512), (hipStream_t)stream, a);
         else GVFI_LAUNCH_COOP(conv_p3x3_stream_kernel<false>, dim3(a.slots * 8), dim3(512), (hipStream_t)stream, a);
         return (int)hipGetLastError();
     }
 #define P3_LAUNCH(PR, V) GVFI_LAUNCH_COOP((conv_p3x3_kernel<PR, V>), dim3(a.per_xcd * 8), dim3(512), (hipStream_t)stream, a)
     if (prof) {
-        if (var & 1) P3_LAUNCH(true, 1); else P3_LAUNCH(true, 0);
+        if (form == 2) P3_LAUNCH(true, 1); else P3_LAUNCH(true, 0);
     } else {
-        if (var & 1) P3_LAUNCH(false, 1); else P3_LAUNCH(false, 0);
+        if (form == 2) P3_LAUNCH(false, 1); else P3_LAUNCH(false, 0);
     }
 #undef P3_LAUNCH
     return (int)hipGetLastError();

@@ -157,6 +157,7 @@ class GIMMVFI_R(nn.Module):
         iters = self._iters()
         eng = self.engine(img_xs.device)
         if not (self.use_graph and img_xs.is_cuda and eng.rt.ev_log is None):
+            self._eager_scope(eng, img_xs, coord, t, ds_factor, _seq)
             return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor, seq=_seq)
         try:
             return self._forward_graph(eng, img_xs, coord, t, iters, ds_factor, _seq)
@@ -172,6 +173,18 @@ class GIMMVFI_R(nn.Module):
             self._graphs = {}
             torch.cuda.synchronize(img_xs.device)
             return eng.forward(img_xs, coord, t, iters=iters, ds_factor=ds_factor, seq=_seq)
+
+    def _eager_scope(self, eng, img_xs, coord, t, ds_factor, seq):
+        """Eager launches keep the runtime's zero-once buffers per input signature like the captured graphs do: at most
+        `max_graphs` signatures, the least recently seen one is released (Runtime.release_once)."""
+        key = ("eager", tuple(img_xs.shape), tuple(tuple(c[0].shape) for c in coord), len(t), ds_factor, seq)
+        lru = self.__dict__.setdefault("_eager_sigs", [])
+        if key in lru:
+            lru.remove(key)
+        lru.append(key)
+        while len(lru) > self.max_graphs:
+            eng.rt.release_once(lru.pop(0))
+        eng.rt.once_scope = key
 
     def forward_sequence(self, frames, coord=None, t=None, ds_factor=None):
         """Addition to the reference API for video: `frames` (B+1, 3, H, W) are consecutive frames; returns what
@@ -193,7 +206,10 @@ class GIMMVFI_R(nn.Module):
         key = (tuple(img_xs.shape), str(img_xs.device), tuple(tuple(c[0].shape) for c in coord), len(t), ds_factor, seq)
         ent = self._graphs.get(key)
         if ent is None and len(self._graphs) >= self.max_graphs:
-            self._graphs.pop(next(iter(self._graphs)))     # oldest signature: its private memory pool is released
+            old = next(iter(self._graphs))
+            self._graphs.pop(old)            # oldest signature: its private memory pool is released ...
+            eng.rt.release_once(old)         # ... and the runtime's zero-once buffers only it used (they live outside the pool)
+        eng.rt.once_scope = key
         if ent is None:
             dev = img_xs.device
             sx = img_xs.detach().to(torch.float32).contiguous().clone()

@@ -266,11 +266,20 @@ class Runtime:
         # A/B switch: 0 keeps the combination block (7x7, 9 -> 18 -> 3) on the patch kernel instead of conv_col7.hip
         self.comb_algo = 0 if os.environ.get("GVFI_COL7", "1") != "0" else 3
         self.use_p3x3 = os.environ.get("GVFI_P3X3", "1") != "0"   # A/B switch: 0 keeps the LDS-DMA kernel on the hot 3x3 layers
+        # A/B switch of the halo-staged 3x3 kernel's launch form (algo bits 13, 14 of gvfi_conv2d_p3x3): 0 = auto (persistent stream
+        # kernel where it applies), 1 = the round-2 tile-per-workgroup kernel, 2 = tile per workgroup + wave-private epilogue
+        self.p3x3_form = int(os.environ.get("GVFI_P3X3_FORM", "0")) & 3
         self.ev_shapes = False   # tags carry the problem shape (bench.py --shapes: per-shape table)
         self._lanes = {}         # stream id -> extra streams for lanes()
         self.last_stats_fused = False
         self.last_planar = False
         self.fold_finalize = os.environ.get("GVFI_FOLD_FINALIZE", "1") != "0"   # A/B switch: finalize_image inside the last 7x7 layer
+        # zero-once buffers (act(once=...)): name/shape -> tensor, and which input signature (`once_scope`, set by the models around
+        # a forward) uses which -- release_once(scope) when that signature's graph is evicted.  ONE forward at a time per runtime:
+        # these buffers (and the engines' caches) are shared by every forward of the runtime, two forwards on different streams
+        # would race on them.
+        self._once_scopes = {}
+        self.once_scope = None
         self.zero_once = os.environ.get("GVFI_ZERO_ONCE", "1") != "0"           # A/B switch: persistent zero-once buffers (act(once=...))
         self.pair_launch = os.environ.get("GVFI_CONV_PAIR", "1") != "0"         # A/B switch: two independent convolutions per launch
         # SepConvGRU halves as one launch each (csrc/gru_fused.hip).  Built in round 5, bit-identical to the two gate convolutions,
@@ -283,6 +292,12 @@ class Runtime:
         # 8 = no epilogue, 16 = no K loop, 24 = neither: how much of the recurrence's wall time is the fixed per-launch cost
         # (launch + prologue [+ epilogue]) and how much the contraction (tools/evidence.sh wdir-floor, profiles/r5_wdir_floor.txt)
         self.wdir_dbg = int(os.environ.get("GVFI_WDIR_DBG", "0")) & 24
+        if self.wdir_dbg:
+            # a profiling switch of tools/ (phases of every weights-direct launch are SKIPPED: times are real, results are not)
+            import warnings
+
+            warnings.warn(f"gimmvfi_hip: GVFI_WDIR_DBG={self.wdir_dbg} is set -- the weights-direct convolutions skip phases of their "
+                          "work (profiling only): EVERY FRAME OF THIS RUNTIME IS GARBAGE", RuntimeWarning, stacklevel=2)
         self.wdir_bm128 = os.environ.get("GVFI_WDIR_BM128", "0") == "1"       # A/B switch: 128-row weights-direct tiles (see conv())
 
     def sibling(self, precision):
@@ -349,7 +364,22 @@ class Runtime:
             if self.on_gpu and torch.cuda.is_current_stream_capturing():
                 return None
             t = self._once[key] = torch.zeros(shape, dtype=dtype, device=self.device)
+        if self.once_scope is not None:
+            self._once_scopes.setdefault(self.once_scope, set()).add(key)
         return t
+
+    def release_once(self, scope):
+        """Drops the zero-once buffers that only the input signature `scope` used (the models call it when they evict that
+        signature's captured graph: the buffers live outside the graph's private pool -- the largest activations of a forward,
+        hundreds of MB per timestep at 4K -- and would otherwise pile up under shape churn).  Buffers another live
+        signature also uses stay."""
+        keys = self._once_scopes.pop(scope, set())
+        live = set().union(*self._once_scopes.values()) if self._once_scopes else set()
+        for k in keys - live:
+            self._once.pop(k, None)
+
+    def once_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self._once.values())
 
     def _chk(self, rc, name):
         self.n_launch += 1
@@ -459,6 +489,8 @@ class Runtime:
         if layer is not None and want == 0 and p.w_layout == 1 and stats is None and self.use_p3x3 \
                 and self.lib.conv2d_p3x3_eligible(C.byref(p)) == 1:
             p.algo = 4 | (algo & ~15)       # halo-staged 3x3 kernel (conv_p3x3.hip) ahead of the LDS-DMA kernel
+            if not (p.algo >> 13) & 3:
+                p.algo |= self.p3x3_form << 13
         if layer is not None and want in (0, 8) and layer.w_frag is not None and layer.use_lin and groups == 1:
             keep = (p.w, p.w_layout, p.algo)
             p.w, p.w_layout, p.algo = layer.w_frag.data_ptr(), 2, 8 | (algo & ~15)
@@ -512,6 +544,8 @@ class Runtime:
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
             kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel",
                      6: "conv_igemm_glds_kernel[wdir]", 7: "conv_col7_kernel", 8: "conv_lin_kernel"}[plan[0]]
+            if plan[0] == 4 and self.lib.conv2d_p3x3_form(C.byref(p)) == 3:
+                kname = "conv_p3x3_stream_kernel"      # (the persistent form: its own kernel in a rocprofv3 trace)
             tag = f"{kname}<{ {L.F32: 'float', L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
             if self.ev_shapes:
                 tag += f" {n}x{h}x{w_} {cin_real}->{p.Cout} {kh}x{kw}s{st}"
@@ -533,11 +567,14 @@ class Runtime:
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
         rc = self.lib.conv2d_pair(C.byref(pa), C.byref(pb), self.stream())
-        if rc == -2:      # not a pair of that variant: two launches
-            self._chk(self.lib.conv2d(C.byref(pa), self.stream()), "conv2d")
-            self._chk(self.lib.conv2d(C.byref(pb), self.stream()), "conv2d")
-        else:
-            self._chk(rc, "conv2d_pair")
+        if rc in (-2, -3):
+            # not a pair the weights-direct variant takes (nothing was launched): two ordinary launches through conv() -- a
+            # subclass's override included --, each logged as what it is (the fallback used to be logged as one
+            # '[wdir-pair]' entry, and -3 raised)
+            self.conv(**a)
+            self.conv(**b)
+            return
+        self._chk(rc, "conv2d_pair")
         if self.ev_log is not None:
             e1.record()
             tag = f"conv_igemm_glds_kernel[wdir-pair]<{ {L.F32: 'float', L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },64,128,kb128,s4>"

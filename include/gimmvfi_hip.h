@@ -169,9 +169,16 @@ int gvfi_conv2d_col7(const gvfi_conv_params* p, void* stream);
  * layers (csrc/conv_p3x3.hip): 16 x 16-pixel output tile whose 18 x 18 input halo is staged once per 64-channel chunk
  * instead of once per tap.  Results are bit-identical to the LDS-DMA kernel's (same K order, same epilogue arithmetic).
  * gvfi_conv2d routes here by itself when gvfi_conv2d_p3x3_eligible == 1 (algo 0) or with algo = 4 (eligible == 2:
- * runnable, but fewer than 65536 output pixels); algo = 2 keeps the LDS-DMA kernel. */
+ * runnable, but fewer than 65536 output pixels); algo = 2 keeps the LDS-DMA kernel.  Two launch forms, same results: with
+ * Cout == 256, out_scale == 1 and at least two tiles per compute unit ONE PERSISTENT workgroup per CU walks its tiles as one
+ * stream of channel chunks (the LDS-DMA ring never drains between tiles, wave-private epilogue, stores retire under the next
+ * tile's K loop: round 6, +4-6 % on the hot layer); else one workgroup per tile.  algo bits 13, 14 are A/B switches: 1 = tile
+ * per workgroup with the workgroup-wide epilogue (the round-2 kernel), 2 = tile per workgroup, 3 = stream where it applies. */
 int gvfi_conv2d_p3x3_eligible(const gvfi_conv_params* p);
 int gvfi_conv2d_p3x3(const gvfi_conv_params* p, void* stream);
+/* the launch form gvfi_conv2d_p3x3 takes for this problem on the current device: 1 / 2 = one workgroup per tile (workgroup-wide /
+ * wave-private epilogue), 3 = persistent stream kernel; 0 = not this kernel's problem */
+int gvfi_conv2d_p3x3_form(const gvfi_conv_params* p);
 /* The same scheme for the mid-channel full-resolution layers (csrc/conv_p3x3s.hip): 3x3 stride-1 zero-padded bf16, ONE
  * source of exactly 32 or 64 channels, Cout <= 64 (multiple of 8), plain weight image (w_layout 0), >= 65536 output
  * pixels -- conv2 / conv4 of the decoder ResBlocks (fi_components.py:107-133), the CNN encoder's 32 -> 32 layers, the

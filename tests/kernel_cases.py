@@ -180,13 +180,16 @@ def conv_pair_case(rt, N=1, H=9, W=12, shapes=((64, 256, 1, 1), (128, 128, 1, 1)
         assert err <= tol(rt, float(ref.abs().max()) + 1.0), err
 
 
-def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, with_res=False, act2=L.ACT_NONE, out_scale=1.0, seed=0, variant=0, algo_new=4, ld_extra=8):
+def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, with_res=False, act2=L.ACT_NONE, out_scale=1.0, seed=0, variant=0, algo_new=4, ld_extra=8,
+                          slope_hi=0.3):
     """The halo-staged 3x3 kernel (conv_p3x3.hip, algo 4) walks K in the LDS-DMA kernel's order and shares its epilogue
-    arithmetic: the two must agree bit for bit."""
+    arithmetic: the two must agree bit for bit.  variant: algo bits 13, 14 (launch form: 0 = the library's choice, 1 = round-2
+    kernel, 2 = tile per workgroup with the wave-private epilogue, 3 = persistent stream kernel); slope_hi > 0.9: PReLU slopes
+    beyond 1 (the epilogue's general activation path instead of max(t, s t))."""
     g = torch.Generator().manual_seed(seed)
     dev = _dev(rt)
     w = _rounded(rt, torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
-    lay = ConvLayer(rt, w, torch.randn(Cout, generator=g), slope=torch.rand(Cout, generator=g) * 0.3 + 0.1)
+    lay = ConvLayer(rt, w, torch.randn(Cout, generator=g), slope=torch.rand(Cout, generator=g) * slope_hi + 0.1)
     x = torch.randn(N, H, W, Cin, generator=g).to(rt.tdtype).to(dev)
     if split is None:
         x0, x1 = View(x, 0, Cin), None
@@ -203,6 +206,25 @@ def p3x3_equals_glds_case(rt, N, H, W, Cin, Cout, split=None, act1=L.ACT_PRELU, 
         outs.append(out.float().cpu())
     assert float((outs[0][..., Cout:] - 7.0).abs().max()) == 0.0
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+def p3x3_repeat_case(rt, N, H, W, Cin, Cout, reps=5, seed=0):
+    """The halo-staged 3x3 kernel in the library's own launch form, `reps` launches of one problem (residual + PReLU): every
+    launch must reproduce the first bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    dev = _dev(rt)
+    lay = ConvLayer(rt, _rounded(rt, torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5), torch.randn(Cout, generator=g),
+                    slope=torch.rand(Cout, generator=g) * 0.3 + 0.1)
+    x = torch.randn(N, H, W, Cin, generator=g).to(rt.tdtype).to(dev)
+    res = torch.randn(N, H, W, Cout, generator=g).to(rt.tdtype).to(dev)
+    first = None
+    for _ in range(reps):
+        out = torch.full((N, H, W, Cout), 7.0, dtype=rt.tdtype, device=dev)
+        rt.conv(lay, View(x, 0, Cin), View(out, 0, Cout), act1=L.ACT_PRELU, res=View(res, 0, Cout), act2=L.ACT_PRELU, slope2=lay.slope, algo=4)
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(out, first)
 
 
 def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5, ctx_split=False, state_f32=False, wdir=False):

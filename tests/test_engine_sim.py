@@ -134,3 +134,28 @@ def test_whole_model_on_the_emulated_kernels(precision, name, sd):
         else:
             assert p >= 60.0, p          # (the GPU runs of these fixtures: 71 - 76 dB; the gate of the GPU suite is 40)
             assert float(d.mean()) < 0.05
+
+
+def test_zero_once_buffers_are_released_with_the_signature_that_used_them():
+    """Runtime's persistent zero-once buffers (the largest activations of a forward) used to pile up under shape churn.
+    They are now booked per input signature (`once_scope`, set by the models around a forward) and dropped by release_once()
+    when that signature's graph is evicted -- unless another live signature uses the same buffer."""
+    rt = SimRuntime("bf16")
+    rt.once_scope = "sig A"
+    a1 = rt.act(1, 4, 4, 3, once="x")            # 3 channels: padded pitch, zero state needed once
+    a2 = rt.f32(2, 5, zero=True, once="y")
+    assert rt.act(1, 4, 4, 3, once="x") is a1    # handed out again, no new tensor
+    rt.once_scope = "sig B"
+    assert rt.act(1, 4, 4, 3, once="x") is a1    # same (name, shape): shared between the signatures
+    b1 = rt.act(1, 8, 8, 3, once="x")
+    n_all = rt.once_bytes()
+    assert n_all == sum(t.numel() * t.element_size() for t in (a1, a2, b1))
+    rt.release_once("sig A")                     # `y` goes, `x` 4x4 stays (sig B uses it)
+    assert rt.once_bytes() == n_all - a2.numel() * a2.element_size()
+    assert rt.act(1, 4, 4, 3, once="x") is a1
+    rt.release_once("sig B")
+    assert rt.once_bytes() == 0
+    rt.release_once("never seen")                # harmless
+    rt.once_scope = None
+    c = rt.act(1, 4, 4, 3, once="x")             # outside any signature: kept for the runtime's life, as before
+    assert c is not a1 and rt.once_bytes() > 0

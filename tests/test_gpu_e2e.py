@@ -5,11 +5,13 @@ and size-independent properties at the benchmark size (448x256, batch 8).
 Stated tolerances (SURVEY.md 8d): fp32 mode PSNR >= 80 dB and flows within 2e-3 px of the reference;
 bf16 mode (bf16 activations/weights, fp32 accumulate; flows / correlation / splat sums fp32) PSNR >= 40 dB.
 """
+import os
+
 import pytest
 import torch
 
 import gimmvfi_r_oracle as orc
-from util import golden_inputs, load_golden, maxabs, nchw, psnr
+from util import ROOT, golden_inputs, load_golden, maxabs, nchw, psnr
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -265,3 +267,18 @@ def test_cli_13_frames_batched_sequence_equals_per_pair_forwards(tmp_path):
             assert (both[:, :W] == ob).all() and (both[:, W:] == ob).all()
     print(f"CLI 13 frames: |video frame - per-pair forward| max {worst} LSB, mean {tot / cnt:.4f} LSB")
     assert worst <= 4 and tot / cnt <= 0.05, (worst, tot / cnt)
+
+
+@pytest.mark.gpu
+def test_rccl_loads_and_gathers_device_tensors_world_size_1():
+    """`backend="nccl"` (= RCCL on ROCm) has only ever run under gloo here: a one-rank process group on the GPU box proves that
+    librccl loads and that the path's collectives (the round gather of uint8 frames, the abort word, the barrier / max of the
+    timed region) take device tensors -- tools/rccl_smoke.py, in a process of its own.  No bytes cross xGMI at world size 1."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("MASTER_PORT", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_smoke.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RCCL OK world=1 backend=nccl" in r.stdout, r.stdout

@@ -135,6 +135,27 @@ def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
     kc.p3x3_equals_glds_case(rt, 2, 250, 443, 256, 256, split=192, seed=1)                       # ragged tiles, conv3 / conv5 geometry
     kc.p3x3_equals_glds_case(rt, 4, 128, 224, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=2)  # final ResBlock
     kc.p3x3_equals_glds_case(rt, 1, 136, 256, 320, 512, split=256, act1=L.ACT_LRELU, out_scale=0.5, seed=3)
+    # launch form 1: the round-2 kernel (workgroup-wide staging tile)
+    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU, variant=1 << 13)
+    kc.p3x3_equals_glds_case(rt, 4, 128, 224, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=2, variant=1 << 13)
+    torch.cuda.synchronize()
+
+
+def test_p3x3_stream_kernel_is_bit_identical_to_the_lds_dma_kernel(rt):
+    """conv_p3x3.hip's persistent form (one workgroup per CU, its tiles as one stream of channel chunks; see the emulated twin
+    of this test): the library's own choice on the production shapes (>= 2 tiles per CU), the forced form on grids with 1-2
+    tiles per workgroup, ragged borders, two sources, residual, both activation paths -- and five launches of the hot layer
+    in a row, bit-equal (a race between the epilogue's staging and the next tile's DMA would show as a rare difference)."""
+    if rt.precision != "bf16":
+        pytest.skip("bf16-only kernel")
+    V = 3 << 13
+    kc.p3x3_equals_glds_case(rt, 2, 250, 443, 256, 256, split=192, seed=1)                                   # 896 ragged tiles: auto = stream
+    kc.p3x3_equals_glds_case(rt, 8, 256, 448, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=2)             # the hot layer, 14 tiles per CU
+    kc.p3x3_equals_glds_case(rt, 4, 128, 224, 256, 256, with_res=True, act2=L.ACT_PRELU, seed=3, variant=V)  # 448 tiles: 1-2 per workgroup
+    kc.p3x3_equals_glds_case(rt, 1, 136, 256, 320, 256, split=256, act1=L.ACT_LRELU, seed=4, variant=V)      # five chunks
+    kc.p3x3_equals_glds_case(rt, 2, 544, 1024, 256, 256, act1=L.ACT_PRELU, seed=5, slope_hi=2.0)             # 2K / 4K grid, slopes > 1
+    kc.p3x3_equals_glds_case(rt, 1, 200, 330, 64, 256, with_res=True, act2=L.ACT_LRELU, seed=6, variant=V)   # one chunk per tile
+    kc.p3x3_repeat_case(rt, 8, 256, 448, 256, 256, reps=5)
     torch.cuda.synchronize()
 
 

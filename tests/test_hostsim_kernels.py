@@ -152,6 +152,26 @@ def test_p3x3_conv_is_bit_identical_to_the_lds_dma_kernel(rt):
     kc.p3x3_equals_glds_case(rt, 1, 7, 40, 192, 256, split=128, seed=11)                          # odd chunk count, image lower than a tile
     kc.p3x3_equals_glds_case(rt, 1, 33, 5, 320, 256, split=256, act1=L.ACT_NONE, with_res=True, act2=L.ACT_PRELU, seed=13)   # image narrower than a tile
     kc.p3x3_equals_glds_case(rt, 2, 16, 16, 64, 512, with_res=True, act2=L.ACT_LRELU, seed=12)   # two Cout tiles, residual
+    # launch form 1: the round-2 kernel (workgroup-wide staging tile); the calls above take the wave-private epilogue
+    kc.p3x3_equals_glds_case(rt, 1, 18, 17, 128, 256, split=64, with_res=True, act2=L.ACT_PRELU, variant=1 << 13)
+    kc.p3x3_equals_glds_case(rt, 1, 9, 33, 64, 256, act1=L.ACT_LRELU, out_scale=0.5, seed=1, variant=1 << 13)
+
+
+def test_p3x3_stream_kernel_is_bit_identical_to_the_lds_dma_kernel(rt):
+    """conv_p3x3.hip's persistent form: one workgroup per compute unit (the emulator launches 8) walks its tiles as ONE stream of
+    channel chunks -- the next tile's first patch / weight stage arrive during the current tile's last chunk, wave-private
+    epilogue in the LDS the last step read.  Several tiles per workgroup, one / odd / even chunk counts (the patch and weight
+    parities differ from tile to tile), two sources, a workgroup's tiles crossing image rows and images, ragged borders, the
+    residual by LDS-DMA and through registers, both activation paths (all slopes <= 1 / some beyond), and the library's own
+    choice of the form (algo bits 13, 14 = 0) -- all under the emulator's adversarial LDS-DMA timing."""
+    if rt.precision != "bf16":
+        pytest.skip("bf16-only kernel")
+    V = 3 << 13
+    kc.p3x3_equals_glds_case(rt, 1, 40, 72, 64, 256, variant=V, seed=21)                                                   # one chunk per tile
+    kc.p3x3_equals_glds_case(rt, 2, 33, 40, 192, 256, split=128, with_res=True, act2=L.ACT_PRELU, seed=22, variant=V)       # three chunks, two images
+    kc.p3x3_equals_glds_case(rt, 1, 50, 50, 128, 256, act1=L.ACT_LRELU, with_res=True, act2=L.ACT_LRELU, seed=23, variant=V)
+    kc.p3x3_equals_glds_case(rt, 1, 33, 65, 128, 256, with_res=True, act2=L.ACT_PRELU, seed=24, variant=V, slope_hi=2.0)    # slopes > 1
+    kc.p3x3_equals_glds_case(rt, 1, 48, 80, 64, 256, act1=L.ACT_NONE, seed=25, slope_hi=2.0)                               # 15 tiles: the library picks the stream form
 
 
 def test_p3x3s_conv_is_bit_identical_to_the_lds_dma_kernel(rt):

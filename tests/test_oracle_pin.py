@@ -109,3 +109,63 @@ def test_f_param_spec_matches_recorded_reference_keys(sd_f):
     keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys_f.json")))
     assert list(keys.keys()) == list(sd_f.keys())
     assert all(list(sd_f[k].shape) == v for k, v in keys.items())
+
+
+def _splat_thread_loop(ten_in, flow):
+    """Independent statement of the reference's ONE native kernel (CuPy `softsplat_out`, modules/softsplat.py:371-421), written
+    the way the kernel is: one "thread" per INPUT element intIndex = ((n * C + c) * H + y) * W + x, floor / +1 corners, the four
+    bilinear weights as products of corner distances, one guarded add per corner -- no tensor operation, no scatter, float32
+    arithmetic through numpy scalars.  ("cross-check it against an independent O(P) reference loop".)"""
+    import numpy as np
+
+    a = ten_in.numpy()
+    f = flow.numpy()
+    N, C, H, W = a.shape
+    out = np.zeros_like(a)
+    f32 = np.float32
+    for n in range(N):
+        for c in range(C):
+            for y in range(H):
+                for x in range(W):
+                    flt_x = f32(x) + f[n, 0, y, x]
+                    flt_y = f32(y) + f[n, 1, y, x]
+                    if not (np.isfinite(flt_x) and np.isfinite(flt_y)):
+                        continue
+                    v = a[n, c, y, x]
+                    nw_x = int(np.floor(flt_x))
+                    nw_y = int(np.floor(flt_y))
+                    ne_x, ne_y = nw_x + 1, nw_y
+                    sw_x, sw_y = nw_x, nw_y + 1
+                    se_x, se_y = nw_x + 1, nw_y + 1
+                    w_nw = (f32(se_x) - flt_x) * (f32(se_y) - flt_y)
+                    w_ne = (flt_x - f32(sw_x)) * (f32(sw_y) - flt_y)
+                    w_sw = (f32(ne_x) - flt_x) * (flt_y - f32(ne_y))
+                    w_se = (flt_x - f32(nw_x)) * (flt_y - f32(nw_y))
+                    for tx, ty, w in ((nw_x, nw_y, w_nw), (ne_x, ne_y, w_ne), (sw_x, sw_y, w_sw), (se_x, se_y, w_se)):
+                        if 0 <= tx < W and 0 <= ty < H:
+                            out[n, c, ty, tx] += v * w
+    return torch.from_numpy(out)
+
+
+def test_splat_restatements_match_an_independent_per_element_loop():
+    """Both vectorised statements of `softsplat_out` -- the oracle's (gimmvfi_r_oracle.splat_sum) and the one the reference is
+    run with on the CPU (ref_harness._cpu_softsplat_out) -- against the thread-per-element loop above: sub-pixel, large,
+    out-of-range, exactly integral and non-finite flows, several sources landing in one cell.  The sums are float adds in
+    different orders, hence 1e-5 (atomics order => 1e-5 abs)."""
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 2, 3, 9, 11
+    x = torch.randn(N, C, H, W, generator=g)
+    flow = torch.randn(N, 2, H, W, generator=g) * 3.0
+    flow[0, :, 0, 0] = torch.tensor([2.0, 1.0])          # integral target: one corner takes everything
+    flow[0, :, 1, 1] = torch.tensor([-40.0, 3.0])        # far outside
+    flow[0, :, 2, 2] = torch.tensor([float("nan"), 0.5])
+    flow[1, :, 3, 3] = torch.tensor([0.25, float("inf")])
+    flow[1, 0, 4, :] = 10.5 - torch.arange(W, dtype=torch.float32)     # a whole row lands in one column
+    flow[1, 1, 4, :] = 0.5
+    flow[0, :, H - 1, W - 1] = torch.tensor([0.5, 0.5])  # two of four corners outside
+    ref = _splat_thread_loop(x, flow)
+    assert float(ref.abs().max()) > 1.0
+    for name, fn in (("oracle", orc.splat_sum), ("ref_harness", rh._cpu_softsplat_out)):
+        got = fn(x, flow)
+        assert torch.isfinite(got).all(), name
+        assert maxabs(got, ref) <= 1e-5, (name, maxabs(got, ref))

@@ -1,4 +1,4 @@
-"""debug: where does a variant of conv_p3x3 differ from variant 0"""
+"""debug: where does a launch form of conv_p3x3 (algo bits 13, 14) differ from form 1 (the round-2 kernel), run to run"""
 import os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "gimm-vfi_amd"))
@@ -15,7 +15,7 @@ res = torch.randn(N, H, W, Cout, device="cuda").to(rt.tdtype)
 for with_res in (False, True):
     kw = dict(res=res, act2=L.ACT_PRELU, slope2=lay.slope) if with_res else {}
     outs = []
-    for v in (0, VAR, VAR, VAR):
+    for v in (1, VAR, VAR, VAR):
         out = rt.act(N, H, W, Cout)
         out.fill_(3.0)
         rt.conv(lay, View(x, 0, Cin), out, act1=L.ACT_PRELU, algo=4 + (v << 13), **kw)
