@@ -173,6 +173,29 @@ __device__ __forceinline__ Lerp src_index(int d, float rscale, int n) {
     return r;
 }
 
+// InstanceNorm statistics (sum, sum of squares per image and channel) are accumulated as 64-bit FIXED-POINT integers: integer
+// addition is associative, so the result does not depend on the order in which the workgroups' atomics arrive -- the float
+// atomics they replace (round 6) were the one run-to-run freedom of the whole path (1e-2 px of flow after RAFT's 20 iterations).
+// A workgroup's partial sums are float (fixed order inside the workgroup); 2^-24 / 2^-20 is below their own rounding.
+// Layout: stats[(n * C + c) * 2 + {0, 1}] as long long (16 bytes per image and channel), zeroed by the caller.
+#define GVFI_STATS_Q0 16777216.0f
+#define GVFI_STATS_Q1 1048576.0f
+__device__ __forceinline__ void gvfi_stats_add(float* stats, long long slot, float s0, float s1) {
+    unsigned long long* q = (unsigned long long*)stats + slot * 2;
+#ifndef GVFI_HOSTSIM
+    atomicAdd(q, (unsigned long long)__float2ll_rn(s0 * GVFI_STATS_Q0));
+    atomicAdd(q + 1, (unsigned long long)__float2ll_rn(s1 * GVFI_STATS_Q1));
+#else
+    __atomic_fetch_add(q, (unsigned long long)llrintf(s0 * GVFI_STATS_Q0), __ATOMIC_RELAXED);
+    __atomic_fetch_add(q + 1, (unsigned long long)llrintf(s1 * GVFI_STATS_Q1), __ATOMIC_RELAXED);
+#endif
+}
+__device__ __forceinline__ void gvfi_stats_get(const float* stats, long long slot, float& s0, float& s1) {
+    const long long* q = (const long long*)stats + slot * 2;
+    s0 = (float)((double)q[0] * (1.0 / 16777216.0));
+    s1 = (float)((double)q[1] * (1.0 / 1048576.0));
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // unsigned division by an invariant divisor d (1 <= d < 2^31) for dividends x < 2^31:
 //   x / d == (umulhi(x, mul) + x) >> sh     (Granlund-Montgomery round-up method, 33-bit magic minus 2^32)

@@ -939,8 +939,7 @@ __device__ __forceinline__ void conv_igemm_glds_body(const ConvArgs2& a, const i
             const int c = n0 + tid;
             if (c < p.Cout) {
                 const long long img = ((long long)g * a.Mg + m_tile0) / HoWo;
-                atomicAdd(p.stats + (img * p.Cout + c) * 2 + 0, s0);
-                atomicAdd(p.stats + (img * p.Cout + c) * 2 + 1, s1);
+                gvfi_stats_add(p.stats, img * p.Cout + c, s0, s1);
             }
         }
     }

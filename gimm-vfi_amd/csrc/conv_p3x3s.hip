@@ -330,8 +330,7 @@ template <int BN, int CK, bool PROF = false> __global__ void __launch_bounds__(2
                     s0 += red[t * 16 + e];
                     s1 += red[t * 16 + 8 + e];
                 }
-                atomicAdd(p.stats + ((long long)img * p.Cout + tid) * 2 + 0, s0);
-                atomicAdd(p.stats + ((long long)img * p.Cout + tid) * 2 + 1, s1);
+                gvfi_stats_add(p.stats, (long long)img * p.Cout + tid, s0, s1);
             }
         }
     }

@@ -57,7 +57,8 @@ extern "C" int gvfi_prep_images(const float* img_xs, void* act, float* img4, int
 // ------------------------------------------------------------------ InstanceNorm2d   raft/extractor.py:17-25,168-220
 // (nn.InstanceNorm2d defaults: biased variance over H*W per (n, c), eps = 1e-5, no affine)
 // Both passes are pure HBM streams: 16-byte vectors (8 bf16 / 4 f32 channels of one pixel per lane), the
-// statistics pass reduces the pixel lanes of a workgroup through LDS and issues one atomic pair per channel.
+// statistics pass reduces the pixel lanes of a workgroup through LDS and issues one (fixed-point, order-independent: gvfi_stats_add)
+// atomic pair per channel.
 #define IN_CHUNK 2048
 template <typename T> struct alignas(16) Vec16 { T e[Elem<T>::VE]; };
 
@@ -99,8 +100,7 @@ __global__ void instnorm_stats_kernel(const T* __restrict__ x, int ld, int C, in
             a0 += red[0][l * C + threadIdx.x];
             a1 += red[1][l * C + threadIdx.x];
         }
-        atomicAdd(&stats[((long long)n * C + threadIdx.x) * 2 + 0], a0);
-        atomicAdd(&stats[((long long)n * C + threadIdx.x) * 2 + 1], a1);
+        gvfi_stats_add(stats, (long long)n * C + threadIdx.x, a0, a1);
     }
 }
 extern "C" int gvfi_instnorm_stats(const void* x, int ld, int C, int N, int HW, float* stats, int dtype, void* stream) {
@@ -129,9 +129,10 @@ __global__ void instnorm_apply_kernel(const T* __restrict__ x, int ld, int C, lo
     if (res) r = *(const Vec16<T>*)(res + pix * ldr + c0);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-        const float2 st = *(const float2*)(stats + ((long long)n * C + c0 + e) * 2);
-        const float mean = st.x * inv;
-        float var = st.y * inv - mean * mean;
+        float s0, s1;
+        gvfi_stats_get(stats, (long long)n * C + c0 + e, s0, s1);
+        const float mean = s0 * inv;
+        float var = s1 * inv - mean * mean;
         if (var < 0.f) var = 0.f;
         float f = (Elem<T>::ld(&v.e[e]) - mean) / sqrtf(var + 1e-5f);
         if (relu && f < 0.f) f = 0.f;

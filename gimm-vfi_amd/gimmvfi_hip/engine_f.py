@@ -778,4 +778,4 @@ class EngineF(Engine):
         of the Twins context encoder at 1/4 and 1/8 -- no projections in this model."""
         flow_up, fmap, cfeat, (h8, w8) = self._flowformer(imgA, B, iters, taps, seq)
         pyr, pyrT = self._bidir_pyramids(fmap, B, h8, w8)
-        return flow_up[:B], flow_up[B:], pyr, pyrT, cfeat[0], cfeat[1], (h8, w8)
+        return flow_up[:B], flow_up[B:], {"pyr": pyr, "pyrT": pyrT, "feat4": cfeat[0], "feat8": cfeat[1]}, (h8, w8)

@@ -396,7 +396,8 @@ class Runtime:
         leaves finalised, clamp((y + 1) / 2, 0, 1), in planar form there and `out` is NOT written (gvfi_finalize_image folded
         in); ``self.last_planar`` says whether that happened (else the caller finalises `out` itself).
         state_f32 (GRU epilogues, bf16 mode): the recurrent state tensors are float (gvfi_conv_params.state_f32).
-        stats: optional zero-initialised f32 [N, cout, 2]; when the library can fuse the InstanceNorm statistics
+        stats: optional zero-initialised f32 [N, cout, 4] (= two 64-bit fixed-point sums per image and channel, stats_tensor());
+        when the library can fuse the InstanceNorm statistics
         into this convolution (gvfi_conv2d_stats_ok) they are accumulated there and True is returned in
         ``self.last_stats_fused``, else the caller computes them with instnorm_stats."""
         x0 = V(x0)
@@ -640,12 +641,22 @@ class Runtime:
                                        self.stream()), "prep_images")
         return act, img4
 
+    def stats_tensor(self, n, c):
+        """Zeroed InstanceNorm statistics of n images x c channels: two 64-bit fixed-point sums each (gvfi_conv_params.stats)."""
+        return self.f32(n, c, 4, zero=True)
+
+    @staticmethod
+    def stats_values(stats):
+        """[n, c, 2] float (sum, sum of squares) of a statistics tensor (tests / diagnostics)."""
+        q = stats.contiguous().view(torch.int64).to(torch.float64)
+        return torch.stack([q[..., 0] / 2.0 ** 24, q[..., 1] / 2.0 ** 20], -1).float()
+
     def instnorm(self, x, c, relu, res=None, out=None, stats=None):
-        """stats: [n, c, 2] already accumulated by the producing convolution (Runtime.conv(stats=...)), else None."""
+        """stats: [n, c, 4] (stats_tensor) already accumulated by the producing convolution (Runtime.conv(stats=...)), else None."""
         x = V(x)
         n, h, w = x.t.shape[:3]
         if stats is None:
-            stats = self.f32(n, c, 2, zero=True)
+            stats = self.stats_tensor(n, c)
             self._chk(self.lib.instnorm_stats(x.ptr, x.ld, c, n, h * w, stats.data_ptr(), self.dtype, self.stream()),
                       "instnorm_stats")
         out = V(self.act(n, h, w, c) if out is None else out)

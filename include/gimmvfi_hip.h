@@ -76,10 +76,11 @@ typedef struct {
     void* y2; int ldy2;                 /* GRU_ZR: r*h destination                          */
     const void* aux0; int lda0;         /* GRU: h                                           */
     const void* aux1; int lda1;         /* GRU_Q: z                                         */
-    float* stats;                       /* optional [N][Cout][2]: per (image, channel) sum and sum of squares of the stored
-                                         * outputs, atomically accumulated by the LDS-DMA kernel's bf16 store loop
-                                         * (InstanceNorm statistics of raft/extractor.py:26-58 fused into the producing
-                                         * convolution); needs Ho*Wo % BM == 0, see gvfi_conv2d_stats_ok */
+    float* stats;                       /* optional [N][Cout][2] x 8 bytes: per (image, channel) sum and sum of squares of the
+                                         * stored outputs as 64-bit fixed point (Q24 / Q20: integer atomics, the result does not
+                                         * depend on the workgroups' order -- round 6; zeroed by the caller), accumulated by the
+                                         * LDS-DMA kernel's bf16 store loop (InstanceNorm statistics of raft/extractor.py:26-58
+                                         * fused into the producing convolution); needs Ho*Wo % BM == 0, see gvfi_conv2d_stats_ok */
     int tile_hint;                      /* 0 = auto, else BN | BM << 10 | NS << 20: Cout tile width 32/64/128/256, (LDS-DMA
                                          * kernel) pixel tile height 64/128 (BN = 128) or 128/256 (BN = 32), and ring depth
                                          * NS = 2..4 of its 128-byte K chunks (4-wave tiles) */
@@ -197,7 +198,8 @@ int gvfi_resize_planes_f32(const float* src, float* dst, int planes, int H, int 
 int gvfi_prep_images(const float* img_xs, void* act, float* img4, int B, int H, int W, int dtype, void* stream);
 
 /* ---- InstanceNorm2d (affine=False, eps=1e-5) of raft fnet, raft/extractor.py:26-30,50-58 */
-int gvfi_instnorm_stats(const void* x, int ld, int C, int N, int HW, float* stats /*[N][C][2] zeroed*/,
+int gvfi_instnorm_stats(const void* x, int ld, int C, int N, int HW, float* stats /*[N][C][2] x 8 bytes (64-bit fixed point, see
+                        gvfi_conv_params.stats), zeroed*/,
                         int dtype, void* stream);
 /* out = relu?( (x-mean)*rstd );  if res: out = relu(res + out) */
 int gvfi_instnorm_apply(const void* x, int ld, int C, int N, int HW, const float* stats, int relu,

@@ -392,12 +392,12 @@ def conv_stats_case(rt, N=2, H=16, W=16, Cin=64, Cout=64, tile=0, algo=0):
     lay = ConvLayer(rt, w, b)
     xa = _to_act(rt, x).to(dev)
     out = rt.act(N, H, W, Cout)
-    stats = rt.f32(N, Cout, 2, zero=True)
+    stats = rt.stats_tensor(N, Cout)
     rt.conv(lay, xa, out, stats=stats, tile=tile, algo=algo)
     assert rt.last_stats_fused
     o = out.float().cpu()
     ref = torch.stack([o.sum((1, 2)), (o * o).sum((1, 2))], -1)          # [N, Cout, 2] of the stored (rounded) values
-    err = float((stats.cpu() - ref).abs().max())
+    err = float((rt.stats_values(stats.cpu()) - ref).abs().max())
     assert err <= 1e-3 * float(ref.abs().max()), err
     # and the normalisation that consumes them equals F.instance_norm of the stored tensor
     y = rt.instnorm(out, Cout, relu=False, stats=stats).t.float().cpu()
@@ -407,7 +407,7 @@ def conv_stats_case(rt, N=2, H=16, W=16, Cin=64, Cout=64, tile=0, algo=0):
         return
     # a shape whose tiles straddle images is refused (caller falls back to gvfi_instnorm_stats)
     out2 = rt.act(N, H - 1, W - 5, Cout)
-    rt.conv(lay, _to_act(rt, x[:, :, :H - 1, :W - 5]).to(dev), out2, stats=rt.f32(N, Cout, 2, zero=True))
+    rt.conv(lay, _to_act(rt, x[:, :, :H - 1, :W - 5]).to(dev), out2, stats=rt.stats_tensor(N, Cout))
     assert not rt.last_stats_fused
 
 
