@@ -558,7 +558,7 @@ class EngineF(Engine):
         hB = rt.act(n, h8, w8, 128)
         inp = rt.act(n, h8, w8, 128)
         # bf16 mode: float GRU state beside the bf16 operand copies, as in Engine._raft
-        sf = self.gru_state_f32 and rt.precision == "bf16"
+        sf = self.gru_state_f32 and rt.precision in ("bf16", "fp16")
         h32A = rt.f32(n, h8, w8, 128) if sf else None
         h32B = rt.f32(n, h8, w8, 128) if sf else None
         if sf:

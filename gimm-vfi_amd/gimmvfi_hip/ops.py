@@ -299,6 +299,8 @@ class Runtime:
             warnings.warn(f"gimmvfi_hip: GVFI_WDIR_DBG={self.wdir_dbg} is set -- the weights-direct convolutions skip phases of their "
                           "work (profiling only): EVERY FRAME OF THIS RUNTIME IS GARBAGE", RuntimeWarning, stacklevel=2)
         self.wdir_bm128 = os.environ.get("GVFI_WDIR_BM128", "0") == "1"       # A/B switch: 128-row weights-direct tiles (see conv())
+        self.wdir_bm128_max = int(os.environ.get("GVFI_WDIR_BM128_MAX", "16384"))     # (largest pixel count that takes them)
+        self.wdir_bm128_cout = int(os.environ.get("GVFI_WDIR_BM128_COUT", "129"))     # (smallest Cout that takes them)
 
     def sibling(self, precision):
         """A runtime of another precision over the same library and device (GIMM-VFI-F's float flow-estimator stages)."""
@@ -431,7 +433,7 @@ class Runtime:
                 algo = 2 | (algo & ~15) | (self.wdir_dbg << 8)
                 # 128-row tiles for the layers with two 128-column tiles (Cout > 128) while the 64-row grid would exceed half of the
                 # chip's 512 workgroup slots: half the weight stream per pixel, and both lanes' launches co-reside (GVFI_WDIR_BM128)
-                if self.wdir_bm128 and tile == 0 and layer.cout > 128 and 12288 <= n * h * w_ <= 16384:
+                if self.wdir_bm128 and tile == 0 and layer.cout >= self.wdir_bm128_cout and 12288 <= n * h * w_ <= self.wdir_bm128_max:
                     tile = 128 | (128 << 10)
                 want = 2
             elif want in (0, 2, 4) and aligned and not (algo & 128):
