@@ -14,6 +14,16 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libgimmvfi_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# Packed fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) are switched OFF for the whole library.  Round 6 found
+# (tools/concurrency_repro.py, tools/victims2.py, profiles/r6_concurrency_repro.txt): a plain gather kernel whose compiler-generated
+# code feeds freshly loaded registers to a packed fp32 instruction computes wrong values in lanes 48..63 of a wave -- a few hundred
+# pixels per launch, only while waves of an LDS-DMA kernel (buffer_load ... lds) are resident on the same CU, i.e. only when the
+# engine's parallel launch sequences put such kernels side by side.  Forcing s_waitcnt vmcnt(0) after every memory instruction does
+# not help; the same source without packed fp32 instructions is exact (two independent kernels, 0 of 200 launches vs 170-190 of 200).
+# The scalar forms have the same throughput on CDNA4's fp32 pipe for these bandwidth-bound kernels; the MFMA kernels lose nothing
+# measurable (profiles/r6_nopk_ab.txt).  GVFI_PACKED_FP32=1 builds with the compiler's default, for reproducing the finding.
+if os.environ.get("GVFI_PACKED_FP32", "0") != "1":
+    FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _deps():

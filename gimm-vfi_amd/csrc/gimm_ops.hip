@@ -91,14 +91,21 @@ __device__ __forceinline__ void sample_border2(const float* __restrict__ img, in
     const float x0f = floorf(fx), y0f = floorf(fy);
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float ax = fx - x0f, ay = fy - y0f;
-    const bool x1ok = x0 + 1 < W, y1ok = y0 + 1 < H;
-    const float* p = img + ((long long)y0 * W + x0) * 2;
+    // the four taps as UNCONDITIONAL loads: a neighbour beyond the border is read at the clamped index and enters with the
+    // weight the clamped coordinate gives it -- exactly 0 (ax == 0 on the last column, ay == 0 on the last row), so the sum
+    // is the border sample.  (Round 6: with the taps behind `if (x1ok)` / `if (y1ok)` the compiler emitted a load / wait /
+    // packed-fp32 sequence per tap, and this kernel returned different values in lanes 48..63 of a few waves whenever an
+    // LDS-DMA kernel was resident on the same CUs; see profiles/r6_concurrency_repro.txt.  The library is built without
+    // packed fp32 instructions since -- build.py -- and this form stays because it is also the faster one: four loads in flight.)
+    const int x1 = x0 + 1 < W ? x0 + 1 : x0, y1 = y0 + 1 < H ? y0 + 1 : y0;
+    const float2 p00 = *(const float2*)(img + ((long long)y0 * W + x0) * 2), p10 = *(const float2*)(img + ((long long)y0 * W + x1) * 2);
+    const float2 p01 = *(const float2*)(img + ((long long)y1 * W + x0) * 2), p11 = *(const float2*)(img + ((long long)y1 * W + x1) * 2);
     float w = (1.f - ax) * (1.f - ay);
-    o0 = w * p[0];
-    o1 = w * p[1];
-    if (x1ok) { w = ax * (1.f - ay); o0 += w * p[2]; o1 += w * p[3]; }
-    if (y1ok) { w = (1.f - ax) * ay; o0 += w * p[2 * W]; o1 += w * p[2 * W + 1]; }
-    if (x1ok && y1ok) { w = ax * ay; o0 += w * p[2 * W + 2]; o1 += w * p[2 * W + 3]; }
+    o0 = w * p00.x;
+    o1 = w * p00.y;
+    w = ax * (1.f - ay); o0 += w * p10.x; o1 += w * p10.y;
+    w = (1.f - ax) * ay; o0 += w * p01.x; o1 += w * p01.y;
+    w = ax * ay; o0 += w * p11.x; o1 += w * p11.y;
 }
 __global__ void splat_weights_kernel(const float* __restrict__ f01, const float* __restrict__ f10,
                                      const float* __restrict__ g9, float alpha_v, float alpha_fe,

@@ -553,7 +553,6 @@ class Engine:
         z0, z1 = rt.f32(B, H, W), rt.f32(B, H, W)
         rt._chk(lib.splat_weights(f01.data_ptr(), f10.data_ptr(), self.g9.data_ptr(), self.alpha_v, self.alpha_fe,
                                   z0.data_ptr(), z1.data_ptr(), B, H, W, st()), "splat_weights")
-        self._start_side()
         e0 = rt.act(n, H, W, 16)
         rt.conv(Ls["cnn_encoder.0"], View(nfA, 0, 2), e0)
         e = rt.act(n, H, W, 32)
@@ -699,14 +698,7 @@ class Engine:
 
         def deferred(fn):
             def run(*a):
-                # Not launched here: _start_side() forks it BEHIND the splat-metric kernel of _motion_encode.  Round 6, once the
-                # InstanceNorm statistics were order-independent and the forward otherwise bit-reproducible: with the side
-                # sequence (the 300 MB volume GEMMs + the up-sampling stacks at 2K) running beside it, that kernel -- the one
-                # data-dependent gather of this stretch, -warp(f_rev, f) -- came out different in a few 16-pixel runs (one
-                # 128-byte line of the flow field each), differently in every launch, in eager mode as in a captured graph, with
-                # system-scope loads too; every other kernel of the stretch reproduced bit for bit.  Root cause not established
-                # (tools/post_lane_dbg.py reproduces it); behind the fork point chosen here the forward is bit-reproducible
-                # (tests/test_gpu_e2e.py: 50 replays == the serial forward).
+                # (launched by _start_side(), right behind the flow estimator: the fork needs the main stream's position there)
                 self._side_pending.append((fn, a))
             return run if defer else fn
 
@@ -714,6 +706,7 @@ class Engine:
         f01, f10, side_out, (h8, w8) = self._flow(imgA, B, iters, taps, seq, front=front, wrap_side=deferred)
         if "feat4" in side_out and not pre:      # (GIMM-VFI-F: the flow estimator's own features; only `front` is deferred)
             deferred(front)(side_out["feat4"], side_out["feat8"])
+        self._start_side()
         h4, w4 = H // 4, W // 4
         scaler = rt.f32(B, zero=True)
         rt._chk(lib.flow_absmax(f01.data_ptr(), f10.data_ptr(), scaler.data_ptr(), B, HW, st()), "flow_absmax")
@@ -724,8 +717,7 @@ class Engine:
         raft_flow = torch.stack([rt.nhwc_to_nchw(f01, 2), rt.nhwc_to_nchw(f10, 2)], dim=2)
 
         # ---- predict_flow (gimmvfi_r.py:158-211): splat metric + latent encoder
-        z0, z1, latcat = self._motion_encode(nfA, f01, f10, B, H, W)      # (forks the deferred side sequence: _start_side)
-        self._start_side()
+        z0, z1, latcat = self._motion_encode(nfA, f01, f10, B, H, W)
         pyr, pyrT, feat4, feat8 = side_out["pyr"], side_out["pyrT"], side_out["feat4"], side_out["feat8"]
         if taps is not None:
             taps["f01"], taps["f10"] = f01, f10

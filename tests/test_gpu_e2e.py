@@ -349,10 +349,97 @@ def test_parallel_launch_sequences_replay_bit_identically_to_the_serial_forward(
     forked = build(True)
     eng = forked.engine(DEV)
     assert eng.raft_lanes == 2 and eng.enc_lanes and eng.post_lanes and eng.synth_lanes
-    for rep in range(50):
+    for rep in range(int(os.environ.get("HAZARD_REPLAYS", "50"))):
         poison()
         got = run(forked)
         for name, a, b in zip(("frames", "flow estimator output", "INR flows"), got, ref):
             assert torch.isfinite(a).all(), (rep, name)
             assert torch.equal(a, b), (rep, name, float((a - b).abs().max()), int((a != b).sum()))
-    print(f"{cfg}: 50 poisoned replays of the forked graph == the serial forward, bit for bit")
+    # ... and beside an ADVERSARIAL PARTNER: a second stream running 4-wave LDS-DMA convolutions on unrelated tensors, so that the
+    # forward's kernels share compute units with LDS-DMA waves.  Round 6 found two plain gather kernels (the splat metric, the
+    # combine front half) computing wrong values in lanes 48..63 of a few waves exactly then -- compiler-generated load / wait /
+    # packed-fp32 sequences, profiles/r6_concurrency_repro.txt; the library is built without packed fp32 instructions since, and
+    # this sweep looks for anything of the kind anywhere in the forward.
+    from gimmvfi_hip import lib as L
+    from gimmvfi_hip.ops import ConvLayer, View
+
+    rt = eng.rt
+    g = torch.Generator().manual_seed(0)
+    lay1 = ConvLayer(rt, torch.randn(256, 256, 1, 1, generator=g) / 16, torch.randn(256, generator=g))
+    lay64 = ConvLayer(rt, torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g))
+    px, py = torch.randn(2, 272, 512, 256, device=DEV).to(rt.tdtype), rt.act(2, 272, 512, 256)
+    qx, qy = torch.randn(2, 544, 1024, 64, device=DEV).to(rt.tdtype), rt.act(2, 544, 1024, 64)
+    sb = torch.cuda.Stream()
+    for rep in range(6):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sb):
+            for i in range(300 if H * W > 500000 else 120):
+                if i & 1:
+                    rt.conv(lay1, View(px, 0, 256), py, algo=2, tile=128)
+                else:
+                    rt.conv(lay64, View(qx, 0, 64), qy)
+        got = run(forked)
+        diffs = [(name, int((a != b).sum()), float((a - b).abs().max())) for name, a, b in zip(("frames", "flow estimator output", "INR flows"), got, ref)]
+        if diffs[0][1]:
+            idx = (got[0] != ref[0]).nonzero()
+            diffs.append(("where", [sorted(set(idx[:, k].tolist()))[:12] for k in range(idx.shape[1] - 2)],
+                          (int(idx[:, -2].min()), int(idx[:, -2].max())), (int(idx[:, -1].min()), int(idx[:, -1].max()))))
+        assert all(d[1] == 0 for d in diffs), ("beside LDS-DMA partners", rep, diffs)
+    print(f"{cfg}: 50 poisoned replays of the forked graph == the serial forward, bit for bit; 6 more beside LDS-DMA partners too")
+
+
+@pytest.mark.gpu
+def test_plain_gather_kernels_are_not_disturbed_by_lds_dma_kernels_on_the_same_cus():
+    """The round-6 reproducers in the suite (profiles/r6_concurrency_repro.txt): gvfi_splat_weights (3x3 neighbourhood + one
+    bilinear warp of a float flow field) and gvfi_combine_warps_up (six bilinear samples of two images per pixel) -- no LDS, no
+    atomics, constant inputs -- launched repeatedly on one stream while a second stream runs LDS-DMA convolutions that leave room
+    for other waves on their CUs.  Built with the compiler's packed fp32 instructions, 170-190 of 200 (splat, round-5 source) and
+    60 of 60 (combine) launches came out different in lanes 48..63 of a few waves; every launch must equal the solo result."""
+    from gimmvfi_hip import lib as L
+    from gimmvfi_hip.ops import ConvLayer, Runtime, View
+
+    rt = Runtime(L.get(), "bf16", DEV)
+    lib = rt.lib
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 1, 544, 1024
+    base = torch.randn(B, 2, H // 8, W // 8, generator=g).to(DEV) * 3
+    f01 = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+    f10 = -torch.nn.functional.interpolate(base.flip(1), size=(H, W), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+    g9 = torch.tensor([1, 2, 1, 2, 4, 2, 1, 2, 1], dtype=torch.float32, device=DEV) / 16
+    Bc, Hc, Wc = 8, 256, 448
+    dec = torch.randn(Bc, Hc, Wc, 24, generator=g).to(DEV)
+    i0, i1 = torch.randn(Bc, Hc, Wc, 4, generator=g).to(DEV), torch.randn(Bc, Hc, Wc, 4, generator=g).to(DEV)
+
+    def metric(o):
+        rt._chk(lib.splat_weights(f01.data_ptr(), f10.data_ptr(), g9.data_ptr(), 1.0, 1.0, o[0].data_ptr(), o[1].data_ptr(), B, H, W,
+                                  rt.stream()), "splat_weights")
+
+    def combine(o):
+        rt._chk(lib.combine_warps_up(i0.data_ptr(), i1.data_ptr(), dec.data_ptr(), 24, Hc, Wc, o[0].data_ptr(), 16, 16, o[1].data_ptr(),
+                                     o[2].data_ptr(), o[3].data_ptr(), Bc, 0, Hc, Wc, rt.dtype, rt.stream()), "combine_warps_up")
+
+    lay1 = ConvLayer(rt, torch.randn(256, 256, 1, 1, generator=g) / 16, torch.randn(256, generator=g))
+    lay64 = ConvLayer(rt, torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g))
+    px, py = torch.randn(2, 272, 512, 256, device=DEV).to(rt.tdtype), rt.act(2, 272, 512, 256)
+    qx, qy = torch.randn(2, 544, 1024, 64, device=DEV).to(rt.tdtype), rt.act(2, 544, 1024, 64)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for name, fn, mkout, n in (("splat_weights", metric, lambda: (torch.empty(B, H, W, device=DEV), torch.empty(B, H, W, device=DEV)), 100),
+                               ("combine_warps_up", combine, lambda: (torch.zeros(Bc, Hc, Wc, 16, device=DEV, dtype=rt.tdtype),
+                                                                     torch.empty(Bc, Hc, Wc, 4, device=DEV), torch.empty(Bc, 3, 2, Hc, Wc, device=DEV),
+                                                                     torch.empty(Bc, 3, 2, Hc, Wc, device=DEV)), 40)):
+        ref = mkout()
+        fn(ref)
+        outs = [mkout() for _ in range(n)]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sb):
+            for i in range(120):
+                if i & 1:
+                    rt.conv(lay1, View(px, 0, 256), py, algo=2, tile=128)
+                else:
+                    rt.conv(lay64, View(qx, 0, 64), qy)
+        with torch.cuda.stream(sa):
+            for o in outs:
+                fn(o)
+        torch.cuda.synchronize()
+        bad = [sum(int((a != b).sum()) for a, b in zip(o, ref)) for o in outs]
+        assert sum(bad) == 0, (name, sum(1 for b_ in bad if b_), sorted(set(bad))[:8])
