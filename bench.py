@@ -192,7 +192,7 @@ def hot_kernel_clock(dev):
                     "a lower bound of the shader clock (the PROF build's stamps add cycles the plain launch does not spend)"}
 
 
-def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None, ev_over_ms=None):
+def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None, ev_over_ms=None, in_flight=1):
     """One workload c (model / batch / frame size / ds / n_interp / precision): the timed region of the driver contract
     (timed_steps), then -- rank 0 -- an instrumented eager pass for the per-kernel roofline figures.  Returns the result
     dict on rank 0 (None elsewhere)."""
@@ -222,13 +222,36 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
         shp = (B, H, W, 3) if NI == 2 else (B, NI - 1, H, W, 3)
         gather_buf = [torch.empty(shp, dtype=torch.uint8, device=dev) for _ in range(world)]
 
-    def step():
-        out = model(x, coords, t=ts, ds_factor=ds)
-        frames = rt.frames_to_u8(out["imgt_pred"][0]) if NI == 2 else torch.stack([rt.frames_to_u8(f) for f in out["imgt_pred"]], 1)
+    def finish(out, m):
+        u8 = m.engine(dev).rt.frames_to_u8
+        frames = u8(out["imgt_pred"][0]) if NI == 2 else torch.stack([u8(f) for f in out["imgt_pred"]], 1)
         if world > 1:
             dist.gather(frames, gather_buf, dst=0)   # the path's only collective: result gather to rank 0
         return frames
 
+    # in_flight > 1: that many independent steps overlap on the device (gimmvfi_hip.model.StepsInFlight: one replica of the model,
+    # one stream and one captured graph per slot, slot k takes steps k, k + depth, ...).  Every step still does all of its work
+    # inside the timed region -- timed_steps() synchronises the device before it stops the clock -- and its frames are bit-identical
+    # to the same step run alone.  Each slot has its own resident input batch (different seeds).
+    pipe, xs = None, [x]
+    if in_flight > 1:
+        from gimmvfi_hip.model import StepsInFlight
+
+        pipe = StepsInFlight(model, depth=in_flight)
+        xs = [x] + [synthetic_pairs(B, H, W, seed=100 + rank + 1000 * k).to(dev) for k in range(1, in_flight)]
+    nstep = [0]
+
+    def step():
+        if pipe is None:
+            return finish(model(x, coords, t=ts, ds_factor=ds), model)
+        k = nstep[0] % in_flight
+        nstep[0] += 1
+        return pipe.submit(xs[k], coords, ts, ds_factor=ds, then=finish)
+
+    if pipe is not None:
+        for k in range(1, in_flight):        # set-up, like building the model: every further slot captures its graph before the warm-up steps
+            pipe.replicas[k](xs[k], coords, t=ts, ds_factor=ds)
+        torch.cuda.synchronize()
     dt = timed_steps(step, steps, warmup, world, torch.cuda.synchronize)
     dt_rank = dt
     # Roofline pass: the timed steps above replay a hipGraph (no host work between kernels), and HIP events cannot
@@ -302,13 +325,13 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
         res = {"value": round(value, 3), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                "dtype": c["precision"], "workload": workload_name(c), "roofline": roofline, "ev_over_ms": ev_over_ms,
                "ev_steps": ev_steps, "flow_iters": 20 if c["model"] == "r" else 32,
-               "gather_bytes_per_rank_per_step": B * (NI - 1) * H * W * 3 if world > 1 else 0}
+               "gather_bytes_per_rank_per_step": B * (NI - 1) * H * W * 3 if world > 1 else 0, "steps_in_flight": in_flight}
         if per_rank is not None:
             res["ms_per_step_per_rank"] = per_rank
         if c["model"] == "f":
             res["flow_precision"] = model.flow_precision
     # captured graphs hold their intermediates in private pools (GBs at 2K / 4K): release them before the next workload
-    del model, step, x, coords, ts, gather_buf
+    del model, step, x, xs, pipe, coords, ts, gather_buf
     import gc
 
     gc.collect()
@@ -334,6 +357,9 @@ def main():
                     help="(--model f) precision policy of the flow estimator: 'f16' (model default: the flow estimator on IEEE-half operands, "
                          ">= 40 dB against the reference everywhere), 'bf16', 'dec' (float decoder), 'fp32', or a stage list -- "
                          "GIMMVFI_F.__init__")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("GIMMVFI_BENCH_IN_FLIGHT", "2")),
+                    help="independent steps overlapping on each GPU (gimmvfi_hip.model.StepsInFlight; 1 = one step at a time): every timed "
+                         "step still runs completely inside the timed region")
     ap.add_argument("--configs", default="auto", choices=["auto", "all", "none"],
                     help="the other BASELINE.json configurations, reported under 'configs' of the same JSON line: auto = with the "
                          "default workload only (N = 1: all of them + an fp32-mode line; N > 1: the two 8-GPU configurations)")
@@ -376,14 +402,16 @@ def main():
             "n_interp": args.n_interp, "precision": args.precision}
     default_workload = (args.model, args.batch, args.height, args.width, args.ds, args.n_interp, args.precision) == \
         ("r", 8, 256, 448, 1.0, 2, "bf16")
-    r = measure(head, args.steps, args.warmup, world, rank, dev, shapes=args.shapes, flow_precision=args.flow_precision)
+    r = measure(head, args.steps, args.warmup, world, rank, dev, shapes=args.shapes, flow_precision=args.flow_precision,
+                in_flight=args.in_flight)
     extras = []
     if args.configs == "all" or (args.configs == "auto" and default_workload and not args.shapes):
         for c in EXTRA_CONFIGS:
             if world > 1 and not c["sharded"]:
                 continue
             try:
-                e = measure(c, args.extra_steps, args.extra_warmup, world, rank, dev, ev_over_ms=None if r is None else r["ev_over_ms"])
+                e = measure(c, args.extra_steps, args.extra_warmup, world, rank, dev, ev_over_ms=None if r is None else r["ev_over_ms"],
+                            in_flight=args.in_flight)
             except Exception as ex:  # a failed extra must not cost the headline its line
                 e = {"error": f"{type(ex).__name__}: {ex}"[:300], "workload": workload_name(c)} if rank == 0 else None
                 torch.cuda.empty_cache()
@@ -446,7 +474,7 @@ def main():
             "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": r["workload"],
-                       "pairs_per_step_per_gpu": B, "flow_iters": r["flow_iters"],
+                       "pairs_per_step_per_gpu": B, "flow_iters": r["flow_iters"], "steps_in_flight": r["steps_in_flight"],
                        **({"flow_precision": r["flow_precision"]} if args.model == "f" else {}),
                        "parallelism": f"pair-sharded x{world}",
                        "world_size_rccl": dist.get_world_size() if world > 1 else 1,
@@ -483,7 +511,8 @@ def compact_line(full, details):
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data")}
     w = cfg["workload"].replace(", seeded random-init weights", "").replace(" interpolation", "").replace(" pairs/GPU", "")
-    line["config"] = {"workload": w, "parallelism": cfg["parallelism"], "world_size_rccl": cfg["world_size_rccl"]}
+    line["config"] = {"workload": w, "parallelism": cfg["parallelism"], "world_size_rccl": cfg["world_size_rccl"],
+                      "steps_in_flight": cfg.get("steps_in_flight", 1)}
     if "ms_per_step_per_rank" in cfg:
         line["config"]["ms_per_step_per_rank"] = cfg["ms_per_step_per_rank"]
     line["roofline"] = {"bound": rf["bound"], "kernel": short(rf["kernel"]), "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],

@@ -198,6 +198,18 @@ class GIMMVFI_R(nn.Module):
     def _iters(self):
         return self.raft_iter  # gimmvfi_r.py:127-132 hard-codes 20
 
+    def _ctor_kwargs(self):
+        return {"config": self.config, "precision": self.precision}
+
+    def replica(self):
+        """A second instance of this model on the same device with the same weights and switches and its OWN engine (packed
+        weights, buffers, captured graphs) -- what StepsInFlight keeps per slot."""
+        r = type(self)(**self._ctor_kwargs())
+        r.load_state_dict(self.state_dict(), strict=True)
+        r = r.to(next(self.parameters()).device).eval()
+        r.use_graph, r.static_outputs, r.max_graphs, r.raft_iter = self.use_graph, self.static_outputs, self.max_graphs, self.raft_iter
+        return r
+
     def _forward_graph(self, eng, img_xs, coord, t, iters, ds_factor, seq=False):
         """Capture once per input signature, then replay; inputs are copied into the graph's static buffers and
         the outputs are returned as fresh tensors (clones), like the eager path."""
@@ -305,6 +317,9 @@ class GIMMVFI_F(GIMMVFI_R):
     def _make_engine(self, runtime):
         return self._engine_cls(runtime, self.state_dict(), flow_precision=self.flow_precision)
 
+    def _ctor_kwargs(self):
+        return {"config": self.config, "precision": self.precision, "flow_precision": self.flow_precision}
+
     @property
     def _engine_cls(self):
         from .engine_f import EngineF
@@ -316,6 +331,59 @@ class GIMMVFI_F(GIMMVFI_R):
 
     def forward(self, img_xs, coord=None, t=None, ds_factor=None, _seq=False):
         return super().forward(img_xs, coord=coord, t=t, iters=None, ds_factor=ds_factor, _seq=_seq)
+
+
+class StepsInFlight:
+    """Addition to the reference API for throughput: `depth` independent steps in flight on one GPU.  Slot k is a replica of the
+    model (its own engine, buffers and captured graphs) with its own stream; submit() launches one forward on the next slot's
+    stream and returns at once, so consecutive steps overlap on the device: the latency-bound flow estimator of one batch runs
+    under the MFMA-bound synthesis of the other (profiles/r6_steps_in_flight.txt: +6 % at 448x256, batch 8; every step's output
+    bit-identical to the same step run alone -- the forward is bit-reproducible, tests/test_gpu_e2e.py).  The arithmetic of a step
+    is untouched: the same launch list as model.forward().
+
+        pipe = StepsInFlight(model, depth=2)
+        h = pipe.submit(img_xs, coord, t, ds_factor=None, then=lambda out, m: to_u8(out["imgt_pred"][0]))
+        ...                                   # submit more; the host never blocks
+        frames = pipe.wait(h)                 # the caller's stream waits for that step (device-side wait, no host sync)
+
+    `then(out, replica)` runs on the slot's stream right behind the forward (the place to convert / pack the outputs).  With
+    model.static_outputs the tensors a step returns are the slot's own graph outputs: valid until that slot's next submit, i.e.
+    for `depth` more submits."""
+
+    def __init__(self, model, depth=2):
+        assert depth >= 1
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("StepsInFlight needs the model on an MI355X ('cuda'): there is no CPU path")
+        self.device = dev
+        self.replicas = [model] + [model.replica() for _ in range(depth - 1)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self._n = 0
+
+    @property
+    def depth(self):
+        return len(self.replicas)
+
+    def submit(self, img_xs, coord, t, ds_factor=None, then=None, sequence=False):
+        k = self._n % len(self.replicas)
+        self._n += 1
+        m, s = self.replicas[k], self.streams[k]
+        s.wait_stream(torch.cuda.current_stream(self.device))          # the inputs were produced on the caller's stream
+        with torch.cuda.stream(s):
+            out = m.forward_sequence(img_xs, coord=coord, t=t, ds_factor=ds_factor) if sequence else m(img_xs, coord, t=t, ds_factor=ds_factor)
+            res = then(out, m) if then is not None else out
+            ev = torch.cuda.Event()
+            ev.record(s)
+        return ev, res
+
+    def wait(self, handle):
+        ev, res = handle
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        return res
+
+    def drain(self):
+        for s in self.streams:
+            s.synchronize()
 
 
 class GIMM(nn.Module):

@@ -443,3 +443,40 @@ def test_plain_gather_kernels_are_not_disturbed_by_lds_dma_kernels_on_the_same_c
         torch.cuda.synchronize()
         bad = [sum(int((a != b).sum()) for a, b in zip(o, ref)) for o in outs]
         assert sum(bad) == 0, (name, sum(1 for b_ in bad if b_), sorted(set(bad))[:8])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["r", "f"])
+def test_steps_in_flight_return_each_steps_own_result_bit_for_bit(cfg, sd, sd_f):
+    """gimmvfi_hip.model.StepsInFlight (what bench.py times by default): two replicas, two streams, consecutive steps overlapping on
+    the device.  Twelve steps over four different batches, submitted without a host wait in between, must each return exactly
+    what the model returns for that batch alone -- frames (uint8, converted on the slot's stream) and flows."""
+    from gimmvfi_hip.model import GIMMVFI_F, GIMMVFI_R, StepsInFlight
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    B, H, W = 8, 256, 448
+    m = (GIMMVFI_F if cfg == "f" else GIMMVFI_R)(precision="bf16")
+    m.load_state_dict(sd_f if cfg == "f" else sd, strict=True)
+    m = m.to(DEV).eval()
+    xs = [synthetic_pairs(B, H, W, seed=40 + i).to(DEV) for i in range(4)]
+    coords = [(m.sample_coord_input(B, (H, W), [0.5], device=DEV), None)]
+    ts = [0.5 * torch.ones(B, device=DEV)]
+
+    def pack(out, mm):
+        return mm.engine(DEV).rt.frames_to_u8(out["imgt_pred"][0]).clone(), out["flowt"][0].float().clone()
+
+    alone = []
+    for x in xs:
+        alone.append(pack(m(x, coords, t=ts), m))
+        torch.cuda.synchronize()
+    assert not torch.equal(alone[0][0], alone[1][0])
+    m.static_outputs = True                      # (the slots' own graph outputs: pack() reads them on the slot's stream)
+    pipe = StepsInFlight(m, depth=2)
+    assert pipe.depth == 2 and pipe.replicas[1] is not m and pipe.replicas[1].static_outputs
+    handles = [pipe.submit(xs[i % 4], coords, ts, then=pack) for i in range(12)]
+    for i, h in enumerate(handles):
+        frames, flow = pipe.wait(h)
+        torch.cuda.synchronize()
+        assert torch.equal(frames, alone[i % 4][0]), (i, int((frames != alone[i % 4][0]).sum()))
+        assert torch.equal(flow, alone[i % 4][1]), i
+    pipe.drain()

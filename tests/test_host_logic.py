@@ -353,3 +353,16 @@ def test_cli_main_abort_reaches_every_rank_gloo_world2(tmp_path, fail):
     assert all(c not in (0, None) for c in codes), (codes, res)
     assert all(v != "ok" for v in res.values()), res
     assert any("injected" in v for v in res.values()) and any(("aborted" in v) or ("injected" in v) for v in res.values())
+
+
+def test_steps_in_flight_refuses_a_model_that_is_not_on_the_gpu():
+    """StepsInFlight is a device-side pipeline: like the model itself it has no CPU path and says so."""
+    import pytest
+    from gimmvfi_hip.model import GIMMVFI_R, StepsInFlight
+
+    m = GIMMVFI_R(precision="bf16")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        StepsInFlight(m, depth=2)
+    r = m.replica()
+    assert type(r) is GIMMVFI_R and r is not m and r.precision == m.precision
+    assert all((a == b).all() for a, b in zip(m.state_dict().values(), r.state_dict().values()))
