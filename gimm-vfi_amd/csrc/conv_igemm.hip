@@ -318,10 +318,7 @@ static bool use_p3x3s(const gvfi_conv_params& p) {
 
 extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
     const gvfi_conv_params& p = *pp;
-    if ((p.algo & 15) == 8) {       // row-linear kernel (conv_lin.hip): explicit request only (the caller has checked eligibility)
-        plan[0] = 8; plan[1] = 64; plan[2] = p.Cout; plan[3] = 2 * (p.c0 + p.c1); plan[4] = 1;
-        return gvfi_conv2d_lin_eligible(pp) ? 0 : -2;
-    }
+    if ((p.algo & 15) == 8) return -2;     // (algo 8 was the row-linear experiment, tools/experiments/csrc/conv_lin.hip: not in the library)
     if (use_p3x3s(p)) {
         plan[0] = 5; plan[1] = 256; plan[2] = p.Cout > 32 ? 64 : 32; plan[3] = 2 * p.c0; plan[4] = 2;
         return 0;
@@ -346,7 +343,7 @@ extern "C" int gvfi_conv2d_plan(const gvfi_conv_params* pp, int* plan) {
 
 extern "C" int gvfi_conv2d(const gvfi_conv_params* pp, void* stream) {
     const gvfi_conv_params& p = *pp;
-    if ((p.algo & 15) == 8) return gvfi_conv2d_lin(pp, stream);
+    if ((p.algo & 15) == 8) return -2;
     if (use_p3x3s(p)) return gvfi_conv2d_p3x3s(pp, stream);
     if (use_p3x3(p)) return gvfi_conv2d_p3x3(pp, stream);
     if ((p.algo & 15) == 2 || ((p.algo & 15) == 0 && gvfi_conv2d_glds_eligible(pp))) return gvfi_conv2d_glds(pp, stream);

@@ -434,15 +434,12 @@ class Engine:
                 sc, sn = h32
                 for nn_ in ("1", "2"):  # SepConvGRU horizontal then vertical  raft/update.py:58-73
                     xm = View(xb, 128, 128)   # [motion(126) | flow(2)]
-                    # (GVFI_GRU_FUSED=1: one launch per half where a workgroup can own whole lines of the 1/8 grid,
-                    # csrc/gru_fused.hip -- bit-identical, measured neutral, off by default: Runtime.gru_fused) else the z | r and
-                    # q convolutions with their gate epilogues
-                    if sf or not rt.gru_half(Ls["gru.zr" + nn_], Ls["gru.q" + nn_], hc, xm, hn, ctx_zr=cx["gru.zr" + nn_],
-                                             ctx_q=cx["gru.q" + nn_], vertical=nn_ == "2"):
-                        rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=xm, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
-                                res=cx["gru.zr" + nn_], state_f32=sf)
-                        rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=xm, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
-                                y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
+                    # the z | r and q convolutions with their gate epilogues (one launch per half was built in round 5 and measured
+                    # neutral: tools/experiments/csrc/gru_fused.hip)
+                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=xm, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
+                            res=cx["gru.zr" + nn_], state_f32=sf)
+                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=xm, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
+                            y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
                     hc, hn = hn, hc
                     sc, sn = sn, sc
                 # after two passes the state is back in hA

@@ -95,7 +95,6 @@ class EngineF(Engine):
     # ------------------------------------------------------------------ weight preparation
     def _lin(self, sd, key, name=None, **kw):
         kw = {k: v for k, v in kw.items() if k != "wdir" or v}
-        kw.setdefault("lin", True)      # many-row, small-K linears take the row-linear kernel (csrc/conv_lin.hip) where it applies
         w = sd[key + ".weight"]
         b = sd.get(key + ".bias")
         self._add(name or key, w.reshape(w.shape[0], w.shape[1], 1, 1), b, **kw)
@@ -103,7 +102,6 @@ class EngineF(Engine):
     def _lin_cat(self, sd, keys, name, **kw):
         w = torch.cat([sd[k + ".weight"] for k in keys], 0)
         b = torch.cat([sd[k + ".bias"] for k in keys], 0)
-        kw.setdefault("lin", True)
         self._add(name, w.reshape(w.shape[0], w.shape[1], 1, 1), b, **kw)
 
     def _ln(self, sd, key):
@@ -238,11 +236,8 @@ class EngineF(Engine):
         # operand types): [flow_token_encoder.0 GELU, .2 (= query), norm1 + position code, q] and [proj + query, norm2,
         # ffn.0 GELU, ffn.3 + x]   decoder.py:84-120, 237-255.  GVFI_F_TOKCHAIN=0 keeps the 5 + 4 separate launches.
         self.chain_a = self.chain_c = None
-        # the whole flow-token path of an iteration as ONE launch (csrc/token_path.hip, bit-identical).  Measured in round 4
-        # (profiles/r4_tokpath_ab_v1.txt, _v2.txt): 74 us against 61 us for the four launches it replaces -- 189.7 vs 191.8 frames/s:
-        # one wave owns 32 tokens end to end, i.e. 448 waves for 14 336 rows, and the look-up's 324 scattered loads per token then
-        # run on 112 CUs with nothing to hide them behind, where the separate look-up spreads 1.2 M threads over the chip.  Off.
-        self.fuse_token_path = os.environ.get("GVFI_F_TOKPATH", "0") != "0"
+        # (the whole flow-token path of an iteration as ONE launch was built in round 4 and measured slower -- 74 us against 61 us for
+        # the four launches, profiles/r4_tokpath_ab_v2.txt -- and left the library in round 6: tools/experiments/csrc/token_path.hip)
         if self.rt.precision in ("bf16", "fp16") and os.environ.get("GVFI_F_TOKCHAIN", "1") != "0":
             ca_ = md + ".decoder_layer.cross_attend"
             w2 = lambda k: sd[k + ".weight"].reshape(sd[k + ".weight"].shape[0], -1)
@@ -635,17 +630,8 @@ class EngineF(Engine):
                     co, co_alt = (rt.flow_step(tapl, patl, fp, co, fl, View(Xs, 126, 2), fc, coords_out=co_alt), co) if it > 0 else \
                         (rt.flow_step(tapl, patl, None, co, fl, View(Xs, 126, 2), fc), co_alt)
                 # flow token: 81 taps of the query's own cost map   decoder.py:237-255, 293-301
-                if tok.chain_a is not None and taps is None and tok.fuse_token_path:
-                    # look-up, both token chains and the cross-attention between them as ONE launch (csrc/token_path.hip)
-                    rtt.token_path(tok.chain_a, tok.chain_c, vol_s, co, View(crt_rows, 64, 81), View(kvm_s, 0, 128), K_LAT, P8,
-                                   View(crt_rows, 0, 64), h8, w8)
-                    lookup_done = True
-                else:
-                    rtt.cost_lookup(vol_s, co, View(crt, 64, 81), rows, h8, w8)
-                    lookup_done = False
-                if lookup_done:
-                    pass
-                elif tok.chain_a is not None and taps is None:
+                rtt.cost_lookup(vol_s, co, View(crt, 64, 81), rows, h8, w8)
+                if tok.chain_a is not None and taps is None:
                     query, q, a_ = tok._tok(rows, 64), tok._tok(rows, 64), tok._tok(rows, 64)
                     rtt.token_chain(tok.chain_a, View(crt_rows, 64, 128), q, out1=query, coords=co, period=rows)
                     rtt.attn_global(q, lay_q, View(kvm_s, 0, 64), View(kvm_s, 64, 64), lay_k, a_, lay_q, m, P8, 1, K_LAT, 8, 8)
@@ -688,13 +674,10 @@ class EngineF(Engine):
                 hc, hn = ha, hb
                 sc, sn = h32
                 for nn_ in ("1", "2"):
-                    # (as in Engine._raft: one launch per half where the lines of the 1/8 grid fit a workgroup)
-                    if sf or not rt.gru_half(Ls["gru.zr" + nn_], Ls["gru.q" + nn_], hc, Xs, hn, ctx_zr=cx["gru.zr" + nn_],
-                                             ctx_q=cx["gru.q" + nn_], vertical=nn_ == "2"):
-                        rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=Xs, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
-                                res=cx["gru.zr" + nn_], state_f32=sf)
-                        rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=Xs, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
-                                y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
+                    rt.conv(Ls["gru.zr" + nn_], hc, zb, x1=Xs, epi=A.EPI_GRU_ZR, y2=rh_, aux0=sc if sf else hc,
+                            res=cx["gru.zr" + nn_], state_f32=sf)
+                    rt.conv(Ls["gru.q" + nn_], rh_, hn, x1=Xs, epi=A.EPI_GRU_Q, aux0=sc if sf else hc, aux1=zb,
+                            y2=sn if sf else None, res=cx["gru.q" + nn_], state_f32=sf)
                     hc, hn = hn, hc
                     sc, sn = sn, sc
                 rt.conv(Ls[u + ".flow_head.conv1"], ha, fh_, act1=A.ACT_RELU)

@@ -73,35 +73,6 @@ class TokenChainParams(C.Structure):
     ]
 
 
-class TokenPathParams(C.Structure):
-    """Mirror of ``gvfi_token_path_params`` (include/gimmvfi_hip.h)."""
-
-    _fields_ = [
-        ("a", TokenChainParams), ("c", TokenChainParams),
-        ("maps", C.c_void_p), ("coords", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("radius", C.c_int),
-        ("taps_out", C.c_void_p), ("ldt", C.c_int),
-        ("kv", C.c_void_p), ("ldkv", C.c_int), ("K", C.c_int), ("P", C.c_longlong), ("scale", C.c_float),
-        ("out", C.c_void_p), ("ldo", C.c_int),
-        ("rows", C.c_longlong), ("dtype", C.c_int),
-    ]
-
-
-class GruParams(C.Structure):
-    """Mirror of ``gvfi_gru_params`` (include/gimmvfi_hip.h)."""
-
-    _fields_ = [
-        ("dtype", C.c_int),
-        ("h", C.c_void_p), ("ldh", C.c_int),
-        ("x", C.c_void_p), ("ldx", C.c_int), ("cx", C.c_int),
-        ("wzr", C.c_void_p), ("wq", C.c_void_p),
-        ("bzr", C.c_void_p), ("bq", C.c_void_p),
-        ("ctx_zr", C.c_void_p), ("ld_czr", C.c_int),
-        ("ctx_q", C.c_void_p), ("ld_cq", C.c_int),
-        ("out", C.c_void_p), ("ldo", C.c_int),
-        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("vertical", C.c_int),
-    ]
-
-
 _CTYPES = {
     "int": C.c_int,
     "float": C.c_float,

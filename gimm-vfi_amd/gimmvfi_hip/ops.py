@@ -56,11 +56,9 @@ def V(t, coff=0, c=None):
 class ConvLayer:
     """Packed weights [Cout][KH][KW][cin_pad] (+ float bias / PReLU slope) of one convolution."""
 
-    def __init__(self, rt, w, b, stride=1, pad=None, pad_mode=L.PAD_ZEROS, slope=None, cin_pad=None, wdir=False, lin=False):
+    def __init__(self, rt, w, b, stride=1, pad=None, pad_mode=L.PAD_ZEROS, slope=None, cin_pad=None, wdir=False):
         """wdir: also pack the MFMA-fragment-ordered image (w_layout = 2) of the weights-direct variant of the LDS-DMA
-        kernel -- for the layers of the flow estimators' recurrences (small M, launch time = one workgroup's K chain).
-        lin: pack the same image for the row-linear kernel (csrc/conv_lin.hip: 1x1 layers on >= 65536 rows, small K); the layer
-        takes it where gvfi_conv2d_lin_eligible says 1 and the LDS-DMA tiles elsewhere."""
+        kernel -- for the layers of the flow estimators' recurrences (small M, launch time = one workgroup's K chain)."""
         cout, cin, kh, kw = w.shape
         cp = roundup(cin, rt.VE) if cin_pad is None else cin_pad
         pk = torch.zeros(cout, kh, kw, cp, dtype=torch.float32, device=w.device)
@@ -81,13 +79,7 @@ class ConvLayer:
             self.w_glds = wk.permute(1, 0, 2, 3).contiguous().to(rt.tdtype).to(rt.device)   # [chunk][n][slot][ve]
         self.w_frag = None
         self.use_wdir = bool(wdir) and os.environ.get("GVFI_WDIR", "1") != "0"
-        # (measured in round 4, profiles/r4_lin_kernel_ab.txt: the row-linear kernel is SLOWER than the LDS-DMA tiles on every one of
-        # GIMM-VFI-F's linears -- 80 vs 60 us for 128 -> 128 on 229 k rows, 180 vs 190 frames/s end to end: an MFMA operand is 16 bytes
-        # of ONE row per lane, i.e. 64 cache lines per load instruction straight from global memory, where the LDS-DMA tile copies
-        # whole rows coalesced; with the rows staged through LDS (v2) 69.8 us / 183.8 frames/s: then the 8-byte output pieces of 32
-        # different rows per store instruction bind.  Off unless GVFI_LIN=1.)
-        self.use_lin = bool(lin) and kh == 1 and kw == 1 and stride == 1 and os.environ.get("GVFI_LIN", "0") == "1"
-        if ((self.use_wdir or self.use_lin) and rt.precision in ("bf16", "fp16") and cp % 64 == 0 and pad_mode == L.PAD_ZEROS
+        if (self.use_wdir and rt.precision in ("bf16", "fp16") and cp % 64 == 0 and pad_mode == L.PAD_ZEROS
                 and kh * kw <= 32):
             k = kh * kw * cp
             nb = (cout + 31) // 32
@@ -282,11 +274,6 @@ class Runtime:
         self.once_scope = None
         self.zero_once = os.environ.get("GVFI_ZERO_ONCE", "1") != "0"           # A/B switch: persistent zero-once buffers (act(once=...))
         self.pair_launch = os.environ.get("GVFI_CONV_PAIR", "1") != "0"         # A/B switch: two independent convolutions per launch
-        # SepConvGRU halves as one launch each (csrc/gru_fused.hip).  Built in round 5, bit-identical to the two gate convolutions,
-        # measured NEUTRAL (profiles/r5_gru_fused_ab_v2.txt: R 362.9 -> 363.8 frames/s, F 194.7 -> 193.9; the kernel itself takes
-        # 35-38 us against 31-32 us for the two launches it replaces: a 64-pixel line tile streams all 384 columns of weights
-        # -- 245 MB from L2 per launch, bound by bytes in flight / latency with one workgroup per CU), so it stays OFF
-        self.gru_fused = os.environ.get("GVFI_GRU_FUSED", "0") == "1"
         self._once = {}
         # PROFILING ONLY (results are garbage): the kernel's phase-skip switches on every weights-direct launch of the recurrences --
         # 8 = no epilogue, 16 = no K loop, 24 = neither: how much of the recurrence's wall time is the fixed per-launch cost
@@ -494,12 +481,6 @@ class Runtime:
             p.algo = 4 | (algo & ~15)       # halo-staged 3x3 kernel (conv_p3x3.hip) ahead of the LDS-DMA kernel
             if not (p.algo >> 13) & 3:
                 p.algo |= self.p3x3_form << 13
-        if layer is not None and want in (0, 8) and layer.w_frag is not None and layer.use_lin and groups == 1:
-            keep = (p.w, p.w_layout, p.algo)
-            p.w, p.w_layout, p.algo = layer.w_frag.data_ptr(), 2, 8 | (algo & ~15)
-            el = self.lib.conv2d_lin_eligible(C.byref(p))
-            if not (el == 1 or (want == 8 and el == 2)):
-                p.w, p.w_layout, p.algo = keep          # not a row-linear problem (few rows, other epilogue): the tile kernels
         if layer is not None and want == 0 and small3:
             keep = (p.w, p.w_layout)
             p.w, p.w_layout = layer.w.data_ptr(), 0
@@ -546,7 +527,7 @@ class Runtime:
             cin_real = (layer.cin if layer is not None else x0.c)
             flops = 2.0 * n * p.Ho * p.Wo * p.Cout * kh * kw * cin_real
             kname = {1: "conv_igemm_kernel", 2: "conv_igemm_glds_kernel", 3: "conv_patch_kernel", 4: "conv_p3x3_kernel", 5: "conv_p3x3s_kernel",
-                     6: "conv_igemm_glds_kernel[wdir]", 7: "conv_col7_kernel", 8: "conv_lin_kernel"}[plan[0]]
+                     6: "conv_igemm_glds_kernel[wdir]", 7: "conv_col7_kernel"}[plan[0]]
             if plan[0] == 4 and self.lib.conv2d_p3x3_form(C.byref(p)) == 3:
                 kname = "conv_p3x3_stream_kernel"      # (the persistent form: its own kernel in a rocprofv3 trace)
             tag = f"{kname}<{ {L.F32: 'float', L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },{plan[1]},{plan[2]},kb{plan[3]},s{plan[4]}>"
@@ -586,46 +567,6 @@ class Runtime:
                 tag += f" {pa.N}x{pa.H}x{pa.W} {la.cin}->{pa.Cout} {pa.KH}x{pa.KW} || {lb.cin}->{pb.Cout} {pb.KH}x{pb.KW}"
             self.ev_log.append((tag, fa + fb, e0, e1))
 
-    def gru_half(self, lay_zr, lay_q, h, x, out, ctx_zr=None, ctx_q=None, vertical=False):
-        """One half of the SepConvGRU as ONE launch (gvfi_gru_half, csrc/gru_fused.hip) where the library takes the geometry;
-        returns False when it does not (the caller then runs the two gate convolutions).  h / out: Views of 128 channels, x: View
-        of 128 or 256 channels; lay_zr / lay_q: the wdir-packed ConvLayers of the z | r and q convolutions over [h | x]."""
-        if not self.gru_fused or lay_zr.w_frag is None or lay_q.w_frag is None or self.dtype == L.F32:
-            return False
-        h, x, out = V(h), V(x), V(out)
-        n, hh, ww = h.t.shape[:3]
-        p = L.GruParams()
-        p.dtype = self.dtype
-        p.h, p.ldh = h.ptr, h.ld
-        p.x, p.ldx, p.cx = x.ptr, x.ld, x.c
-        p.wzr, p.wq = lay_zr.w_frag.data_ptr(), lay_q.w_frag.data_ptr()
-        p.bzr = None if lay_zr.b is None else lay_zr.b.data_ptr()
-        p.bq = None if lay_q.b is None else lay_q.b.data_ptr()
-        if ctx_zr is not None:
-            assert ctx_zr.dtype == torch.float32 and ctx_q.dtype == torch.float32
-            p.ctx_zr, p.ld_czr = ctx_zr.data_ptr(), ctx_zr.shape[-1]
-            p.ctx_q, p.ld_cq = ctx_q.data_ptr(), ctx_q.shape[-1]
-        else:
-            p.ctx_zr, p.ld_czr, p.ctx_q, p.ld_cq = None, 0, None, 0
-        p.out, p.ldo = out.ptr, out.ld
-        p.N, p.H, p.W, p.vertical = n, hh, ww, 1 if vertical else 0
-        if h.c != 128 or out.c != 128 or (lay_zr.kh, lay_zr.kw) != ((5, 1) if vertical else (1, 5)) or lay_zr.cin_pad != 128 + x.c \
-                or lay_zr.cout != 256 or lay_q.cout != 128 or self.lib.gru_half_ok(C.byref(p)) != 1:
-            return False
-        if self.ev_log is not None:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        self._chk(self.lib.gru_half(C.byref(p), self.stream()), "gru_half")
-        if self.ev_log is not None:
-            e1.record()
-            tag = f"gru_half_kernel<{ {L.BF16: 'bf16', L.F16: 'f16'}[self.dtype] },64,128,kb128,s4>"
-            if self.ev_shapes:
-                tag += f" {n}x{hh}x{ww} {128 + x.c}->384 {'5x1' if vertical else '1x5'}"
-            self.ev_log.append((tag, 2.0 * n * hh * ww * 384 * 5 * (128 + x.c), e0, e1))
-        return True
-
-    # ------------------------------------------------------------------ thin wrappers
     def resize_planes(self, src, scale):
         *lead, h, w = src.shape
         ho, wo = int(math.floor(h * scale)), int(math.floor(w * scale))
@@ -722,26 +663,6 @@ class Runtime:
         p.out2, p.ldo2 = out2.ptr, out2.ld
         p.rows, p.dtype = rows, self.dtype
         self._chk(self.lib.token_chain(C.byref(p), self.stream()), "token_chain")
-
-    def token_path(self, ch_a, ch_c, maps, coords, taps_out, kv, n_latent, tokens_per_image, out, h, w, radius=4):
-        """The flow-token path of one decoder iteration in one launch (gvfi_token_path): cost look-up -> chain `ch_a` -> one-query
-        attention over the map's latent tokens -> chain `ch_c`.  taps_out / out: Views of [rows, ld] token matrices; kv: View of
-        the [images * K * P, >= 128] key | value matrix; coords float [rows, 2]."""
-        p = L.TokenPathParams()
-        taps_out, out, kv = V(taps_out), V(out), V(kv)
-        rows = out.npix
-        for dst, ch in ((p.a, ch_a), (p.c, ch_c)):
-            dst.wfrag, dst.bias = ch.wfrag.data_ptr(), ch.bias.data_ptr()
-            dst.ln_g, dst.ln_b, dst.eps, dst.ln_after = ch.ln_g.data_ptr(), ch.ln_b.data_ptr(), ch.eps, ch.ln_after
-            dst.act0, dst.act1, dst.res2_from0 = ch.act0, ch.act1, int(ch.res2_from0)
-        assert coords.dtype == torch.float32 and coords.is_contiguous() and maps.dtype == torch.float32 and maps.is_contiguous()
-        assert taps_out.npix == rows and out.c == 64 and taps_out.c >= (2 * radius + 1) ** 2 and kv.c >= 128
-        p.maps, p.coords, p.h, p.w, p.radius = maps.data_ptr(), coords.data_ptr(), h, w, radius
-        p.taps_out, p.ldt = taps_out.ptr, taps_out.ld
-        p.kv, p.ldkv, p.K, p.P, p.scale = kv.ptr, kv.ld, n_latent, tokens_per_image, float(8 ** -0.5)
-        p.out, p.ldo = out.ptr, out.ld
-        p.rows, p.dtype = rows, self.dtype
-        self._chk(self.lib.token_path(C.byref(p), self.stream()), "token_path")
 
     def s2d_conv(self, layer, x, out, **kw):
         """x: contiguous [N, H, W, ld] activation tensor (H, W multiples of layer.k), out: [N, H/k, W/k, cout]."""

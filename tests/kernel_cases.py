@@ -47,18 +47,9 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
     slope = torch.rand(Cout, generator=g) * 0.3 + 0.1
     x, w = _rounded(rt, x), _rounded(rt, w)
     dev = _dev(rt)
-    keep_lin = os.environ.get("GVFI_LIN")
-    if (algo & 15) == 8:
-        os.environ["GVFI_LIN"] = "1"       # (the row-linear kernel is off by default: measured slower, profiles/r4_lin_kernel_ab.txt)
-    try:
-        lay = ConvLayer(rt, w, b, stride=stride, pad=None if pad is None else (pad, pad),
-                        pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope, wdir=(algo & 15) == 6, lin=(algo & 15) == 8)
-    finally:       # the switch is read when the layer is packed; leave the process environment as it was
-        if keep_lin is None:
-            os.environ.pop("GVFI_LIN", None)
-        else:
-            os.environ["GVFI_LIN"] = keep_lin
-    if (algo & 15) in (6, 8):
+    lay = ConvLayer(rt, w, b, stride=stride, pad=None if pad is None else (pad, pad),
+                    pad_mode=L.PAD_REFLECT if reflect else L.PAD_ZEROS, slope=slope, wdir=(algo & 15) == 6)
+    if (algo & 15) == 6:
         assert lay.w_frag is not None, "fragment-ordered weight image not packed"
     if split is None:
         xa = _to_act(rt, x).to(dev)
@@ -104,8 +95,6 @@ def conv_case(rt, N, H, W, Cin, Cout, KH, KW, stride=1, reflect=False, act1=L.AC
         out.fill_(3.0)
         rt.conv(lay, x0, View(out, coff, Cout), x1=x1, act1=act1, res=None if res is None else View(res, 0, Cout), act2=act2,
                 slope2=lay.slope if act2 == L.ACT_PRELU else None, out_scale=out_scale, tile=tile, algo=algo)
-        if (algo & 15) == 8:
-            assert rt.last_algo == 8, "the row-linear kernel declined this problem"
         got = out.float().cpu()
         assert float((got[..., :coff] - 3.0).abs().max()) == 0.0 if coff else True
         assert float((got[..., coff + Cout:] - 3.0).abs().max()) == 0.0        # nothing beyond the slice is written
@@ -281,59 +270,6 @@ def gru_case(rt, N=1, H=6, W=9, C=16, seed=0, kh=1, kw=5, ctx_split=False, state
         ez = float((zb.cpu().permute(0, 3, 1, 2) - z).abs().max())
         assert ez <= 1e-4, ez
     return err
-
-
-def gru_fused_case(rt, N=2, H=6, W=20, CX=128, vertical=False, seed=0, with_ctx=True, with_bias=False):
-    """gvfi_gru_half (one SepConvGRU half as ONE launch, csrc/gru_fused.hip) against the two weights-direct launches it replaces
-    (GRU_ZR / GRU_Q epilogues of gvfi_conv2d): bit-identical h', and against torch.  h: 128 channels; x: CX (128: RAFT's
-    [motion | flow], 256: FlowFormer's [motion | flow | aggregated motion]) channels inside a wider buffer; ctx: the float
-    pre-activation terms of the context share; vertical: the 5 x 1 half (two image columns per workgroup)."""
-    g = torch.Generator().manual_seed(seed)
-    dev = _dev(rt)
-    C = 128
-    kh, kw = (5, 1) if vertical else (1, 5)
-    h = _rounded(rt, torch.tanh(torch.randn(N, C, H, W, generator=g)))
-    x = _rounded(rt, torch.randn(N, CX, H, W, generator=g))
-    wz, wr, wq = (_rounded(rt, torch.randn(C, C + CX, kh, kw, generator=g) / ((C + CX) * 5) ** 0.5) for _ in range(3))
-    bzr = torch.randn(2 * C, generator=g) * 0.3 if with_bias else None
-    bq = torch.randn(C, generator=g) * 0.3 if with_bias else None
-    lzr = ConvLayer(rt, torch.cat([wz, wr], 0), bzr, wdir=True)
-    lq = ConvLayer(rt, wq, bq, wdir=True)
-    czr = (torch.randn(N, H, W, 2 * C, generator=g) * 0.5).to(dev) if with_ctx else None
-    cq = (torch.randn(N, H, W, C, generator=g) * 0.5).to(dev) if with_ctx else None
-    ha = _to_act(rt, h).to(dev)
-    xw = rt.act(N, H, W, C + CX)                     # x lives at a channel offset of a wider tensor (as in the engine)
-    xw[..., :C] = 5.0
-    xw[..., C:] = x.permute(0, 2, 3, 1).to(xw.dtype).to(dev)
-    xv = View(xw, C, CX)
-    # (a) the two launches
-    zb, rh, hn2 = rt.act(N, H, W, C), rt.act(N, H, W, C), rt.act(N, H, W, C)
-    rt.conv(lzr, ha, zb, x1=xv, epi=L.EPI_GRU_ZR, y2=rh, aux0=ha, res=czr)
-    rt.conv(lq, rh, hn2, x1=xv, epi=L.EPI_GRU_Q, aux0=ha, aux1=zb, res=cq)
-    assert rt.last_algo == 2      # (the weights-direct variant of the LDS-DMA kernel took them)
-    # (b) one launch
-    hn1 = torch.full((N, H, W, C + 8), 3.0, dtype=rt.tdtype, device=dev)
-    keep = rt.gru_fused
-    rt.gru_fused = True
-    n0 = rt.n_launch
-    took = rt.gru_half(lzr, lq, ha, xv, View(hn1, 0, C), ctx_zr=czr, ctx_q=cq, vertical=vertical)
-    rt.gru_fused = keep
-    assert took and rt.n_launch - n0 == 1
-    got = hn1.float().cpu()
-    assert float((got[..., C:] - 3.0).abs().max()) == 0.0                     # nothing beyond the 128 channels is written
-    assert torch.equal(got[..., :C], hn2.float().cpu()), float((got[..., :C] - hn2.float().cpu()).abs().max())
-    # (c) torch
-    pad = (kh // 2, kw // 2)
-    hx = torch.cat([h, x], 1)
-    cz = czr.cpu().permute(0, 3, 1, 2) if with_ctx else torch.zeros(N, 2 * C, H, W)
-    cqq = cq.cpu().permute(0, 3, 1, 2) if with_ctx else torch.zeros(N, C, H, W)
-    z = torch.sigmoid(F.conv2d(hx, wz, None if bzr is None else bzr[:C], padding=pad) + cz[:, :C])
-    r = torch.sigmoid(F.conv2d(hx, wr, None if bzr is None else bzr[C:], padding=pad) + cz[:, C:])
-    q = torch.tanh(F.conv2d(torch.cat([_rounded(rt, r * h), x], 1), wq, bq, padding=pad) + cqq)
-    zz = _rounded(rt, z)
-    ref = (1 - zz) * h + zz * q
-    err = float((got[..., :C].permute(0, 3, 1, 2) - ref).abs().max())
-    assert err <= tol(rt, 2.0), err
 
 
 def corr_volume_case(rt, B=2, h=5, w=7, C=32, seed=0):

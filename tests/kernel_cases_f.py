@@ -259,46 +259,3 @@ def token_chain_case(rt, rows=75):
     go = out.float().cpu()
     assert float((go[:, 64:] - 5.0).abs().max()) == 0.0
     assert float((go[:, :64] - ref).abs().max()) <= 2 * tol(rt, float(ref.abs().max())), float((go[:, :64] - ref).abs().max())
-
-
-def token_path_case(rt, images=3, h=5, w=7, K=8):
-    """gvfi_token_path (csrc/token_path.hip) against the four launches it replaces -- gvfi_cost_lookup, gvfi_token_chain (A),
-    gvfi_attn_global, gvfi_token_chain (C) -- bit for bit: cost_forward taps and cost_global features.  Ragged last wave,
-    coordinates on and beyond the map's border, outputs that are channel slices of the wide cost tensor."""
-    if rt.precision == "fp32":
-        return
-    g = _g(11)
-    dev = rt.device
-    rd = lambda t: _r(rt, t)
-    P = h * w
-    rows = images * P
-    W0, W1, W2 = rd(torch.randn(64, 81, generator=g) / 9), rd(torch.randn(64, 64, generator=g) / 8), rd(torch.randn(64, 64, generator=g) / 8)
-    Wp, W3, W4 = rd(torch.randn(64, 128, generator=g) / 11), rd(torch.randn(64, 64, generator=g) / 8), rd(torch.randn(64, 64, generator=g) / 8)
-    b = [torch.randn(64, generator=g) * 0.1 for _ in range(6)]
-    g1, b1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
-    g2, b2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
-    cha = TokenChain(rt, [W0, W1, W2], b[:3], (g1, b1), 1e-5, 1, act0=L.ACT_GELU)
-    chc = TokenChain(rt, [Wp, W3, W4], b[3:], (g2, b2), 1e-5, 0, act1=L.ACT_GELU, res2_from0=True)
-    maps = torch.randn(rows, P, generator=g).contiguous().to(dev)
-    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
-    coords = torch.stack([xs, ys], -1).reshape(1, P, 2).repeat(images, 1, 1) + torch.randn(images, P, 2, generator=g) * 3.0
-    coords[0, 0] = torch.tensor([-7.5, 2.0])            # far outside: every tap absent
-    coords[1, 3] = torch.tensor([float(w - 1), float(h - 1)])   # exactly on the last cell
-    coords = coords.reshape(rows, 2).contiguous().to(dev)
-    kv = rd(torch.randn(images * K * P, 128, generator=g)).to(rt.tdtype).to(dev)
-    # ---- the separate launches
-    crt = torch.zeros(rows, 192, dtype=rt.tdtype, device=dev)
-    rt.cost_lookup(maps, coords, View(crt, 64, 81), rows, h, w)
-    query, q, a_ = (torch.zeros(rows, 64, dtype=rt.tdtype, device=dev) for _ in range(3))
-    rt.token_chain(cha, View(crt, 64, 128), q, out1=query, coords=coords, period=rows)
-    rt.attn_global(q, (P, 1, 0), View(kv, 0, 64), View(kv, 64, 64), (K * P, 1, P), a_, (P, 1, 0), images, P, 1, K, 8, 8)
-    rt.token_chain(chc, a_, View(crt, 0, 64), in1=query, res0=query)
-    # ---- one launch
-    crt2 = torch.zeros(rows, 192, dtype=rt.tdtype, device=dev)
-    crt2[:, 145:] = 9.0                                  # (the fused kernel does not depend on the tensor's zero padding)
-    rt.token_path(cha, chc, maps, coords, View(crt2, 64, 81), View(kv, 0, 128), K, P, View(crt2, 0, 64), h, w)
-    a, c = crt.float().cpu(), crt2.float().cpu()
-    assert torch.isfinite(a[:, :145]).all() and float(a[:, :64].abs().max()) > 0.1
-    assert torch.equal(a[:, 64:145], c[:, 64:145]), float((a[:, 64:145] - c[:, 64:145]).abs().max())
-    assert torch.equal(a[:, :64], c[:, :64]), float((a[:, :64] - c[:, :64]).abs().max())
-    assert float((c[:, 145:] - 9.0).abs().max()) == 0.0

@@ -97,31 +97,6 @@ def test_engine_f_sim_token_chains_equal_the_separate_launches(sd_f, monkeypatch
     assert psnr(outs["1"]["imgt_pred"][0], outs["0"]["imgt_pred"][0]) > 55.0
 
 
-def test_engine_f_sim_token_path_equals_the_four_launches(sd_f, monkeypatch):
-    """One launch per decoder iteration for the whole flow-token path (gvfi_token_path, GVFI_F_TOKPATH=1 -- OFF by default: measured
-    slower, profiles/r4_tokpath_ab_v2.txt) against the four launches it replaces (the default, GVFI_F_TOKPATH=0: look-up | chain |
-    attention | chain), same emulated engine, three iterations: bit-identical
-    flows and frames."""
-    import torch
-
-    from gimmvfi_hip.engine_f import EngineF
-    from sim_runtime import SimRuntime
-
-    meta, _ = load_golden("f_128x192_t050")
-    x, coords, ts = golden_inputs(meta)
-    outs = {}
-    for sw in ("1", "0"):
-        monkeypatch.setenv("GVFI_F_TOKPATH", sw)
-        eng = EngineF(SimRuntime("bf16"), sd_f)
-        assert eng.fuse_token_path == (sw == "1") and eng.chain_a is not None
-        n0 = eng.rt.n_launch
-        outs[sw] = eng.forward(x, coords, ts, iters=3)
-        outs[sw + "n"] = eng.rt.n_launch - n0
-    assert torch.equal(outs["1"]["raft_flow"], outs["0"]["raft_flow"])
-    assert torch.equal(outs["1"]["imgt_pred"][0], outs["0"]["imgt_pred"][0])
-    assert outs["0n"] - outs["1n"] == 3 * 3 * 2      # three launches fewer per iteration and launch sequence (two sub-batches)
-
-
 def test_engine_f_sim_flow_precision_policy(sd_f):
     """bf16 engine with the flow estimator's stages in float (GIMMVFI_F(flow_precision=...)): with all three stages in
     float the flows are those of the fp32 engine, the frames those of bf16 synthesis; a single float stage still runs the

@@ -59,17 +59,6 @@ CONV_SHAPES = [
     (8, 32, 56, 256, 18, 1, 1, dict(out_f32=True, coff=0, bf16_only=True)),
     (1, 1, 14336, 192, 128, 1, 1, dict(algo=6, split=64, act1=L.ACT_GELU, with_res=True, coff=0, bf16_only=True)),
     (1, 40, 56, 96, 96, 3, 3, dict(act1=L.ACT_RELU)),                                         # 64-byte chunks, 4-deep ring (counted vmcnt)
-    # row-linear kernel (conv_lin.hip, algo 8): weights resident in registers, rows streamed; every (K, N) instantiation, ragged
-    # last tile, GELU / ReLU, float residual + float output (the transformer residual streams), 16-bit residual, two sources
-    (1, 1, 75, 128, 128, 1, 1, dict(algo=8, coff=8, bf16_only=True)),
-    (1, 1, 70, 128, 256, 1, 1, dict(algo=8, coff=0, act1=L.ACT_GELU, bf16_only=True)),
-    (1, 1, 40, 128, 384, 1, 1, dict(algo=8, coff=8, with_res=True, res_f32=True, out_f32=True, bf16_only=True)),
-    (1, 1, 37, 128, 512, 1, 1, dict(algo=8, coff=0, act1=L.ACT_GELU, bf16_only=True)),
-    (1, 1, 33, 192, 128, 1, 1, dict(algo=8, coff=8, split=64, bf16_only=True)),
-    (1, 1, 65, 192, 256, 1, 1, dict(algo=8, coff=0, with_res=True, bf16_only=True)),
-    (1, 1, 64, 256, 128, 1, 1, dict(algo=8, coff=8, act1=L.ACT_RELU, bf16_only=True)),
-    (1, 1, 31, 256, 192, 1, 1, dict(algo=8, coff=0, out_f32=True, bf16_only=True)),
-    (2, 3, 17, 512, 128, 1, 1, dict(algo=8, coff=8, with_res=True, res_f32=True, out_f32=True, bf16_only=True)),
     # halo-staged 3x3 kernel (conv_p3x3.hip)
     (1, 17, 19, 64, 256, 3, 3, dict(algo=4, act1=L.ACT_PRELU, pad16=True, bf16_only=True)),
     (1, 17, 19, 128, 256, 3, 3, dict(algo=4, split=64, act1=L.ACT_PRELU, with_res=True, act2=L.ACT_PRELU, pad16=True, bf16_only=True)),
@@ -189,23 +178,6 @@ def test_gru_epilogues(rt):
         kc.gru_case(rt, N=2, H=32, W=56, C=128, kh=5, kw=1, seed=6, state_f32=True, ctx_split=True, wdir=True)
         kc.gru_case(rt, N=1, H=5, W=7, C=64, kh=1, kw=5, seed=7, state_f32=True, wdir=True)
         kc.gru_case(rt, kh=1, kw=5, seed=8, state_f32=True)
-
-
-def test_gru_half_as_one_launch_equals_the_two_gate_convolutions():
-    """csrc/gru_fused.hip on the GPU: the recurrence's real shapes (8 images of 32 x 56, RAFT and FlowFormer widths, bf16 and
-    half) and the ragged / idle-row cases of the emulator test."""
-    from gimmvfi_hip.ops import Runtime
-
-    for prec in ("bf16", "fp16"):
-        rtx = Runtime(L.get(), prec, "cuda:0")
-        kc.gru_fused_case(rtx, N=8, H=32, W=56, vertical=False)
-        kc.gru_fused_case(rtx, N=8, H=32, W=56, vertical=True, seed=1)
-        kc.gru_fused_case(rtx, N=8, H=32, W=56, CX=256, vertical=False, seed=2)
-        kc.gru_fused_case(rtx, N=8, H=32, W=56, CX=256, vertical=True, seed=3)
-        kc.gru_fused_case(rtx, N=1, H=7, W=3, vertical=True, seed=4)
-        kc.gru_fused_case(rtx, N=2, H=2, W=64, vertical=False, seed=5, with_bias=True)
-        kc.gru_fused_case(rtx, N=1, H=32, W=2, vertical=True, seed=6, with_ctx=False)
-    torch.cuda.synchronize()
 
 
 def test_conv_pair_launch_equals_two_launches(rt):

@@ -47,8 +47,6 @@ def _all(rt):
     kf.tile_softmax_case(rt)
     kf.token_chain_case(rt)
     kf.token_chain_case(rt, rows=32)
-    kf.token_path_case(rt)
-    kf.token_path_case(rt, images=2, h=8, w=8)
 
 
 def test_flowformer_kernels_emulated(rt_sim, monkeypatch):

@@ -17,6 +17,7 @@
 // Same arithmetic as the LDS-DMA kernel up to the order in which an MFMA adds its 16 products (results agree to fp32
 // rounding of the accumulation, as between any two tile shapes of that kernel).
 #include "conv_mma.h"
+#include "gimmvfi_experiments.h"
 
 struct LinArgs {
     gvfi_conv_params p;

@@ -17,6 +17,7 @@
 // gate arithmetic (conv_mma.h: fast_sigmoid / fast_tanh, (acc + context term) + bias) are those of the two launches: the
 // result is bit-identical to them (tests/kernel_cases.py:gru_fused_case, emulator + GPU).
 #include "conv_mma.h"
+#include "gimmvfi_experiments.h"
 #include <type_traits>
 
 struct GruArgs {

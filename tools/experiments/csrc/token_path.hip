@@ -10,6 +10,7 @@
 // LDS / registers.  Rounding to the activation type happens exactly where the separate launches store a tensor, and every
 // float expression is theirs (cost_lookup_kernel, token_chain_kernel, AttnAcc of flowformer_ops.hip): bit-identical results.
 #include "conv_mma.h"
+#include "gimmvfi_experiments.h"
 
 #ifndef GVFI_HOSTSIM
 #define TP_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
