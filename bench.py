@@ -130,6 +130,44 @@ def event_overhead_ms(dev):
     return max(sum(c0.elapsed_time(c1) for c0, c1 in pairs) / 200 - ca.elapsed_time(cb) / 200, 0.0)
 
 
+def recurrence_probe(dev, B=8, H=256, W=448, reps=8):
+    """The launch-bound part of the step IN THIS RUN: wall time of one RAFT iteration, both recurrence lanes
+    overlapped as in the step -- the same captured forward replayed with 20 and with 4 iterations (GIMMVFI_R.raft_iter), the
+    difference over 16.  This, not the hot kernel, is where the pool's boxes differ: ~20 us kernels in dependent chains of 13
+    launches follow the fabric / L2 clocks and the command processor, the hot kernel follows the power limit."""
+    from gimmvfi_hip.model import GIMMVFI_R
+    from gimmvfi_hip.params import random_state_dict
+    from gimmvfi_hip.synth import synthetic_pairs
+
+    sd = random_state_dict(0)
+    x = synthetic_pairs(B, H, W, seed=100).to(dev)
+    ms = {}
+    for iters in (20, 4):
+        m = GIMMVFI_R(precision="bf16")
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).eval()
+        m.static_outputs = True
+        m.raft_iter = iters
+        coords = [(m.sample_coord_input(B, (H, W), [0.5], device=dev), None)]
+        ts = [0.5 * torch.ones(B, device=dev)]
+        for _ in range(2):
+            m(x, coords, t=ts)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            m(x, coords, t=ts)
+        e1.record()
+        torch.cuda.synchronize()
+        ms[iters] = e0.elapsed_time(e1) / reps
+        del m
+    per_it = (ms[20] - ms[4]) / 16.0
+    return {"us_per_iteration": round(per_it * 1e3, 1), "recurrence_ms_per_step": round(per_it * 20, 3),
+            "step_ms_20_iters": round(ms[20], 3), "step_ms_4_iters": round(ms[4], 3),
+            "note": "one step at a time; (graph replay with raft_iter 20 - with 4) / 16: wall time of one RAFT iteration with both lanes "
+                    "overlapped (13 launches per lane); x 20 = the recurrence's share of the step"}
+
+
 def hot_kernel_clock(dev):
     """Effective shader clock of the dominant kernel IN THIS RUN: one profiled launch of the hot layer (8 x 256 x 448, 256 -> 256,
     3x3: conv_p3x3.hip's PROF instantiation, wave 0 of every workgroup adds up s_memtime cycles per phase) between two HIP
@@ -451,6 +489,16 @@ def main():
                 roofline["clock"] = hot_kernel_clock(dev)
             except Exception as ex:       # the probe must never cost the run its line
                 roofline["clock"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        roofline["recurrence"] = None
+        if default_workload and args.precision == "bf16":
+            try:
+                roofline["recurrence"] = recurrence_probe(dev)
+            except Exception as ex:       # the probe must never cost the run its line
+                roofline["recurrence"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
         roofline["traffic_note"] = (f"HBM bytes/launch of the 256->256 layer from profiles/{pmc_name} (separate rocprofv3 PMC passes, "
                                     "FETCH_SIZE x2 + WRITE_SIZE); algorithmic 0.94 GB" if traffic is not None
                                     else "no PMC pass for this workload")
@@ -525,6 +573,8 @@ def compact_line(full, details):
     if isinstance(rf.get("clock"), dict) and "mhz" in rf["clock"]:
         line["roofline"]["clock_mhz"] = rf["clock"]["mhz"]
         line["roofline"]["cycles_per_tile"] = rf["clock"]["cycles_per_tile"]
+    if isinstance(rf.get("recurrence"), dict) and "us_per_iteration" in rf["recurrence"]:
+        line["roofline"]["raft_iteration_us"] = rf["recurrence"]["us_per_iteration"]      # (the launch-bound part, measured in this run)
     if "path" in rf:
         line["roofline"]["path_frac"] = rf["path"]["frac"]
     cb = full.get("cpu_baseline")

@@ -4,7 +4,8 @@
 # Outputs go to gpurun_out/<out-tag>/; copy what is to be judged into profiles/ (rNN_ prefix).  Steps:
 #   tests            the whole GPU suite (-m gpu) + parity lines          tests-fast   the suite without the live-CPU-oracle cases
 #   smoke            __graft_entry__.smoke()
-#   bench            the default bench line (headline + every BASELINE configuration)
+#   bench            the default bench line (headline + every BASELINE configuration; two steps in flight, bench.py's default)
+#                    (the shapes- / prof- / timeline- / hbm- steps run ONE step at a time: per-kernel figures, not throughput)
 #   shapes-<cfg>     per-conv-shape table of one configuration (cfg: r448 r2k r4k f448 f4k)
 #   prof-<cfg>       rocprofv3 --kernel-trace summary (tools/rocpd_stats.py) of one configuration
 #   timeline-<cfg>   wall-clock structure of one step (first start / last end per kernel, GPU-busy union; tools/phase_timeline.py)
@@ -36,10 +37,10 @@ for step in "$@"; do
       grep -E "^(448x256|R |F |demo|2k_|4k_|demo2k|SNU|XTEST|CLI|FAMILY)|passed|failed|rc " $O/gpu_tests.log | cut -c1-230 > $O/gpu_parity.log; tail -3 $O/gpu_parity.log;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log;;
     bench) ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --details $O/bench_full.json ) > $O/bench_line.json 2> $O/bench_all.err; echo "rc $?" >> $O/bench_all.err; tail -c 1700 $O/bench_line.json;;
-    shapes-*) c=${step#shapes-}; timeout 400 python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) --shapes $O/conv_shapes_$c.md > $O/bench_$c.json 2> $O/bench_$c.err; head -12 $O/conv_shapes_$c.md | cut -c1-160;;
-    prof-*) c=${step#prof-}; timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$c -o run -- python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/prof_$c.log 2>&1
+    shapes-*) c=${step#shapes-}; timeout 400 python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) --shapes $O/conv_shapes_$c.md > $O/bench_$c.json 2> $O/bench_$c.err; head -12 $O/conv_shapes_$c.md | cut -c1-160;;
+    prof-*) c=${step#prof-}; timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$c -o run -- python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/prof_$c.log 2>&1
       python tools/rocpd_stats.py $O/prof_$c $O/kernel_stats_$c.md > /dev/null; rm -rf $O/prof_$c; head -14 $O/kernel_stats_$c.md | cut -c1-160;;
-    timeline-*) c=${step#timeline-}; timeout 400 rocprofv3 --kernel-trace -d $O/tl_$c -o run -- python bench.py --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/tl_$c.log 2>&1
+    timeline-*) c=${step#timeline-}; timeout 400 rocprofv3 --kernel-trace -d $O/tl_$c -o run -- python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 5 --warmup 2 $(cfg_args $c) > $O/tl_$c.log 2>&1
       python tools/phase_timeline.py $O/tl_$c prep_images $O/phase_timeline_$c.md > /dev/null; rm -rf $O/tl_$c; head -3 $O/phase_timeline_$c.md | cut -c1-220;;
     pmc-p3x3)
       p() { n=$1; shift; rm -rf $O/pmc_$n; ONLYP3=1 timeout 150 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$n -o run -- python tools/conv_bench.py bf16 "final.resblock 256->256 3x3 @256" > $O/pmc_$n.log 2>&1; }
@@ -52,7 +53,7 @@ for step in "$@"; do
       p tcc TCC_HIT_sum TCC_MISS_sum; p tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum; p fetch FETCH_SIZE; p write WRITE_SIZE
       python tools/pmc_report.py ConvArgs2 $O/pw_sq $O/pw_sq2 $O/pw_tcc $O/pw_tcp $O/pw_fetch $O/pw_write > $O/pmc_wdir.txt 2>&1; cut -c85-200 $O/pmc_wdir.txt; rm -rf $O/pw_*/;;
     hbm-*) c=${step#hbm-}       # needs kernel_stats_<cfg>.md of a prof-<cfg> step of the same tag (un-profiled durations)
-      for ctr in FETCH_SIZE WRITE_SIZE; do rm -rf $O/hbm_$ctr; timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/hbm_$ctr -o run -- python bench.py --configs none --no-cpu-baseline --steps 3 --warmup 1 $(cfg_args $c) > $O/hbm_$ctr.log 2>&1; done
+      for ctr in FETCH_SIZE WRITE_SIZE; do rm -rf $O/hbm_$ctr; timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/hbm_$ctr -o run -- python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 3 --warmup 1 $(cfg_args $c) > $O/hbm_$ctr.log 2>&1; done
       python tools/pmc_table.py $O/kernel_stats_$c.md $O/hbm_table_$c.md $O/hbm_FETCH_SIZE $O/hbm_WRITE_SIZE > /dev/null; rm -rf $O/hbm_FETCH_SIZE $O/hbm_WRITE_SIZE; head -16 $O/hbm_table_$c.md | cut -c1-170;;
     cli-2k) GVFI_CLI_TIMING=1 timeout 300 python tools/cli_bench.py 33 2048 1088 8 0.5 > $O/cli_bench_2k.txt 2>&1; cut -c1-300 $O/cli_bench_2k.txt;;
     cli-2k-dry8) timeout 400 python tools/cli_bench.py 65 2048 1088 8 0.5 8 dry > $O/cli_bench_2k_dry8.txt 2>&1; cut -c1-400 $O/cli_bench_2k_dry8.txt;;
@@ -60,19 +61,19 @@ for step in "$@"; do
     ab-host)   # same-box A/B of the round-5 host-side changes (zero-once buffers + graph-static outputs) at 448x256 and 4K
       : > $O/ab_host.txt
       for rep in 1 2; do for val in 0 1; do for cfg in r448 r4k; do
-        line=$(GVFI_ZERO_ONCE=$val GIMMVFI_STATIC_OUTPUTS=$val timeout 400 python bench.py --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --details $O/ab_tmp.json 2>/dev/null | tail -1)
+        line=$(GVFI_ZERO_ONCE=$val GIMMVFI_STATIC_OUTPUTS=$val timeout 400 python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --details $O/ab_tmp.json 2>/dev/null | tail -1)
         echo "zero_once=static_outputs=$val $cfg $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_host.txt
       done; done; done; cat $O/ab_host.txt;;
     ab-*)   # ab-<ENVVAR>: same-box A/B of a switch (0 / 1 / 0 / 1) on the R and F 448x256 headlines, graph replay only
       v=${step#ab-}; : > $O/ab_$v.txt
       for rep in 1 2; do for val in 0 1; do for mdl in r f; do
-        line=$(env $v=$val timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --model $mdl --details $O/ab_tmp.json 2>/dev/null | tail -1)
+        line=$(env $v=$val timeout 300 python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 20 --warmup 5 --model $mdl --details $O/ab_tmp.json 2>/dev/null | tail -1)
         echo "$v=$val model=$mdl $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/ab_$v.txt
       done; done; done; cat $O/ab_$v.txt;;
     wdir-floor)   # what bounds the recurrence: the same graph with the weights-direct launches' K loop / epilogue skipped (garbage results)
       : > $O/wdir_floor.txt
       for dbg in 0 16 8 24 0; do for lanes in 2 1; do
-        line=$(GVFI_WDIR_DBG=$dbg GVFI_RAFT_LANES=$lanes timeout 300 python bench.py --configs none --no-cpu-baseline --steps 20 --warmup 5 --details $O/ab_tmp.json 2>/dev/null | tail -1)
+        line=$(GVFI_WDIR_DBG=$dbg GVFI_RAFT_LANES=$lanes timeout 300 python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 20 --warmup 5 --details $O/ab_tmp.json 2>/dev/null | tail -1)
         echo "GVFI_WDIR_DBG=$dbg lanes=$lanes $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/wdir_floor.txt
       done; done; cat $O/wdir_floor.txt;;
     fpolicy-all) timeout 900 python tools/f_policy_diag.py "--policies=dec:f16;enc:f16,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy_all.txt 2>&1; cut -c1-250 $O/f_policy_all.txt | tail -14;;
@@ -80,7 +81,7 @@ for step in "$@"; do
       : > $O/fpol_bench.txt
       for pol in "dec:f16" "f16" "enc:f16,cost:f16,dec:f16" "dec:f16" "f16"; do
         for cfg in f448 f4k; do
-          line=$(timeout 400 python bench.py --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --flow-precision "$pol" --details $O/ab_tmp.json 2>/dev/null | tail -1)
+          line=$(timeout 400 python bench.py --in-flight 1 --configs none --no-cpu-baseline --steps 10 --warmup 3 $(cfg_args $cfg) --flow-precision "$pol" --details $O/ab_tmp.json 2>/dev/null | tail -1)
           echo "$cfg $pol $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $O/fpol_bench.txt
         done; done; cat $O/fpol_bench.txt;;
     fpolicy) timeout 600 python tools/f_policy_diag.py demo2k_ds050 "--policies=dec:f16;enc,dec:f16;cost,dec:f16;enc,cost,dec:f16;enc:f16,cost:f16,dec:f16" > $O/f_policy.txt 2>&1; cut -c1-260 $O/f_policy.txt | tail -8;;
