@@ -1,15 +1,15 @@
 """Fill the measured results of a bench.py line (all configurations) into DESIGN.md / README.md placeholders.
-usage: python tools/fill_results.py profiles/r5_bench_all_final.json"""
+usage: python tools/fill_results.py profiles/r6_bench_all_final.json"""
 import json
 import re
 import sys
 
 ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][-1])
-rows = [("R 448×256, 8 pairs, t = 0.5 (`configs[1]`, the driver's headline)", d["value"], d["ms_per_step"], d["roofline"], "338.95 (driver) / 348.4")]
-r3 = {"configs[2]": "107.2 (driver) / 112.0", "configs[2]/[4] frame size: R at 4K DS 0.25": "94.1 (driver) / 97.2", "configs[3]": "186.9 (driver) / 191.8",
-      "configs[4]": "64.7 (driver) / 66.3", "configs[1] in fp32 mode (the reference's own arithmetic)": "57.9",
-      "configs[3] in fp32 mode (the reference's own arithmetic)": "—"}
+rows = [("R 448×256, 8 pairs, t = 0.5 (`configs[1]`, the driver's headline)", d["value"], d["ms_per_step"], d["roofline"], "359.8")]
+r3 = {"configs[2]": "115.9", "configs[2]/[4] frame size: R at 4K DS 0.25": "102.1", "configs[3]": "194.0",
+      "configs[4]": "69.2", "configs[1] in fp32 mode (the reference's own arithmetic)": "58.7",
+      "configs[3] in fp32 mode (the reference's own arithmetic)": "40.9"}
 names = {"configs[2]": "R 2K 2048×1088 DS 0.5, 8× (`configs[2]`, per GPU)", "configs[2]/[4] frame size: R at 4K DS 0.25": "R 4K 4096×2176 DS 0.25, 8×",
          "configs[3]": "F 448×256, 8 pairs (`configs[3]`), default policy `f16`", "configs[4]": "F 4K DS 0.25, 8× (`configs[4]`, per GPU)",
          "configs[1] in fp32 mode (the reference's own arithmetic)": "R 448×256, 8 pairs, **fp32 mode** (exact-f32 MFMA: the reference's own arithmetic)",
@@ -17,8 +17,8 @@ names = {"configs[2]": "R 2K 2048×1088 DS 0.5, 8× (`configs[2]`, per GPU)", "c
 for c in d.get("configs", []):
     rows.append((names[c["baseline_config"]], c["value"], c["ms_per_step"], c["roofline"], r3[c["baseline_config"]]))
 tab = ["**All configurations of the metric, one MI355X, one `bench.py` run** (`" + sys.argv[1] + "`; box-to-box spread of the same",
-       "build 2–4 %, so gains are quoted from same-box A/Bs, `profiles/HISTORY.md`):", "",
-       "| configuration | frames/s | ms/step | dominant kernel: achieved / peak | whole path / peak | end of round 4 |", "|---|---|---|---|---|---|"]
+       "build 2–4 %, so gains are quoted from same-box A/Bs, `profiles/HISTORY.md`; " + str(d["config"].get("steps_in_flight", 1)) + " steps in flight per GPU, `bench.py`'s default):", "",
+       "| configuration | frames/s | ms/step | dominant kernel: achieved / peak | whole path / peak | end of round 5 |", "|---|---|---|---|---|---|"]
 for n, v, ms, rf, old in rows:
     path = rf.get("path", {}).get("frac")
     tab.append(f"| {n} | **{v:.1f}** | {ms:.1f} | `{rf['kernel'].split('<')[0]}` {rf['achieved']:.0f} / {rf['peak']:.0f} TFLOP/s = **{rf['frac']:.2f}** "
@@ -39,9 +39,9 @@ ffp32 = byc.get("configs[3] in fp32 mode (the reference's own arithmetic)", {"va
 ck = d["roofline"].get("clock") or {}
 sp = (f"GIMM-VFI-R 448×256, 8 pairs/step: **{d['value']:.1f} interpolated frames/s** ({d['ms_per_step']:.1f} ms/step); 2K DS 0.5 8×: **{byc['configs[2]']['value']:.1f}**; "
       f"4K DS 0.25 8×: **{byc['configs[2]/[4] frame size: R at 4K DS 0.25']['value']:.1f}**; GIMM-VFI-F: **{byc['configs[3]']['value']:.1f}** at 448×256, **{byc['configs[4]']['value']:.1f}** at 4K; "
-      f"fp32 mode (the reference's own arithmetic): R {fp32['value']:.1f}, F {ffp32['value']:.1f}.  Round 4 (its own box): 348.4 / 112.0 / 97.2 / 191.8 / 66.3 / 57.9; the pool's boxes differ by ~5 %.  "
+      f"fp32 mode (the reference's own arithmetic): R {fp32['value']:.1f}, F {ffp32['value']:.1f}.  Round 5 (its own box): 359.8 / 115.9 / 102.1 / 194.0 / 69.2 / 58.7 / 40.9; the pool's boxes differ by ~5 %.  "
       f"Hot 3×3 256→256 convolution {d['roofline']['achieved']:.0f} TFLOP/s = {d['roofline']['frac']:.2f} of the dense bf16 peak ({ck.get('cycles_per_tile', 0):.0f} cycles per tile at >= {ck.get('mhz', 0):.0f} MHz measured in the run; "
-      "MFMA pipe busy 0.70 at the clock the power limit allows, `DESIGN.md §4`); CLI end to end incl. PNG decode "
+      "MFMA pipe busy 0.72 at the clock the power limit allows, `DESIGN.md §4`); two steps in flight per GPU (`StepsInFlight`, +3–9 %, every step bit-identical to the same step alone); CLI end to end incl. PNG decode "
       "and writing every frame: 2K DS 0.5 8× 79–82 frames/s on one GPU, host-encode bound (`profiles/r5_cli_bench_*.txt`)")
 r = open(ROOT + "/README.md").read()
 r = re.sub(r"@@SPEED@@|<!-- speed -->.*?<!-- /speed -->", "<!-- speed -->" + sp + "<!-- /speed -->", r, flags=re.S)
