@@ -286,10 +286,19 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
         nstep[0] += 1
         return pipe.submit(xs[k], coords, ts, ds_factor=ds, then=finish)
 
+    calib = None
     if pipe is not None:
-        for k in range(1, in_flight):        # set-up, like building the model: every further slot captures its graph before the warm-up steps
-            pipe.replicas[k](xs[k], coords, t=ts, ds_factor=ds)
+        pipe.prime(x, coords, ts, ds_factor=ds)     # set-up, like building the model: every slot captures its graph before the warm-up steps
         torch.cuda.synchronize()
+        # set-up too: which hardware queues the two slots' launch streams sit on decides whether the steps overlap at all
+        # (StepsInFlight.calibrate: forked and linear slot graphs on a few pairs of streams, timed for a few steps each, the best kept --
+        # or the model alone when nothing beats it)
+        if in_flight == 2 and os.environ.get("GIMMVFI_BENCH_CALIBRATE", "1") != "0":
+            def fps(v):
+                return {k_: fps(x_) for k_, x_ in v.items()} if isinstance(v, dict) else (round(v * B * (NI - 1), 1) if isinstance(v, float) else v)
+
+            calib = fps(pipe.calibrate(x, coords, ts, ds_factor=ds))
+            calib["unit"] = "frames/s, 8 steps per configuration"
     dt = timed_steps(step, steps, warmup, world, torch.cuda.synchronize)
     dt_rank = dt
     # Roofline pass: the timed steps above replay a hipGraph (no host work between kernels), and HIP events cannot
@@ -363,7 +372,8 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
         res = {"value": round(value, 3), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                "dtype": c["precision"], "workload": workload_name(c), "roofline": roofline, "ev_over_ms": ev_over_ms,
                "ev_steps": ev_steps, "flow_iters": 20 if c["model"] == "r" else 32,
-               "gather_bytes_per_rank_per_step": B * (NI - 1) * H * W * 3 if world > 1 else 0, "steps_in_flight": in_flight}
+               "gather_bytes_per_rank_per_step": B * (NI - 1) * H * W * 3 if world > 1 else 0, "steps_in_flight": pipe.depth if pipe is not None else 1,
+               "in_flight_calibration": calib}
         if per_rank is not None:
             res["ms_per_step_per_rank"] = per_rank
         if c["model"] == "f":
@@ -523,6 +533,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": r["workload"],
                        "pairs_per_step_per_gpu": B, "flow_iters": r["flow_iters"], "steps_in_flight": r["steps_in_flight"],
+                       **({"in_flight_calibration": r["in_flight_calibration"]} if r.get("in_flight_calibration") else {}),
                        **({"flow_precision": r["flow_precision"]} if args.model == "f" else {}),
                        "parallelism": f"pair-sharded x{world}",
                        "world_size_rccl": dist.get_world_size() if world > 1 else 1,

@@ -81,9 +81,23 @@ class Engine:
         self.misc_lanes = os.environ.get("GVFI_MISC_LANES", "0") == "1"      # (A/B switch: two more small fork / joins, see _raft / _synthesize)
         self.enc_lanes = os.environ.get("GVFI_ENC_LANES", "1") != "0"
         self.post_lanes = os.environ.get("GVFI_POST_LANES", "1") != "0"
+        self._lane_defaults = None
         self._tb_mem = {}
         self.layers = {}
         self._build(sd)
+
+    def set_serial_launch(self, serial=True):
+        """serial=True: every parallel launch sequence off -- the captured forward is a LINEAR graph that runs entirely on its
+        launch stream (the branches of a forked graph run on internal streams of the HIP runtime).  3-7 % slower for one forward
+        at a time; one of the two slot kinds StepsInFlight.calibrate() chooses between.  serial=False restores the switches."""
+        names = ("raft_lanes", "synth_lanes", "misc_lanes", "enc_lanes", "post_lanes")
+        if self._lane_defaults is None:
+            self._lane_defaults = {n: getattr(self, n) for n in names}
+        if serial:
+            self.raft_lanes, self.synth_lanes, self.misc_lanes, self.enc_lanes, self.post_lanes = 1, False, False, False, False
+        else:
+            for n, v in self._lane_defaults.items():
+                setattr(self, n, v)
 
     # ------------------------------------------------------------------ weight preparation
     def _add(self, name, w, b, **kw):

@@ -116,6 +116,9 @@ class GIMMVFI_R(nn.Module):
         # frames right away -- can opt out: the outputs are then the graph's own static tensors, valid until that next
         # forward (at 4K x 7 timesteps the clones were 87 copies / 1.4 ms of a 72 ms step; 38 copies / 0.15 ms at 448x256).
         self.static_outputs = os.environ.get("GIMMVFI_STATIC_OUTPUTS", "0") == "1"
+        # serial_launch: the engine's parallel launch sequences off (Engine.set_serial_launch): a linear graph per forward.  Slower for
+        # one forward at a time (-3 ... -7 %); one of the slot kinds of StepsInFlight.
+        self.serial_launch = False
 
     # ---- engine cache invalidation: weights are folded/packed for the kernels lazily
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -144,6 +147,10 @@ class GIMMVFI_R(nn.Module):
             self._engine = self._make_engine(runtime)
             self._engine_key = key
             self._graphs = {}     # graphs captured on the previous engine replay ITS buffers and packed weights
+        if getattr(self._engine, "_serial_applied", None) != self.serial_launch:
+            self._engine.set_serial_launch(self.serial_launch)
+            self._engine._serial_applied = self.serial_launch
+            self._graphs = {}     # (captured with the other launch structure)
         return self._engine
 
     def _make_engine(self, runtime):
@@ -208,6 +215,7 @@ class GIMMVFI_R(nn.Module):
         r.load_state_dict(self.state_dict(), strict=True)
         r = r.to(next(self.parameters()).device).eval()
         r.use_graph, r.static_outputs, r.max_graphs, r.raft_iter = self.use_graph, self.static_outputs, self.max_graphs, self.raft_iter
+        r.serial_launch = self.serial_launch
         return r
 
     def _forward_graph(self, eng, img_xs, coord, t, iters, ds_factor, seq=False):
@@ -336,12 +344,13 @@ class GIMMVFI_F(GIMMVFI_R):
 class StepsInFlight:
     """Addition to the reference API for throughput: `depth` independent steps in flight on one GPU.  Slot k is a replica of the
     model (its own engine, buffers and captured graphs) with its own stream; submit() launches one forward on the next slot's
-    stream and returns at once, so consecutive steps overlap on the device: the latency-bound flow estimator of one batch runs
-    under the MFMA-bound synthesis of the other (profiles/r6_steps_in_flight.txt: +6 % at 448x256, batch 8; every step's output
-    bit-identical to the same step run alone -- the forward is bit-reproducible, tests/test_gpu_e2e.py).  The arithmetic of a step
-    is untouched: the same launch list as model.forward().
+    stream and returns at once, so consecutive steps overlap on the device at kernel granularity -- two latency-bound launch
+    chains fill each other's gaps (profiles/r6_steps_in_flight.txt, r6_queue_probe*.txt: +5 ... +14 % at 448x256, batch 8; every
+    step's output bit-identical to the same step run alone -- the forward is bit-reproducible, tests/test_gpu_e2e.py).  The
+    arithmetic of a step is untouched: the same kernels as model.forward().
 
         pipe = StepsInFlight(model, depth=2)
+        pipe.calibrate(img_xs, coord, t)      # once per input signature (set-up, like capturing the graphs): see calibrate()
         h = pipe.submit(img_xs, coord, t, ds_factor=None, then=lambda out, m: to_u8(out["imgt_pred"][0]))
         ...                                   # submit more; the host never blocks
         frames = pipe.wait(h)                 # the caller's stream waits for that step (device-side wait, no host sync)
@@ -350,19 +359,39 @@ class StepsInFlight:
     model.static_outputs the tensors a step returns are the slot's own graph outputs: valid until that slot's next submit, i.e.
     for `depth` more submits."""
 
-    def __init__(self, model, depth=2):
+    def __init__(self, model, depth=2, serial=None):
+        """serial: True = the slots launch LINEAR graphs (model.serial_launch: the engine's parallel launch sequences off), False =
+        the model's own (forked) graphs, None = the model's own until calibrate() has measured both kinds."""
         assert depth >= 1
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("StepsInFlight needs the model on an MI355X ('cuda'): there is no CPU path")
         self.device = dev
-        self.replicas = [model] + [model.replica() for _ in range(depth - 1)]
+        self.model = model
+        self._auto = serial is None
+        self.serial = model.serial_launch if serial is None else bool(serial)
+        self.replicas = self._make_replicas(depth, self.serial)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.calibration = None
         self._n = 0
+
+    def _make_replicas(self, depth, serial):
+        if serial == self.model.serial_launch:
+            return [self.model] + [self.model.replica() for _ in range(depth - 1)]
+        reps = []                                    # (the model handed in keeps its own setting: every slot is a replica then)
+        for _ in range(depth):
+            r = self.model.replica()
+            r.serial_launch = serial
+            reps.append(r)
+        return reps
 
     @property
     def depth(self):
         return len(self.replicas)
+
+    @staticmethod
+    def _forward(m, img_xs, coord, t, ds_factor, sequence):
+        return m.forward_sequence(img_xs, coord=coord, t=t, ds_factor=ds_factor) if sequence else m(img_xs, coord, t=t, ds_factor=ds_factor)
 
     def submit(self, img_xs, coord, t, ds_factor=None, then=None, sequence=False):
         k = self._n % len(self.replicas)
@@ -370,11 +399,18 @@ class StepsInFlight:
         m, s = self.replicas[k], self.streams[k]
         s.wait_stream(torch.cuda.current_stream(self.device))          # the inputs were produced on the caller's stream
         with torch.cuda.stream(s):
-            out = m.forward_sequence(img_xs, coord=coord, t=t, ds_factor=ds_factor) if sequence else m(img_xs, coord, t=t, ds_factor=ds_factor)
+            out = self._forward(m, img_xs, coord, t, ds_factor, sequence)
             res = then(out, m) if then is not None else out
             ev = torch.cuda.Event()
             ev.record(s)
         return ev, res
+
+    def prime(self, img_xs, coord, t, ds_factor=None, sequence=False):
+        """One forward per slot, slot 0 first, each on its own stream: captures every slot's graph (set-up)."""
+        for m, st in zip(self.replicas, self.streams):
+            with torch.cuda.stream(st):
+                self._forward(m, img_xs, coord, t, ds_factor, sequence)
+            st.synchronize()
 
     def wait(self, handle):
         ev, res = handle
@@ -384,6 +420,76 @@ class StepsInFlight:
     def drain(self):
         for s in self.streams:
             s.synchronize()
+
+    def calibrate(self, img_xs, coord, t, ds_factor=None, steps=8, extra_pairs=3, sequence=False):
+        """Choose how the two slots are run BY MEASUREMENT (depth 2), because whether two captured forwards in flight overlap
+        on this runtime is decided by state nobody controls.  Round 6 measured (profiles/r6_queue_probe*.txt), for the same two
+        graphs and nothing changed but the pair of launch streams: 199 / 201 / 226 frames/s (F 448x256) and 362 / 372 / 386 / 397
+        (R); pairs of streams that alias onto one of HIP's 4 hardware queues do not overlap at all, some other pairs run SLOWER
+        than one step at a time (a slot's launch queue colliding with the internal streams the other graph's branches run on),
+        whole processes in which no pair lets two forked F graphs overlap, and linear graphs (no branches) that overlap on the
+        streams they were first replayed on.  The outcome is stable for a given pair of graphs and streams, so it can be
+        measured once: for each slot kind (the model's forked graphs; linear graphs, unless the constructor fixed the kind) the
+        slots are primed on a fresh pair of streams and timed for `steps` steps there and on `extra_pairs` more fresh pairs; the
+        best configuration stays if it beats the model alone, one step at a time, by more than 1 % -- otherwise the pipeline
+        degenerates to exactly that (depth 1).  Set-up work like capturing the graphs: call it once per input signature before
+        the steady state.  Returns the table (steps/s)."""
+        import gc
+        import time
+
+        if len(self.replicas) != 2:
+            return {}
+        dev = self.device
+
+        def rate(n=steps):
+            best = 0.0
+            for rep in range(2):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    self.submit(img_xs, coord, t, ds_factor=ds_factor, sequence=sequence)
+                torch.cuda.synchronize(dev)
+                if rep:                              # (the first repetition warms the configuration up)
+                    best = n / (time.perf_counter() - t0)
+            return best
+
+        report = {}
+        keep = (self.replicas, self.streams, self.serial)
+        self.replicas, self.streams = [self.model], [torch.cuda.Stream(device=dev)]
+        self.prime(img_xs, coord, t, ds_factor=ds_factor, sequence=sequence)
+        base = report["model alone, one step at a time"] = rate()
+        self.replicas, self.streams, self.serial = keep
+        best = (base * 1.01, None)
+        tried = []
+        for kind in ([self.serial] + ([not self.serial] if self._auto else [])):
+            name = "linear graphs" if kind else "forked graphs"
+            reps = self.replicas if kind == self.serial else self._make_replicas(2, kind)
+            self.replicas = reps
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self.prime(img_xs, coord, t, ds_factor=ds_factor, sequence=sequence)
+            tab = report[name] = {}
+            for trial in range(1 + extra_pairs):
+                if trial:
+                    self.streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+                r = tab["streams as primed" if trial == 0 else f"fresh stream pair {trial}"] = rate()
+                if r > best[0]:
+                    best = (r, (reps, list(self.streams), kind, name + ", " + ("streams as primed" if trial == 0 else f"fresh stream pair {trial}")))
+            tried.append(reps)
+            for old in tried:                        # (memory: a captured 4K forward holds tens of GB -- only the leader's graphs stay)
+                if best[1] is None or best[1][0] is not old:
+                    for m in old:
+                        if m is not self.model:
+                            m._graphs = {}
+            gc.collect()
+            torch.cuda.empty_cache()
+        if best[1] is None:
+            self.replicas, self.streams, self.serial = [self.model], [torch.cuda.Stream(device=dev)], self.model.serial_launch
+            report["picked"] = "model alone, one step at a time"
+        else:
+            self.replicas, self.streams, self.serial, report["picked"] = best[1]
+        self.prime(img_xs, coord, t, ds_factor=ds_factor, sequence=sequence)      # (a kind whose graphs were dropped above is re-captured)
+        self.calibration = report
+        return report
 
 
 class GIMM(nn.Module):

@@ -159,3 +159,19 @@ def test_zero_once_buffers_are_released_with_the_signature_that_used_them():
     rt.once_scope = None
     c = rt.act(1, 4, 4, 3, once="x")             # outside any signature: kept for the runtime's life, as before
     assert c is not a1 and rt.once_bytes() > 0
+
+
+def test_serial_launch_switch_turns_every_parallel_launch_sequence_off_and_back(sd):
+    """Engine.set_serial_launch (the linear-graph slot kind of StepsInFlight): all five lane switches off, and restored exactly."""
+    from hostsim.sim_runtime import SimRuntime
+    from gimmvfi_hip.engine import Engine
+
+    eng = Engine(SimRuntime("fp32"), sd)
+    names = ("raft_lanes", "synth_lanes", "misc_lanes", "enc_lanes", "post_lanes")
+    before = {n: getattr(eng, n) for n in names}
+    assert before["raft_lanes"] == 2 and before["enc_lanes"] and before["post_lanes"] and before["synth_lanes"]
+    eng.set_serial_launch(True)
+    assert eng.raft_lanes == 1 and not any(getattr(eng, n) for n in names[1:])
+    eng.set_serial_launch(True)
+    eng.set_serial_launch(False)
+    assert {n: getattr(eng, n) for n in names} == before

@@ -473,10 +473,27 @@ def test_steps_in_flight_return_each_steps_own_result_bit_for_bit(cfg, sd, sd_f)
     m.static_outputs = True                      # (the slots' own graph outputs: pack() reads them on the slot's stream)
     pipe = StepsInFlight(m, depth=2)
     assert pipe.depth == 2 and pipe.replicas[1] is not m and pipe.replicas[1].static_outputs
-    handles = [pipe.submit(xs[i % 4], coords, ts, then=pack) for i in range(12)]
-    for i, h in enumerate(handles):
-        frames, flow = pipe.wait(h)
-        torch.cuda.synchronize()
-        assert torch.equal(frames, alone[i % 4][0]), (i, int((frames != alone[i % 4][0]).sum()))
-        assert torch.equal(flow, alone[i % 4][1]), i
-    pipe.drain()
+
+    def check(tag):
+        handles = [pipe.submit(xs[i % 4], coords, ts, then=pack) for i in range(12)]
+        for i, h in enumerate(handles):
+            frames, flow = pipe.wait(h)
+            torch.cuda.synchronize()
+            assert torch.equal(frames, alone[i % 4][0]), (tag, i, int((frames != alone[i % 4][0]).sum()))
+            assert torch.equal(flow, alone[i % 4][1]), (tag, i)
+        pipe.drain()
+
+    check("forked slots on the streams they were created with")
+    # calibrate() chooses slot kind (the model's forked graphs / linear graphs) and launch streams by measurement, or falls back to
+    # the model alone; whatever it picks, every step still returns the model's own result
+    report = pipe.calibrate(xs[0], coords, ts, steps=3, extra_pairs=1)
+    assert report["picked"] in ("model alone, one step at a time",) or report["picked"].split(",")[0] in ("forked graphs", "linear graphs")
+    assert set(report) >= {"model alone, one step at a time", "forked graphs", "linear graphs", "picked"}
+    assert pipe.depth in (1, 2) and all(r.serial_launch == pipe.serial for r in pipe.replicas)
+    check("after calibrate(): " + report["picked"])
+    # and a pipeline whose slots are linear graphs by construction
+    pipe = StepsInFlight(m, depth=2, serial=True)
+    assert all(r.serial_launch and r is not m for r in pipe.replicas) and not m.serial_launch
+    check("linear slots")
+    e = pipe.replicas[0].engine(DEV)
+    assert e.raft_lanes == 1 and not (e.enc_lanes or e.post_lanes or e.synth_lanes)

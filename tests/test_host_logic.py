@@ -363,6 +363,7 @@ def test_steps_in_flight_refuses_a_model_that_is_not_on_the_gpu():
     m = GIMMVFI_R(precision="bf16")
     with pytest.raises(RuntimeError, match="MI355X"):
         StepsInFlight(m, depth=2)
+    m.serial_launch = True
     r = m.replica()
-    assert type(r) is GIMMVFI_R and r is not m and r.precision == m.precision
+    assert type(r) is GIMMVFI_R and r is not m and r.precision == m.precision and r.serial_launch
     assert all((a == b).all() for a, b in zip(m.state_dict().values(), r.state_dict().values()))
