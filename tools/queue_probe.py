@@ -65,9 +65,7 @@ pipe.streams[1] = hp
 print(f"   slot 1 on a high-priority stream: spin ratio {spin_ratio(*pipe.streams):.2f}; {rate():.1f} frames/s")
 pipe.streams[0] = torch.cuda.Stream(device=DEV, priority=-1)
 print(f"   both slots on high-priority streams: spin ratio {spin_ratio(*pipe.streams):.2f}; {rate():.1f} frames/s")
-for steps in (4, 12, 24):
-    pipe2 = StepsInFlight(m, depth=2, serial=False)
-    tab = pipe2.calibrate(xs[0], coords, ts, steps=steps)
-    print(f"StepsInFlight.calibrate, {steps} steps per pairing (frames/s):", {k: (round(v * B, 1) if isinstance(v, float) else v) for k, v in tab["forked graphs"].items()})
-    pipe = pipe2
-    print(f"   after calibration: {rate(20):.1f} frames/s")
+pipe = StepsInFlight(m, depth=2)
+tab = pipe.calibrate(xs[0], coords, ts)
+print("StepsInFlight.calibrate (steps/s):", tab)
+print(f"   after calibration: depth {pipe.depth}, {rate(20):.1f} frames/s")

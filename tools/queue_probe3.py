@@ -1,4 +1,4 @@
-"""Probe 3: StepsInFlight with serial (linear-graph) slots, depth 1..4, slot streams on distinct hardware queues.
+"""Probe 3: StepsInFlight with forked / linear slot graphs at depth 1..4, then what calibrate() picks.
 usage: python tools/queue_probe3.py [r|f] [B H W ds NI]"""
 import os
 import sys
@@ -46,17 +46,15 @@ def rate(pipe, K=16):
     return B * (NI - 1) * K / (time.perf_counter() - t0)
 
 
-for depth, serial in ((2, {'none': None, 'forked': False, 'linear': True}[os.environ.get('KIND', 'none')]),):
+for depth, serial in ((1, False), (1, True), (2, False), (2, True), (3, True), (4, True)):
     pipe = StepsInFlight(m, depth=depth, serial=serial)
     pipe.prime(x, coords, ts, ds_factor=dsf)
-    r0 = rate(pipe)
-    extra = ""
-    if depth == 2:
-        tab = pipe.calibrate(x, coords, ts, ds_factor=dsf)
-        extra = "; calibrated (" + tab["picked"] + f"): {rate(pipe):.1f}"
-        for k, v in tab.items():
-            if isinstance(v, dict):
-                print("   ", k, {kk: (round(vv * B * (NI - 1), 1) if isinstance(vv, float) else vv) for kk, vv in v.items()})
-    print(f"{mdl} {W}x{H} depth {depth} {'serial' if serial else 'forked'} slots: {r0:.1f} frames/s as created{extra}")
+    print(f"{mdl} {W}x{H} depth {depth} {'linear' if serial else 'forked'} slots on the streams they were primed on: {rate(pipe):.1f} frames/s")
     del pipe
     torch.cuda.empty_cache()
+pipe = StepsInFlight(m, depth=2)
+tab = pipe.calibrate(x, coords, ts, ds_factor=dsf)
+scale = B * (NI - 1)
+print("StepsInFlight.calibrate (frames/s):", {k: ({kk: round(vv * scale, 1) for kk, vv in v.items()} if isinstance(v, dict) else (round(v * scale, 1) if isinstance(v, float) else v))
+                                              for k, v in tab.items()})
+print(f"   after calibration: depth {pipe.depth}, {rate(pipe):.1f} frames/s")
