@@ -102,6 +102,9 @@ EXTRA_CONFIGS = [
 ]
 
 
+FORCE_GATHER = os.environ.get("GIMMVFI_BENCH_FORCE_GATHER", "0") == "1"
+
+
 def workload_name(c):
     return (f"GIMM-VFI-{c['model'].upper()} {c['width']}x{c['height']} batch={c['batch']} pairs/GPU, {c['n_interp']}x interpolation "
             f"(t=i/{c['n_interp']}), DS_SCALE={c['ds']:g}, seeded random-init weights")
@@ -256,14 +259,17 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
     ts = [(i / NI) * torch.ones(B, device=dev) for i in range(1, NI)]
     rt = model.engine(dev).rt
     gather_buf = None
-    if world > 1 and rank == 0:
+    # (GIMMVFI_BENCH_FORCE_GATHER=1: the RCCL gather also at world size 1 -- the N > 1 step, collectives issued from the slots' streams
+    # included, rehearsed on a one-GPU box; the process group is initialised in main())
+    do_gather = world > 1 or FORCE_GATHER
+    if do_gather and rank == 0:
         shp = (B, H, W, 3) if NI == 2 else (B, NI - 1, H, W, 3)
         gather_buf = [torch.empty(shp, dtype=torch.uint8, device=dev) for _ in range(world)]
 
     def finish(out, m):
         u8 = m.engine(dev).rt.frames_to_u8
         frames = u8(out["imgt_pred"][0]) if NI == 2 else torch.stack([u8(f) for f in out["imgt_pred"]], 1)
-        if world > 1:
+        if do_gather:
             dist.gather(frames, gather_buf, dst=0)   # the path's only collective: result gather to rank 0
         return frames
 
@@ -441,8 +447,12 @@ def main():
         sys.exit(f"bench.py: rank {rank} needs GPU {local} but {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or FORCE_GATHER:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
         assert dist.get_world_size() == world
 
@@ -556,8 +566,16 @@ def main():
                 f.write("\n")
         except OSError:
             details = None
-        print(json.dumps(line if args.full_line else compact_line(line, details)))
-    if world > 1:
+        # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would otherwise be flushed at exit, BEHIND
+        # the line: flush it out first so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line if args.full_line else compact_line(line, details)), flush=True)
+    if world > 1 or FORCE_GATHER:
         dist.destroy_process_group()
 
 
