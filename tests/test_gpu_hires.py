@@ -296,12 +296,16 @@ def test_hires_matches_reference_fixture(sd, name, prec):
 # easy cases pass) = measured value (profiles/r5_f_policy_all.txt; two calls agree within 0.2 dB) - 1.5 dB / x1.3 / x1.3 / x1.2.
 # Fast mode (flow_precision = "bf16"): per-case pins = measured value + margin (three calls of round 3 agree within 0.3 dB): it
 # reaches 40 dB only while the flows are small (the *_fh015 fixtures below).
-F_DEFAULT_BOUNDS = {
-    "demo_864x736": (51.4, 0.0095, 0.125, 7.7),    # measured 53.0 dB, 0.0071, 0.095 px, 6.3 px  (51 px flows; "dec:f16": 50.3 dB)
-    "2k_ds050": (48.8, 0.037, 0.082, 5.2),         # 50.3 dB, 0.028, 0.063 px, 4.3 px
-    "demo2k_ds050": (42.1, 0.185, 0.111, 7.9),     # 43.7 dB, 0.14, 0.085 px, 6.5 px      (the hardest case; "dec:f16": 41.6 dB)
-    "4k_ds025": (45.3, 0.195, 0.083, 5.2),         # 46.8 dB, 0.15, 0.063 px, 4.3 px
+F_REQUIREMENT_DB = 40.0      # every bf16-mode test of this suite: >= 40 dB against the reference, on every fixture
+# measured (PSNR dB, fraction of crop pixels > 1 LSB, mean flow error px, p99.9 flow error px), profiles/r6_gpu_parity_final.log
+F_DEFAULT_MEASURED = {
+    "demo_864x736": (52.9, 0.0073, 0.096, 6.4),    # (51 px flows; policy "dec:f16" of rounds 3-4: 50.3 dB)
+    "2k_ds050": (50.3, 0.028, 0.063, 4.3),
+    "demo2k_ds050": (43.6, 0.142, 0.085, 6.6),     # (the hardest case; "dec:f16": 41.6 dB; all-float flow estimator: 46.2 dB)
+    "4k_ds025": (46.8, 0.15, 0.064, 4.3),
 }
+# gate = max(requirement, measured - 1.5 dB); the three error figures: measured x 1.3 / x 1.3 / x 1.2
+F_DEFAULT_BOUNDS = {k: (max(F_REQUIREMENT_DB, v[0] - 1.5), v[1] * 1.3, v[2] * 1.3, v[3] * 1.2) for k, v in F_DEFAULT_MEASURED.items()}
 F_FAST_BOUNDS = {
     "demo_864x736": (37.5, 0.14, 0.50, 14.5),      # measured 39.0 dB, 0.11, 0.41 px, 12.6 px
     "2k_ds050": (38.3, 0.25, 0.26, 9.6),           # 39.8 dB, 0.20, 0.21 px, 8.3 px
