@@ -598,7 +598,8 @@ def compact_line(full, details):
     if "pmc" in rf:
         line["roofline"]["mfma_busy"] = rf["pmc"]["mfma_busy_frac"]
     if rf.get("traffic") is not None:
-        line["roofline"]["traffic_src"] = line["roofline"]["mfma_busy_src"] = rf["traffic_src"].split(" (")[0] + " (committed)"
+        # (one provenance string for both PMC-derived figures, traffic and mfma_busy: the line has to stay below 2 KB)
+        line["roofline"]["pmc_src"] = rf["traffic_src"].split(" (")[0] + " (committed PMC pass: traffic, mfma_busy)"
     if isinstance(rf.get("clock"), dict) and "mhz" in rf["clock"]:
         line["roofline"]["clock_mhz"] = rf["clock"]["mhz"]
         line["roofline"]["cycles_per_tile"] = rf["clock"]["cycles_per_tile"]
