@@ -303,8 +303,14 @@ def measure(c, steps, warmup, world, rank, dev, shapes=None, flow_precision=None
             def fps(v):
                 return {k_: fps(x_) for k_, x_ in v.items()} if isinstance(v, dict) else (round(v * B * (NI - 1), 1) if isinstance(v, float) else v)
 
-            calib = fps(pipe.calibrate(x, coords, ts, ds_factor=ds))
-            calib["unit"] = "frames/s, 8 steps per configuration"
+            try:
+                calib = fps(pipe.calibrate(x, coords, ts, ds_factor=ds))
+                calib["unit"] = "frames/s, 8 steps per configuration"
+            except Exception as ex:      # (set-up must never cost the run its line: fall back to the model alone, one step at a time)
+                calib = {"error": f"{type(ex).__name__}: {ex}"[:200], "picked": "model alone, one step at a time (calibration failed)"}
+                pipe.replicas, pipe.streams = [model], [torch.cuda.Stream(device=dev)]
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
     dt = timed_steps(step, steps, warmup, world, torch.cuda.synchronize)
     dt_rank = dt
     # Roofline pass: the timed steps above replay a hipGraph (no host work between kernels), and HIP events cannot
