@@ -421,19 +421,20 @@ class StepsInFlight:
         for s in self.streams:
             s.synchronize()
 
-    def calibrate(self, img_xs, coord, t, ds_factor=None, steps=8, extra_pairs=3, sequence=False):
+    def calibrate(self, img_xs, coord, t, ds_factor=None, steps=8, max_pairs=8, extra_pairs=2, good_enough=1.03, sequence=False):
         """Choose how the two slots are run BY MEASUREMENT (depth 2), because whether two captured forwards in flight overlap
-        on this runtime is decided by state nobody controls.  Round 6 measured (profiles/r6_queue_probe*.txt), for the same two
+        on this runtime is decided by state nobody controls.  Round 6 measured (profiles/r6_queue_probe.txt), for the same two
         graphs and nothing changed but the pair of launch streams: 199 / 201 / 226 frames/s (F 448x256) and 362 / 372 / 386 / 397
         (R); pairs of streams that alias onto one of HIP's 4 hardware queues do not overlap at all, some other pairs run SLOWER
         than one step at a time (a slot's launch queue colliding with the internal streams the other graph's branches run on),
-        whole processes in which no pair lets two forked F graphs overlap, and linear graphs (no branches) that overlap on the
-        streams they were first replayed on.  The outcome is stable for a given pair of graphs and streams, so it can be
-        measured once: for each slot kind (the model's forked graphs; linear graphs, unless the constructor fixed the kind) the
-        slots are primed on a fresh pair of streams and timed for `steps` steps there and on `extra_pairs` more fresh pairs; the
-        best configuration stays if it beats the model alone, one step at a time, by more than 1 % -- otherwise the pipeline
-        degenerates to exactly that (depth 1).  Set-up work like capturing the graphs: call it once per input signature before
-        the steady state.  Returns the table (steps/s)."""
+        whole processes in which no pair lets two forked F graphs overlap, and linear graphs (no branches) that overlap on
+        about every second pair of fresh streams.  The outcome is stable for a given pair of graphs and streams, so it can be
+        measured once.  Linear slots first (unless the constructor fixed the kind): primed on a fresh pair of streams and timed
+        for `steps` steps there, then on further fresh pairs until one beats the model alone by `good_enough` or `max_pairs` are
+        spent; then the other kind on the streams it is primed on + `extra_pairs` fresh pairs; the best configuration stays if it
+        beats the model alone, one step at a time, by more than 1 % -- otherwise the pipeline degenerates to exactly that
+        (depth 1).  Set-up work like capturing the graphs: call it once per input signature before the steady state.  Returns
+        the table (steps/s)."""
         import gc
         import time
 
@@ -461,19 +462,23 @@ class StepsInFlight:
         self.replicas, self.streams, self.serial = keep
         best = (base * 1.01, None)
         tried = []
-        for kind in ([self.serial] + ([not self.serial] if self._auto else [])):
+        kinds = [True, False] if self._auto else [self.serial]
+        for n_kind, kind in enumerate(kinds):
             name = "linear graphs" if kind else "forked graphs"
-            reps = self.replicas if kind == self.serial else self._make_replicas(2, kind)
+            reps = keep[0] if kind == keep[2] else self._make_replicas(2, kind)      # (the slots the pipeline was built with / new ones)
             self.replicas = reps
             self.streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
             self.prime(img_xs, coord, t, ds_factor=ds_factor, sequence=sequence)
             tab = report[name] = {}
-            for trial in range(1 + extra_pairs):
+            for trial in range(max_pairs if n_kind == 0 else 1 + extra_pairs):
                 if trial:
                     self.streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-                r = tab["streams as primed" if trial == 0 else f"fresh stream pair {trial}"] = rate()
+                where = "streams as primed" if trial == 0 else f"fresh stream pair {trial}"
+                r = tab[where] = rate()
                 if r > best[0]:
-                    best = (r, (reps, list(self.streams), kind, name + ", " + ("streams as primed" if trial == 0 else f"fresh stream pair {trial}")))
+                    best = (r, (reps, list(self.streams), kind, name + ", " + where))
+                if n_kind == 0 and r >= good_enough * base:
+                    break
             tried.append(reps)
             for old in tried:                        # (memory: a captured 4K forward holds tens of GB -- only the leader's graphs stay)
                 if best[1] is None or best[1][0] is not old:

@@ -486,7 +486,7 @@ def test_steps_in_flight_return_each_steps_own_result_bit_for_bit(cfg, sd, sd_f)
     check("forked slots on the streams they were created with")
     # calibrate() chooses slot kind (the model's forked graphs / linear graphs) and launch streams by measurement, or falls back to
     # the model alone; whatever it picks, every step still returns the model's own result
-    report = pipe.calibrate(xs[0], coords, ts, steps=3, extra_pairs=1)
+    report = pipe.calibrate(xs[0], coords, ts, steps=3, max_pairs=3, extra_pairs=1)
     assert report["picked"] in ("model alone, one step at a time",) or report["picked"].split(",")[0] in ("forked graphs", "linear graphs")
     assert set(report) >= {"model alone, one step at a time", "forked graphs", "linear graphs", "picked"}
     assert pipe.depth in (1, 2) and all(r.serial_launch == pipe.serial for r in pipe.replicas)
