@@ -134,9 +134,9 @@ def event_overhead_ms(dev):
 
 
 def recurrence_probe(dev, B=8, H=256, W=448, reps=8):
-    """The launch-bound part of the step IN THIS RUN: wall time of one RAFT iteration, both recurrence lanes
-    overlapped as in the step -- the same captured forward replayed with 20 and with 4 iterations (GIMMVFI_R.raft_iter), the
-    difference over 16.  This, not the hot kernel, is where the pool's boxes differ: ~20 us kernels in dependent chains of 13
+    """The launch-bound part of the step IN THIS RUN: wall time of one RAFT iteration as one launch sequence
+    (linear graph) -- the same captured forward replayed with 20 and with 4 iterations (GIMMVFI_R.raft_iter), the difference
+    over 16.  This, not the hot kernel, is where the pool's boxes differ: ~20 us kernels in dependent chains of 13
     launches follow the fabric / L2 clocks and the command processor, the hot kernel follows the power limit."""
     from gimmvfi_hip.model import GIMMVFI_R
     from gimmvfi_hip.params import random_state_dict
@@ -150,7 +150,8 @@ def recurrence_probe(dev, B=8, H=256, W=448, reps=8):
         m.load_state_dict(sd, strict=True)
         m = m.to(dev).eval()
         m.static_outputs = True
-        m.raft_iter = iters
+        m.serial_launch = True      # (a linear graph: how well a forked graph's branches overlap depends on the process's stream-to-queue
+        m.raft_iter = iters         #  mapping -- profiles/r6_queue_probe.txt -- and would make this probe measure that instead)
         coords = [(m.sample_coord_input(B, (H, W), [0.5], device=dev), None)]
         ts = [0.5 * torch.ones(B, device=dev)]
         for _ in range(2):
@@ -167,8 +168,9 @@ def recurrence_probe(dev, B=8, H=256, W=448, reps=8):
     per_it = (ms[20] - ms[4]) / 16.0
     return {"us_per_iteration": round(per_it * 1e3, 1), "recurrence_ms_per_step": round(per_it * 20, 3),
             "step_ms_20_iters": round(ms[20], 3), "step_ms_4_iters": round(ms[4], 3),
-            "note": "one step at a time; (graph replay with raft_iter 20 - with 4) / 16: wall time of one RAFT iteration with both lanes "
-                    "overlapped (13 launches per lane); x 20 = the recurrence's share of the step"}
+            "note": "one step at a time, LINEAR graphs (every parallel launch sequence off); (graph replay with raft_iter 20 - with 4) / 16: "
+                    "wall time of one RAFT iteration as ONE launch sequence (2 x 13 launches); x 20 = the recurrence's share of a linear step "
+                    "(two lanes overlap it by about a quarter)"}
 
 
 def hot_kernel_clock(dev):
