@@ -367,3 +367,32 @@ def test_steps_in_flight_refuses_a_model_that_is_not_on_the_gpu():
     r = m.replica()
     assert type(r) is GIMMVFI_R and r is not m and r.precision == m.precision and r.serial_launch
     assert all((a == b).all() for a, b in zip(m.state_dict().values(), r.state_dict().values()))
+
+
+def test_compact_bench_line_stays_below_2_kb_also_for_eight_ranks():
+    """bench.py prints the compact form of its record: the driver keeps a bounded tail of stdout, so the line must stay below 2 KB --
+    also with the per-rank step times of an 8-GPU run and every in-run probe in it.  Checked on the committed record of the final
+    run (profiles/r6_bench_all_final_box2.json) blown up to eight ranks."""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "r6_bench_all_final_box2.json")))
+    one = json.dumps(bench.compact_line(full, "gpurun_out/bench_full.json"))
+    assert len(one) < 2048, len(one)
+    full["n_gpus"] = 8
+    full["config"]["parallelism"] = "pair-sharded x8"
+    full["config"]["world_size_rccl"] = 8
+    full["config"]["ms_per_step_per_rank"] = [20.123 + 0.011 * r for r in range(8)]
+    full["config"]["gather_bytes_per_rank_per_step"] = 2752512
+    full["configs"] = full["configs"][:2]                 # (N > 1 times the two configurations BASELINE defines on 8 GPUs)
+    eight = json.loads(json.dumps(bench.compact_line(full, "gpurun_out/bench_full.json")))
+    assert len(json.dumps(eight)) < 2048, len(json.dumps(eight))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in eight, k
+    assert eight["config"]["steps_in_flight"] == 2 and len(eight["config"]["ms_per_step_per_rank"]) == 8
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(eight["roofline"])
